@@ -1,0 +1,247 @@
+"""CPU oracle for the KL-divergence NMF multiplicative-update path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a float64 numpy restatement of the
+algorithm in the reference `multimodal/lib/nmf.py` (+ the two helpers it pulls
+from `lib/metrics.py` and `lib/array_utils.py`, and the stacking / slicing
+logic of `multimodal/learner.py`).  It exists so that `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` have
+something to check the HIP path against.  Nothing under `multimodal_amd/` may
+import it: the product path is HIP-only and fails loudly without its extension.
+
+Parity pin: every function here is checked against golden vectors produced by
+importing the reference itself in the build container
+(`tests/golden/make_golden.py` -> `tests/golden/*.npz`,
+`tests/test_oracle_golden.py`), and against the three known-answer tests the
+reference holds (`tests/test_metrics.py:48-54`, `tests/test_array_utils.py:31-41`,
+`tests/test_nmf_kl.py:56-68`).  The dense arithmetic underneath the reference is
+numpy/OpenBLAS (third party, unpinned: reference `setup.py:34`), so agreement is
+to 1e-10 relative, not bitwise (dgemm summation order is implementation-defined).
+
+The restatement keeps the reference's behaviour *including* its quirks
+ and its redundant work (a separate W.H product for
+the loss and for the ratio), because it is also the timed CPU baseline.
+"""
+
+import sys
+
+import numpy as np
+
+EPS_RATIO = 1.e-8      # hard-coded default of _Q / error / generalized_KL
+                       # (reference nmf.py:232,297,325 and metrics.py:15)
+EPS_NORMALIZE = 1.e-16  # reference array_utils.py:19
+
+
+# ---------------------------------------------------------------- helpers ---
+
+def normalize_sum(a, axis=0, eps=EPS_NORMALIZE):
+    """a / (eps + sum(a, axis)) with the summed axis kept for broadcasting.
+
+    Follows reference multimodal/lib/array_utils.py:19-22 (ValueError when the
+    axis does not exist).
+    """
+    a = np.asarray(a)
+    if axis >= a.ndim:
+        raise ValueError
+    return a / (eps + a.sum(axis=axis, keepdims=True))
+
+
+def generalized_kl(x, y, eps=EPS_RATIO, axis=None):
+    """I-divergence sum(x*log((x+eps)/(y+eps)) - x + y).
+
+    Follows reference multimodal/lib/metrics.py:18-20.
+    """
+    x = np.asarray(x)
+    y = np.asarray(y)
+    ratio = (x + eps) / (y + eps)
+    return (x * np.log(ratio) - x + y).sum(axis=axis)
+
+
+def scale_matrix(matrix, factors, axis=0):
+    """Scale columns (axis=0) or lines (axis=1) of a 2-D array by a vector.
+
+    Follows reference multimodal/lib/nmf.py:29-49.
+    """
+    matrix = np.asarray(matrix)
+    if matrix.ndim != 2:
+        raise ValueError("expected a 2-D array, got shape %r" % (matrix.shape,))
+    if axis not in (0, 1):
+        raise ValueError("axis must be 0 or 1")
+    factors = np.squeeze(np.asarray(factors))
+    if axis == 1:
+        factors = factors[:, None]
+    return matrix * factors
+
+
+def check_input(X):
+    """Input contract of fit_transform: >=2-D, finite, non-negative.
+
+    Follows reference sklearn_utils.py:59-97 and nmf.py:23-26,193-194.
+    """
+    X = np.atleast_2d(np.asarray(X))
+    if X.dtype.kind == 'f' and not np.isfinite(X.sum()) \
+            and not np.isfinite(X).all():
+        raise ValueError("array contains NaN or infinity")
+    if (X < 0).any():
+        raise ValueError("Negative values in data passed to NMF.fit")
+    return X
+
+
+# ------------------------------------------------------- single-step rules ---
+
+def ratio_q(X, W, H, eps=EPS_RATIO):
+    """Q = (X + eps) / (W.H + eps), dense.  Reference nmf.py:325-336."""
+    return (X + eps) / (W.dot(H) + eps)
+
+
+def kl_error(X, W, H):
+    """Loss as the reference evaluates it (its own W.H product, eps=1e-8).
+
+    Reference nmf.py:297-310 -> metrics.py:18-20.
+    """
+    return generalized_kl(X, W.dot(H))
+
+
+def updated_w(X, W, H, Q=None):
+    """W * (Q.H^T) -- no denominator.  Reference nmf.py:338-343."""
+    if Q is None:
+        Q = ratio_q(X, W, H)
+    return W * Q.dot(H.T)
+
+
+def updated_h(X, W, H, Q=None):
+    """normalize_rows(H * (W^T.Q)).  Reference nmf.py:345-351."""
+    if Q is None:
+        Q = ratio_q(X, W, H)
+    return normalize_sum(H * W.T.dot(Q), axis=1)
+
+
+def update_step(X, W, H, fit=True, scale_W=False):
+    """One multiplicative update; returns (W_new, H_new).
+
+    Reference nmf.py:232-257.  Q is computed once from the *old* W; the H rule
+    then pairs that old Q with the *new* W (quirk q2).
+    """
+    if scale_W:  # reference nmf.py:246-250 (dead from every caller, kept)
+        W = scale_matrix(normalize_sum(W, axis=1), X.sum(axis=1), axis=1)
+    Q = ratio_q(X, W, H)
+    W_new = updated_w(X, W, H, Q=Q)
+    H_new = updated_h(X, W_new, H, Q=Q) if fit else H
+    return W_new, H_new
+
+
+# ------------------------------------------------------------ the hot loop ---
+
+def init_factors(X, k, H0=None, rng=None):
+    """(W0, H0): H0 given or drawn, W0 = X.H0^T.  Reference nmf.py:147-157."""
+    n, f = X.shape
+    if H0 is None:
+        draw = np.random.random if rng is None else rng.random_sample
+        H0 = normalize_sum(np.abs(draw((k, f))) + .01, axis=1)
+    else:
+        assert H0.shape == (k, f)
+    return X.dot(H0.T), H0
+
+
+def fit_transform(X, k=None, H0=None, max_iter=200, tol=1e-6, fit=True,
+                  components=None, rng=None, warn=True):
+    """The loop of reference nmf.py:159-230 as a pure function.
+
+    Returns (W, H, errors).  `errors` has one entry per *executed* update, each
+    recorded before that update (q5).  With fit=False the dictionary
+    `components` is held fixed (this is what `transform` does after setting
+    `_init_dictionary = components_`, reference nmf.py:275-291).
+    """
+    X = check_input(X)
+    n, f = X.shape
+    if not k:
+        k = f
+    if not fit:
+        H0 = components if H0 is None else H0
+    W, H = init_factors(X, k, H0=H0, rng=rng)
+    if not fit:
+        H = components
+    prev = np.inf
+    tol_abs = tol * n * f
+    errors = []
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        err = kl_error(X, W, H)
+        if prev - err < tol_abs:
+            break
+        prev = err
+        errors.append(err)
+        W, H = update_step(X, W, H, fit=fit)
+    if warn and n_iter == max_iter and tol_abs > 0:
+        sys.stderr.write("Warning: Iteration limit reached during fit\n")
+    return W, H, errors
+
+
+def transform(X, components, max_iter=200, tol=1e-6):
+    """Coefficients for a fixed dictionary.  Reference nmf.py:275-291."""
+    W, _, errors = fit_transform(X, k=components.shape[0], max_iter=max_iter,
+                                 tol=tol, fit=False, components=components)
+    return W, errors
+
+
+# ------------------------------------------------------------ learner side ---
+
+def stack_modalities(blocks, coefs):
+    """hstack of c*m.  Reference learner.py:53-56, array_utils.py:5-9."""
+    return np.hstack([c * np.asarray(m) for m, c in zip(blocks, coefs)])
+
+
+def axis_range(dims, idx):
+    """Column range of modality idx.  Reference learner.py:58-62."""
+    start = sum(dims[:idx])
+    return start, start + dims[idx]
+
+
+def learner_train(blocks, coefs, k, iterations, H0):
+    """MultimodalLearner.train: tol=0 fit of the stacked matrix.
+
+    Reference learner.py:31-41.  Returns (dico, W).
+    """
+    V = stack_modalities(blocks, coefs)
+    W, H, _ = fit_transform(V, k=k, H0=H0, max_iter=iterations, tol=0)
+    return H, W
+
+
+def learner_internal(blocks, coefs, dico_slices, iterations):
+    """reconstruct_internal_multi: transform against column-sliced dictionary.
+
+    Reference learner.py:67-78 + fit_coefficients learner.py:11-15.
+    """
+    V = stack_modalities(blocks, coefs)
+    D = np.hstack(dico_slices)
+    W, _ = transform(V, D, max_iter=iterations, tol=0)
+    return W
+
+
+# ---------------------------------------------------- synthetic workload ---
+
+def synthetic_block(base_seed, b, rows, f, k_true, Ht=None):
+    """Row block b of the seeded factorisable+noise V of SURVEY.md section 8d."""
+    if Ht is None:
+        Ht = synthetic_Ht(base_seed, f, k_true)
+    rs = np.random.RandomState(base_seed + 1 + b)
+    Wt = rs.gamma(1.0, 1.0, (rows, k_true))
+    return Wt.dot(Ht) / k_true + 0.05 * rs.random_sample((rows, f))
+
+
+def synthetic_Ht(base_seed, f, k_true):
+    return np.random.RandomState(base_seed).gamma(0.5, 1.0, (k_true, f))
+
+
+def synthetic_V(base_seed, n, f, k_true, block=8192):
+    Ht = synthetic_Ht(base_seed, f, k_true)
+    out = np.empty((n, f))
+    for b, r0 in enumerate(range(0, n, block)):
+        r1 = min(n, r0 + block)
+        out[r0:r1] = synthetic_block(base_seed, b, r1 - r0, f, k_true, Ht)
+    return out
+
+
+def synthetic_H0(base_seed, f, k):
+    return normalize_sum(
+        np.random.RandomState(base_seed - 1).random_sample((k, f)) + .01,
+        axis=1)

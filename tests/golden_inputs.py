@@ -1,0 +1,69 @@
+"""Seeded inputs shared by the golden-vector generator and the tests.
+
+`gen_inputs` must stay byte-for-byte equivalent in behaviour to the function of
+the same name in tests/golden/make_golden.py (the fixtures store only seeds and
+reference outputs; inputs are regenerated from the legacy RandomState stream).
+"""
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False)
+
+
+def _normalize_rows(a):
+    return a / (1e-16 + a.sum(axis=1, keepdims=True))
+
+
+def gen_inputs(seed, n, f, k):
+    rs = np.random.RandomState(seed)
+    X = np.abs(rs.random_sample((n, f)))
+    H0 = _normalize_rows(np.abs(rs.random_sample((k, f))) + .01)
+    return X, H0
+
+
+def g2_inputs(g):
+    seed, n, f, k = int(g['seed']), int(g['n']), int(g['f']), int(g['k'])
+    X, H0 = gen_inputs(seed, n, f, k)
+    Xt = np.abs(np.random.RandomState(seed + 1).random_sample((17, f)))
+    return X, H0, Xt
+
+
+def g3_inputs(g):
+    seed, n, f, k = int(g['seed']), int(g['n']), int(g['f']), int(g['k'])
+    rs = np.random.RandomState(seed)
+    X = np.abs(rs.random_sample((n, f)))
+    W = np.abs(rs.random_sample((n, k)))
+    H = np.abs(rs.random_sample((k, f)))
+    return X, W, H
+
+
+def g5_inputs(g):
+    seed, n, k = int(g['seed']), int(g['n']), int(g['k'])
+    dims = [int(d) for d in g['dims']]
+    rs = np.random.RandomState(seed)
+    blocks = [np.abs(rs.random_sample((n, d))) for d in dims]
+    f = sum(dims)
+    H0 = _normalize_rows(np.abs(rs.random_sample((k, f))) + .01)
+    test = [np.abs(rs.random_sample((7, d))) for d in dims]
+    return blocks, dims, H0, test
+
+
+def g6_inputs(g):
+    seed, n, f, k = int(g['seed']), int(g['n']), int(g['f']), int(g['k'])
+    rs = np.random.RandomState(seed)
+    dense = np.abs(rs.random_sample((n, f))) * (rs.random_sample((n, f)) < .5)
+    W = np.abs(rs.random_sample((n, k)))
+    H = np.abs(rs.random_sample((k, f)))
+    return dense, W, H
+
+
+def g8_edge_inputs():
+    X, H0 = gen_inputs(81, 12, 9, 3)
+    X[4, :] = 0
+    X[:, 2] = 0
+    return X, H0
