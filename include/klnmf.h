@@ -1,0 +1,179 @@
+/* klnmf.h -- C-ABI of the MI355X-native KL-divergence NMF hot path.
+ *
+ * This is the drop-in boundary for the multiplicative-update loop of
+ * omangin/multimodal (`multimodal/lib/nmf.py`).  Every entry point below names
+ * the reference interface it replaces (file:line, relative to the reference
+ * root).  Plain pointers and sizes only; no exceptions cross the boundary:
+ * every function returns an int status (0 = ok, <0 = error class) and the
+ * message for the calling thread is available from klnmf_last_error().
+ *
+ * One context = one GPU (one process per GPU in the multi-GPU case; the
+ * collective between shards is issued by the host between klnmf_iter_* calls,
+ * see INTEGRATION.md).  A context is used from one thread at a time; different
+ * contexts may be used from different threads.  All calls are asynchronous on
+ * the context's stream unless they return data to the host.
+ *
+ * Matrices named as in the reference: V/X [n,f] data (rows = samples),
+ * W [n,k] coefficients, H [k,f] dictionary (`components_`), Q [n,f] ratio.
+ */
+#ifndef KLNMF_H
+#define KLNMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLNMF_VERSION 100            /* 0.1.0 */
+
+/* status codes */
+#define KLNMF_OK            0
+#define KLNMF_ERR_ARG      -1        /* bad argument / wrong state        */
+#define KLNMF_ERR_ALLOC    -2        /* device or host allocation failed  */
+#define KLNMF_ERR_HIP      -3        /* HIP runtime error                 */
+#define KLNMF_ERR_UNSUPP   -4        /* shape not supported by this mode  */
+
+/* arithmetic modes */
+#define KLNMF_PREC_F64      0        /* fp64 everywhere (reference arithmetic)      */
+#define KLNMF_PREC_F32      1        /* fp32 everywhere                              */
+#define KLNMF_PREC_BF16     2        /* bf16 MFMA operands, fp32 accumulate/masters, V stored bf16 */
+#define KLNMF_PREC_BF16_V32 3        /* as BF16 but V stored fp32                    */
+
+/* host element types for uploads / downloads */
+#define KLNMF_DT_F32        0
+#define KLNMF_DT_F64        1
+
+typedef struct klnmf_ctx klnmf_ctx;
+
+/* ---- library / device -------------------------------------------------- */
+int         klnmf_version(void);
+const char *klnmf_last_error(void);
+/* arch string (e.g. "gfx950"), CU count, HBM bytes: roofline constants for bench.py */
+int         klnmf_device_info(int device, char *arch, int arch_len,
+                              int *cu_count, uint64_t *hbm_bytes);
+
+/* ---- context ----------------------------------------------------------- */
+/* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for an
+ * own stream.  Replaces constructing KLdivNMF (nmf.py:136-145) + the implicit
+ * "everything lives in host numpy arrays" of the reference. */
+int klnmf_create(klnmf_ctx **out, int device, int precision, void *stream);
+int klnmf_destroy(klnmf_ctx *ctx);
+
+/* Declare the local problem: n rows held by this context, f features, k
+ * components, and the capacity of the per-iteration loss record.
+ * (nmf.py:196-199: shapes taken from X and n_components.) */
+int klnmf_set_problem(klnmf_ctx *ctx, int64_t n, int64_t f, int64_t k,
+                      int64_t max_iter_capacity);
+
+/* ---- data in ------------------------------------------------------------ */
+/* Upload the sub-block V[row0:row0+rows, col0:col0+cols] = scale * src, src a
+ * host array with leading dimension ld (elements).  One call per modality
+ * block replaces learner.py:53-56 (`safe_hstack([c * m ...])`): the scale,
+ * cast and column placement are fused into the upload (K6). */
+int klnmf_upload_V(klnmf_ctx *ctx, const void *src, int dtype,
+                   int64_t rows, int64_t cols, int64_t ld,
+                   int64_t row0, int64_t col0, double scale);
+/* Same from a device-resident fp32 block (bench / device-side pipelines). */
+int klnmf_upload_V_device(klnmf_ctx *ctx, const float *dsrc,
+                          int64_t rows, int64_t cols, int64_t ld,
+                          int64_t row0, int64_t col0, double scale);
+/* Dictionary [k,f], C order (nmf.py:149-155 `_init_dictionary`, learner.py:13
+ * `components_ = dictionary`). */
+int klnmf_set_H(klnmf_ctx *ctx, const void *src, int dtype);
+/* Coefficients [n,k], C order (tests call `_update(X, W)` with their own W). */
+int klnmf_set_W(klnmf_ctx *ctx, const void *src, int dtype);
+/* Ratio [n,f] given by the caller (nmf.py:338-351: the `Q=` argument).
+ * F64/F32 modes only. */
+int klnmf_set_Q(klnmf_ctx *ctx, const void *src, int dtype);
+
+/* ---- the path ----------------------------------------------------------- */
+/* W0 = V . H^T  (nmf.py:156). */
+int klnmf_init_W(klnmf_ctx *ctx);
+
+/* The whole loop of nmf.py:212-222 on the device, single GPU:
+ *   for it in 1..max_iter: err = error(); if prev - err < tol_abs: break;
+ *                          errors.append(err); W (and H if fit) = update
+ * errors_out receives n_done losses (each recorded before its update);
+ * *stopped = 1 when the stop rule fired (the break), 0 when the limit ended
+ * the loop.  Synchronous. */
+int klnmf_run(klnmf_ctx *ctx, int64_t max_iter, int fit, double tol_abs,
+              double *errors_out, int64_t *n_done, int *stopped);
+
+/* The same loop in pieces, for the row-sharded multi-GPU case: the host issues
+ * the collective between the pieces (sum of the exchange buffers over ranks).
+ *   klnmf_loop_begin                          reset prev_error / counters
+ *   per iteration:
+ *     klnmf_iter_rowpass   loss partial + W update        -> loss exchange
+ *     [all-reduce loss exchange]
+ *     klnmf_iter_decide    stop rule (nmf.py:214-220)
+ *     klnmf_iter_colpass   H numerator W_new^T . Q_old    -> numerator exchange
+ *     [all-reduce numerator exchange]
+ *     klnmf_iter_update_H  H * num, row-normalise (nmf.py:349-350)
+ *     klnmf_iter_advance   swap the W_old / W_new buffers
+ *   klnmf_loop_end         sync, fetch errors / counters
+ * After the stop rule fires every later piece is a no-op on the device, so the
+ * host may enqueue all max_iter iterations without synchronising. */
+int klnmf_loop_begin(klnmf_ctx *ctx);
+int klnmf_iter_rowpass(klnmf_ctx *ctx, int fit);
+int klnmf_iter_decide(klnmf_ctx *ctx, double tol_abs);
+int klnmf_iter_colpass(klnmf_ctx *ctx);
+int klnmf_iter_update_H(klnmf_ctx *ctx);
+/* advance the W ping-pong after one iteration's pieces have been enqueued */
+int klnmf_iter_advance(klnmf_ctx *ctx);
+int klnmf_loop_end(klnmf_ctx *ctx, double *errors_out, int64_t *n_done,
+                   int *stopped);
+/* Device pointers of the two exchange buffers (what the collective sums):
+ * loss: 2 doubles; numerator: *numer_count elements of fp32 (BF16 modes, F32)
+ * or fp64 (F64).  The buffers are owned by the context. */
+int klnmf_exchange_buffers(klnmf_ctx *ctx, void **loss_ptr, void **numer_ptr,
+                           int64_t *numer_count, int *numer_is_f64);
+/* Use caller-owned device buffers as the exchange buffers instead (e.g. torch
+ * tensors handed to torch.distributed.all_reduce): loss_ptr >= 2 doubles,
+ * numer_ptr >= numer_count elements.  NULL keeps the current buffer. */
+int klnmf_bind_exchange(klnmf_ctx *ctx, void *loss_ptr, void *numer_ptr);
+
+/* Step-granular entry points (unit parity with the reference's private
+ * methods).  Synchronous. */
+/* error(X, W, H)                      nmf.py:297-310 + metrics.py:18-20 */
+int klnmf_error(klnmf_ctx *ctx, double *loss);
+/* one _update(X, W, _fit) without stop rule: nmf.py:232-257 */
+int klnmf_update(klnmf_ctx *ctx, int fit);
+/* eps of klnmf_step_Q (the `eps=` argument of _Q, nmf.py:325; default 1e-8).
+ * The loop itself always uses 1e-8, as the reference does (nmf.py:232,251). */
+int klnmf_set_ratio_eps(klnmf_ctx *ctx, double eps);
+/* Q = (V+eps)/(W.H+eps) into the context's Q buffer (F64/F32 modes): nmf.py:325-336 */
+int klnmf_step_Q(klnmf_ctx *ctx);
+/* W <- W * (Q . H^T) with the Q buffer: nmf.py:338-343 */
+int klnmf_step_W(klnmf_ctx *ctx);
+/* H <- normalize_rows(H * (W^T . Q)) with the Q buffer: nmf.py:345-351 */
+int klnmf_step_H(klnmf_ctx *ctx);
+/* generalized_KL(x, y) of two host arrays of `count` elements: metrics.py:18-20 */
+int klnmf_generalized_kl(klnmf_ctx *ctx, const void *x, const void *y, int dtype,
+                         int64_t count, double eps, double *out);
+
+/* ---- data out ----------------------------------------------------------- */
+int klnmf_get_W(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,k] */
+int klnmf_get_H(klnmf_ctx *ctx, void *dst, int dtype);   /* [k,f] */
+int klnmf_get_Q(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,f], F64/F32 modes */
+
+/* ---- measurement -------------------------------------------------------- */
+/* When enabled, every row-pass / column-pass launch is bracketed by HIP events
+ * on the context's stream; klnmf_profile_read returns launch counts and summed
+ * milliseconds since the last reset (synchronises). */
+int klnmf_profile_enable(klnmf_ctx *ctx, int on);
+int klnmf_profile_read(klnmf_ctx *ctx, int64_t *rowpass_launches,
+                       double *rowpass_ms, int64_t *colpass_launches,
+                       double *colpass_ms, int reset);
+int klnmf_synchronize(klnmf_ctx *ctx);
+
+/* ---- hardware probes (tests) -------------------------------------------- */
+/* Runs the MFMA / LDS-transpose layout self-checks the fused kernels rely on;
+ * *failed = bitmask of failing probes (0 = all good). */
+int klnmf_selftest(int device, int *failed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLNMF_H */

@@ -1,0 +1,344 @@
+"""ctypes binding of libklnmf.so (the C-ABI declared in include/klnmf.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device
+is usable, everything that computes raises.  The binding mirrors the header one
+to one; `Context` is a thin RAII wrapper used by `lib/nmf.py`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libklnmf.so')
+
+PREC_F64, PREC_F32, PREC_BF16, PREC_BF16_V32 = 0, 1, 2, 3
+PRECISIONS = {'f64': PREC_F64, 'fp64': PREC_F64, 'float64': PREC_F64,
+              'f32': PREC_F32, 'fp32': PREC_F32, 'float32': PREC_F32,
+              'bf16': PREC_BF16, 'bf16_v32': PREC_BF16_V32}
+DT_F32, DT_F64 = 0, 1
+
+ERR_ARG, ERR_ALLOC, ERR_HIP, ERR_UNSUPP = -1, -2, -3, -4
+
+_c = ctypes
+_ctx_p = _c.c_void_p
+_i64 = _c.c_int64
+
+# name -> (restype, argtypes); must list every symbol of include/klnmf.h
+SIGNATURES = {
+    'klnmf_version': (_c.c_int, []),
+    'klnmf_last_error': (_c.c_char_p, []),
+    'klnmf_device_info': (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_int,
+                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64)]),
+    'klnmf_create': (_c.c_int, [_c.POINTER(_ctx_p), _c.c_int, _c.c_int, _c.c_void_p]),
+    'klnmf_destroy': (_c.c_int, [_ctx_p]),
+    'klnmf_set_problem': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64]),
+    'klnmf_upload_V': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64, _i64, _i64,
+                                  _i64, _i64, _c.c_double]),
+    'klnmf_upload_V_device': (_c.c_int, [_ctx_p, _c.c_void_p, _i64, _i64, _i64, _i64,
+                                         _i64, _c.c_double]),
+    'klnmf_set_H': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
+    'klnmf_set_W': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
+    'klnmf_set_Q': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
+    'klnmf_init_W': (_c.c_int, [_ctx_p]),
+    'klnmf_run': (_c.c_int, [_ctx_p, _i64, _c.c_int, _c.c_double,
+                             _c.POINTER(_c.c_double), _c.POINTER(_i64),
+                             _c.POINTER(_c.c_int)]),
+    'klnmf_loop_begin': (_c.c_int, [_ctx_p]),
+    'klnmf_iter_rowpass': (_c.c_int, [_ctx_p, _c.c_int]),
+    'klnmf_iter_decide': (_c.c_int, [_ctx_p, _c.c_double]),
+    'klnmf_iter_colpass': (_c.c_int, [_ctx_p]),
+    'klnmf_iter_update_H': (_c.c_int, [_ctx_p]),
+    'klnmf_iter_advance': (_c.c_int, [_ctx_p]),
+    'klnmf_loop_end': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double), _c.POINTER(_i64),
+                                  _c.POINTER(_c.c_int)]),
+    'klnmf_exchange_buffers': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_void_p),
+                                          _c.POINTER(_c.c_void_p), _c.POINTER(_i64),
+                                          _c.POINTER(_c.c_int)]),
+    'klnmf_bind_exchange': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_void_p]),
+    'klnmf_error': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double)]),
+    'klnmf_update': (_c.c_int, [_ctx_p, _c.c_int]),
+    'klnmf_set_ratio_eps': (_c.c_int, [_ctx_p, _c.c_double]),
+    'klnmf_step_Q': (_c.c_int, [_ctx_p]),
+    'klnmf_step_W': (_c.c_int, [_ctx_p]),
+    'klnmf_step_H': (_c.c_int, [_ctx_p]),
+    'klnmf_generalized_kl': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_void_p, _c.c_int, _i64,
+                                        _c.c_double, _c.POINTER(_c.c_double)]),
+    'klnmf_get_W': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
+    'klnmf_get_H': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
+    'klnmf_get_Q': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
+    'klnmf_profile_enable': (_c.c_int, [_ctx_p, _c.c_int]),
+    'klnmf_profile_read': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double),
+                                      _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.c_int]),
+    'klnmf_synchronize': (_c.c_int, [_ctx_p]),
+    'klnmf_selftest': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_int)]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    """A non-zero status from the C-ABI."""
+
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "klnmf error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libklnmf.so and declare every entry point.  Raises if it is absent:
+    the product path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "HIP extension %s is missing; build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if a symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(status):
+    if status != 0:
+        msg = load().klnmf_last_error()
+        msg = msg.decode('utf-8', 'replace') if msg else ''
+        if status == ERR_ALLOC:
+            raise MemoryError("klnmf: " + msg)
+        raise NativeError(status, msg)
+
+
+def _np_dtype_code(a):
+    if a.dtype == np.float64:
+        return DT_F64
+    if a.dtype == np.float32:
+        return DT_F32
+    raise TypeError("expected float32/float64, got %s" % a.dtype)
+
+
+def _as_float_array(a):
+    """C-contiguous float32/float64 view or copy of a (ints -> float64)."""
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    return np.ascontiguousarray(a)
+
+
+def device_info(device=0):
+    lib = load()
+    arch = ctypes.create_string_buffer(64)
+    cu = _c.c_int(0)
+    mem = _c.c_uint64(0)
+    _check(lib.klnmf_device_info(device, arch, 64, ctypes.byref(cu), ctypes.byref(mem)))
+    return {'arch': arch.value.decode(), 'cu_count': cu.value, 'hbm_bytes': mem.value}
+
+
+def selftest(device=0):
+    lib = load()
+    failed = _c.c_int(-1)
+    _check(lib.klnmf_selftest(device, ctypes.byref(failed)))
+    return failed.value
+
+
+class Context(object):
+    """One GPU-resident KL-NMF problem (V, W, H on the device)."""
+
+    def __init__(self, precision='f64', device=0, stream=None):
+        self._lib = load()
+        self._h = _ctx_p()
+        if isinstance(precision, str):
+            precision = PRECISIONS[precision]
+        self.precision = precision
+        _check(self._lib.klnmf_create(ctypes.byref(self._h), device, precision,
+                                      _c.c_void_p(stream) if stream else None))
+        self.n = self.f = self.k = 0
+        self.cap = 0
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.klnmf_destroy(self._h)
+            self._h = _ctx_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def exact(self):
+        return self.precision in (PREC_F64, PREC_F32)
+
+    # -- data in --
+    def set_problem(self, n, f, k, max_iter_capacity):
+        _check(self._lib.klnmf_set_problem(self._h, n, f, k, max(1, max_iter_capacity)))
+        self.n, self.f, self.k, self.cap = n, f, k, max(1, max_iter_capacity)
+
+    def upload_V(self, block, row0=0, col0=0, scale=1.0):
+        """V[row0:, col0:] block = scale * block (any strides; row-major view
+        is uploaded without a host copy when rows are contiguous)."""
+        a = np.asarray(block)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        if a.ndim != 2:
+            raise ValueError("2-D block expected")
+        if a.shape[0] == 0 or a.shape[1] == 0:
+            return
+        if a.strides[1] != a.itemsize or a.strides[0] % a.itemsize or \
+                a.strides[0] < a.shape[1] * a.itemsize:
+            a = np.ascontiguousarray(a)
+        ld = a.strides[0] // a.itemsize
+        _check(self._lib.klnmf_upload_V(self._h, a.ctypes.data, _np_dtype_code(a),
+                                        a.shape[0], a.shape[1], ld, row0, col0,
+                                        float(scale)))
+
+    def upload_V_device(self, dev_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
+        _check(self._lib.klnmf_upload_V_device(self._h, _c.c_void_p(dev_ptr), rows, cols, ld,
+                                               row0, col0, float(scale)))
+
+    def set_H(self, H):
+        H = _as_float_array(H)
+        assert H.shape == (self.k, self.f)
+        _check(self._lib.klnmf_set_H(self._h, H.ctypes.data, _np_dtype_code(H)))
+
+    def set_W(self, W):
+        W = _as_float_array(W)
+        assert W.shape == (self.n, self.k)
+        _check(self._lib.klnmf_set_W(self._h, W.ctypes.data, _np_dtype_code(W)))
+
+    def set_Q(self, Q):
+        Q = _as_float_array(Q)
+        assert Q.shape == (self.n, self.f)
+        _check(self._lib.klnmf_set_Q(self._h, Q.ctypes.data, _np_dtype_code(Q)))
+
+    # -- the path --
+    def init_W(self):
+        _check(self._lib.klnmf_init_W(self._h))
+
+    def run(self, max_iter, fit, tol_abs):
+        """Returns (errors list, n_done, stopped)."""
+        max_iter = int(max_iter)
+        if max_iter > self.cap:
+            raise ValueError("max_iter exceeds capacity")
+        errs = np.zeros(max(1, max_iter), dtype=np.float64)
+        nd = _i64(0)
+        stopped = _c.c_int(0)
+        _check(self._lib.klnmf_run(self._h, max_iter, 1 if fit else 0, float(tol_abs),
+                                   errs.ctypes.data_as(_c.POINTER(_c.c_double)),
+                                   ctypes.byref(nd), ctypes.byref(stopped)))
+        return [float(e) for e in errs[:nd.value]], nd.value, bool(stopped.value)
+
+    def loop_begin(self):
+        _check(self._lib.klnmf_loop_begin(self._h))
+
+    def iter_rowpass(self, fit=True):
+        _check(self._lib.klnmf_iter_rowpass(self._h, 1 if fit else 0))
+
+    def iter_decide(self, tol_abs):
+        _check(self._lib.klnmf_iter_decide(self._h, float(tol_abs)))
+
+    def iter_colpass(self):
+        _check(self._lib.klnmf_iter_colpass(self._h))
+
+    def iter_update_H(self):
+        _check(self._lib.klnmf_iter_update_H(self._h))
+
+    def iter_advance(self):
+        _check(self._lib.klnmf_iter_advance(self._h))
+
+    def loop_end(self, max_iter):
+        errs = np.zeros(max(1, int(max_iter)), dtype=np.float64)
+        nd = _i64(0)
+        stopped = _c.c_int(0)
+        _check(self._lib.klnmf_loop_end(self._h, errs.ctypes.data_as(_c.POINTER(_c.c_double)),
+                                        ctypes.byref(nd), ctypes.byref(stopped)))
+        return [float(e) for e in errs[:nd.value]], nd.value, bool(stopped.value)
+
+    def exchange_buffers(self):
+        """(loss_ptr, numer_ptr, numer_count, numer_is_f64) device pointers."""
+        lp, npt = _c.c_void_p(), _c.c_void_p()
+        cnt = _i64(0)
+        is64 = _c.c_int(0)
+        _check(self._lib.klnmf_exchange_buffers(self._h, ctypes.byref(lp), ctypes.byref(npt),
+                                                ctypes.byref(cnt), ctypes.byref(is64)))
+        return lp.value, npt.value, cnt.value, bool(is64.value)
+
+    def bind_exchange(self, loss_ptr, numer_ptr):
+        _check(self._lib.klnmf_bind_exchange(self._h, _c.c_void_p(loss_ptr),
+                                             _c.c_void_p(numer_ptr)))
+
+    def error(self):
+        out = _c.c_double(0)
+        _check(self._lib.klnmf_error(self._h, ctypes.byref(out)))
+        return out.value
+
+    def update(self, fit=True):
+        _check(self._lib.klnmf_update(self._h, 1 if fit else 0))
+
+    def set_ratio_eps(self, eps):
+        _check(self._lib.klnmf_set_ratio_eps(self._h, float(eps)))
+
+    def step_Q(self):
+        _check(self._lib.klnmf_step_Q(self._h))
+
+    def step_W(self):
+        _check(self._lib.klnmf_step_W(self._h))
+
+    def step_H(self):
+        _check(self._lib.klnmf_step_H(self._h))
+
+    def generalized_kl(self, x, y, eps):
+        x = _as_float_array(x).ravel()
+        y = _as_float_array(y).ravel()
+        if x.dtype != y.dtype:
+            x = x.astype(np.float64)
+            y = y.astype(np.float64)
+        out = _c.c_double(0)
+        _check(self._lib.klnmf_generalized_kl(self._h, x.ctypes.data, y.ctypes.data,
+                                              _np_dtype_code(x), x.size, float(eps),
+                                              ctypes.byref(out)))
+        return out.value
+
+    # -- data out --
+    def _get(self, fn, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        _check(fn(self._h, out.ctypes.data, _np_dtype_code(out)))
+        return out
+
+    def get_W(self, dtype=np.float64):
+        return self._get(self._lib.klnmf_get_W, (self.n, self.k), dtype)
+
+    def get_H(self, dtype=np.float64):
+        return self._get(self._lib.klnmf_get_H, (self.k, self.f), dtype)
+
+    def get_Q(self, dtype=np.float64):
+        return self._get(self._lib.klnmf_get_Q, (self.n, self.f), dtype)
+
+    # -- measurement --
+    def profile_enable(self, on=True):
+        _check(self._lib.klnmf_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        rn, cn = _i64(0), _i64(0)
+        rms, cms = _c.c_double(0), _c.c_double(0)
+        _check(self._lib.klnmf_profile_read(self._h, ctypes.byref(rn), ctypes.byref(rms),
+                                            ctypes.byref(cn), ctypes.byref(cms),
+                                            1 if reset else 0))
+        return {'rowpass_launches': rn.value, 'rowpass_ms': rms.value,
+                'colpass_launches': cn.value, 'colpass_ms': cms.value}
+
+    def synchronize(self):
+        _check(self._lib.klnmf_synchronize(self._h))

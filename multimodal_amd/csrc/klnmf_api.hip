@@ -1,0 +1,1035 @@
+// C-ABI of the MI355X-native KL-NMF path (see include/klnmf.h for the contract
+// and the reference interfaces each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/klnmf.h"
+#include "common.hip.h"
+#include "exact.hip.h"
+#include "mfma.hip.h"
+#include "probe.hip.h"
+
+using namespace klnmf;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct ApiError {
+    int code;
+    std::string msg;
+};
+
+[[noreturn]] void fail(int code, const std::string &m) { throw ApiError{code, m}; }
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            fail(e_ == hipErrorOutOfMemory ? KLNMF_ERR_ALLOC : KLNMF_ERR_HIP,              \
+                 std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        f();
+        return KLNMF_OK;
+    } catch (const ApiError &e) {
+        g_err = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return KLNMF_ERR_HIP;
+    } catch (...) {
+        g_err = "unknown error";
+        return KLNMF_ERR_HIP;
+    }
+}
+
+int grid_for(int64_t count, int block = 256, int cap = 4096) {
+    int64_t g = (count + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct klnmf_ctx {
+    int device = 0;
+    int prec = KLNMF_PREC_F64;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+
+    int64_t n = 0, f = 0, k = 0, cap = 0;
+    bool have_problem = false;
+    int cur = 0;          // index of the current W buffer
+    int loop_start_cur = 0;
+    int64_t loop_iters = 0;
+
+    // common device state
+    DevState *st = nullptr;
+    double *errors = nullptr;
+    double *loss_xchg = nullptr;
+    std::vector<void *> allocs;
+
+    // exact modes (T = double or float)
+    void *V = nullptr, *W[2] = {nullptr, nullptr}, *H = nullptr, *Q = nullptr;
+    void *Npart = nullptr, *numer = nullptr;
+    double *loss_part = nullptr;
+    int64_t loss_part_count = 0;
+    int nsplit = 1, kchunk = 0;
+
+    // bf16 modes
+    int KT = 0, KP = 0, ks = 0;
+    int64_t n_pad = 0, f_pad = 0, w_rows = 0;
+    int nrt = 0, nct = 0, nst = 0, ncb = 0, nchunks = 0, stages_per_chunk = 0;
+    void *VtA = nullptr, *VtB = nullptr;
+    float *W32[2] = {nullptr, nullptr};
+    __bf16 *Wb[2] = {nullptr, nullptr};
+    float *H32 = nullptr;
+    __bf16 *Ht = nullptr, *HTb = nullptr;
+    float *NpartF = nullptr, *numerF = nullptr;
+    float2 *loss_part2 = nullptr;
+
+    // profiling
+    double ratio_eps = kEpsRatio;   // only the step API honours a non-default value
+
+    bool profiling = false;
+    std::vector<EventPair> ev_row, ev_col;
+
+    bool is_exact() const { return prec == KLNMF_PREC_F64 || prec == KLNMF_PREC_F32; }
+    size_t esize() const { return prec == KLNMF_PREC_F64 ? 8 : 4; }
+    size_t vsize() const { return prec == KLNMF_PREC_BF16 ? 2 : 4; }
+
+    void *dalloc(size_t bytes, bool zero = true) {
+        void *p = nullptr;
+        if (bytes == 0) bytes = 16;
+        HIPCHK(hipMalloc(&p, bytes));
+        allocs.push_back(p);
+        if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, stream));
+        return p;
+    }
+    void free_all() {
+        for (void *p : allocs) (void)hipFree(p);
+        allocs.clear();
+        for (auto &e : ev_row) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto &e : ev_col) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        ev_row.clear();
+        ev_col.clear();
+        have_problem = false;
+    }
+};
+
+namespace {
+
+void use(klnmf_ctx *c) {
+    if (!c) fail(KLNMF_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+}
+void need_problem(klnmf_ctx *c) {
+    use(c);
+    if (!c->have_problem) fail(KLNMF_ERR_ARG, "klnmf_set_problem has not been called");
+}
+
+EventPair begin_event(klnmf_ctx *c, std::vector<EventPair> &v) {
+    EventPair e{};
+    HIPCHK(hipEventCreate(&e.a));
+    HIPCHK(hipEventCreate(&e.b));
+    HIPCHK(hipEventRecord(e.a, c->stream));
+    v.push_back(e);
+    return e;
+}
+
+// ---------------------------------------------------------------- dispatch ---
+template <int MODE, typename VT>
+void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
+#define KL_ROW_CASE(KTV)                                                                        \
+    case KTV: {                                                                                 \
+        auto kern = k_rowpass<KTV, MODE, VT>;                                                   \
+        const int lds = 2 * h_stage_lds(32 * KTV);                                              \
+        static thread_local int attr_dev = -1;                                                  \
+        if (attr_dev != c->device) {                                                            \
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr_dev = c->device;                                                               \
+        }                                                                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);                \
+        break;                                                                                  \
+    }
+    switch (c->KT) {
+        KL_ROW_CASE(1) KL_ROW_CASE(2) KL_ROW_CASE(3) KL_ROW_CASE(4)
+        KL_ROW_CASE(5) KL_ROW_CASE(6) KL_ROW_CASE(7) KL_ROW_CASE(8)
+        default: fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels");
+    }
+#undef KL_ROW_CASE
+    HIPCHK(hipGetLastError());
+}
+
+template <typename VT>
+void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
+#define KL_COL_CASE(KTV)                                                                        \
+    case KTV: {                                                                                 \
+        auto kern = k_colpass<KTV, VT>;                                                         \
+        const int lds = 4 * w_stage_lds(32 * KTV);                                              \
+        static thread_local int attr_dev = -1;                                                  \
+        if (attr_dev != c->device) {                                                            \
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr_dev = c->device;                                                               \
+        }                                                                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);                \
+        break;                                                                                  \
+    }
+    switch (c->KT) {
+        KL_COL_CASE(1) KL_COL_CASE(2) KL_COL_CASE(3) KL_COL_CASE(4)
+        KL_COL_CASE(5) KL_COL_CASE(6) KL_COL_CASE(7) KL_COL_CASE(8)
+        default: fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels");
+    }
+#undef KL_COL_CASE
+    HIPCHK(hipGetLastError());
+}
+
+void fast_rowpass(klnmf_ctx *c, int mode) {
+    RowPassArgs a{};
+    a.VtA = c->VtA;
+    a.Ht = c->Ht;
+    a.Wb_old = c->Wb[c->cur];
+    a.W32_old = c->W32[c->cur];
+    a.Wb_new = c->Wb[c->cur ^ 1];
+    a.W32_new = c->W32[c->cur ^ 1];
+    a.loss_part = c->loss_part2;
+    a.st = c->st;
+    a.nrt = c->nrt;
+    a.nct = c->nct;
+    a.nst = c->nst;
+    a.ks = c->ks;
+    const int grid = (c->nrt + kWavesPerWG - 1) / kWavesPerWG;
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_row);
+    const bool v16 = c->prec == KLNMF_PREC_BF16;
+    switch (mode) {
+        case ROW_UPDATE:
+            v16 ? launch_rowpass_kt<ROW_UPDATE, __bf16>(c, a, grid) : launch_rowpass_kt<ROW_UPDATE, float>(c, a, grid);
+            break;
+        case ROW_INIT:
+            v16 ? launch_rowpass_kt<ROW_INIT, __bf16>(c, a, grid) : launch_rowpass_kt<ROW_INIT, float>(c, a, grid);
+            break;
+        default:
+            v16 ? launch_rowpass_kt<ROW_LOSS, __bf16>(c, a, grid) : launch_rowpass_kt<ROW_LOSS, float>(c, a, grid);
+            break;
+    }
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+}
+
+void fast_colpass(klnmf_ctx *c) {
+    ColPassArgs a{};
+    a.VtB = c->VtB;
+    a.HTb = c->HTb;
+    a.Wb_old = c->Wb[c->cur];
+    a.Wb_new = c->Wb[c->cur ^ 1];
+    a.Npart = c->NpartF;
+    a.st = c->st;
+    a.nrt = c->nrt;
+    a.nct = c->nct;
+    a.ncb = c->ncb;
+    a.nchunks = c->nchunks;
+    a.stages_per_chunk = c->stages_per_chunk;
+    a.ks = c->ks;
+    a.f_pad = c->f_pad;
+    const int grid = c->ncb * c->nchunks;
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_col);
+    if (c->prec == KLNMF_PREC_BF16) launch_colpass_kt<__bf16>(c, a, grid);
+    else launch_colpass_kt<float>(c, a, grid);
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    const int64_t count = (int64_t)c->KP * c->f_pad;
+    hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4)), dim3(256), 0, c->stream,
+                       (const float *)c->NpartF, c->numerF, count / 4, c->nchunks,
+                       (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
+void fast_pack_H(klnmf_ctx *c, int do_update) {
+    hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
+                       (const float *)c->numerF, c->Ht, c->HTb, c->f, c->f_pad, c->KP, do_update,
+                       do_update ? (const DevState *)c->st : (const DevState *)nullptr);
+    HIPCHK(hipGetLastError());
+}
+
+// ------------------------------------------------------------ exact pieces ---
+template <typename T>
+void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
+    EpiQ<T> epi{(const T *)c->V, (T *)c->Q, c->f, c->loss_part, write_q, 0.0, (T)eps};
+    dim3 grid((unsigned)((c->f + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), 1);
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_row);
+    hipLaunchKernelGGL((k_gemm<T, EpiQ<T>>), grid, dim3(256), 0, c->stream, (int)c->n, (int)c->f,
+                       (int)c->k, (const T *)c->W[c->cur], (int64_t)c->k, (int64_t)1,
+                       (const T *)c->H, (int64_t)c->f, (int64_t)1, (int)c->k + GK,
+                       (const DevState *)c->st, epi);
+    HIPCHK(hipGetLastError());
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    hipLaunchKernelGGL(k_sum_doubles, dim3(1), dim3(1024), 0, c->stream,
+                       (const double *)c->loss_part, c->loss_part_count, c->loss_xchg,
+                       (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
+// W_new = W * (Qsrc . H^T)   (multiply=0: W_new = Qsrc . H^T, i.e. W0 with Qsrc = V)
+template <typename T>
+void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
+    EpiW<T> epi{(const T *)c->W[c->cur], (T *)c->W[c->cur ^ 1], c->k, multiply};
+    dim3 grid((unsigned)((c->k + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), 1);
+    hipLaunchKernelGGL((k_gemm<T, EpiW<T>>), grid, dim3(256), 0, c->stream, (int)c->n, (int)c->k,
+                       (int)c->f, (const T *)qsrc, (int64_t)c->f, (int64_t)1, (const T *)c->H,
+                       (int64_t)1, (int64_t)c->f, (int)c->f + GK, (const DevState *)c->st, epi);
+    HIPCHK(hipGetLastError());
+}
+
+// numer = W[widx]^T . Q
+template <typename T>
+void exact_N(klnmf_ctx *c, int widx) {
+    EpiN<T> epi{(T *)c->Npart, c->f, c->k * c->f};
+    dim3 grid((unsigned)((c->f + GT - 1) / GT), (unsigned)((c->k + GT - 1) / GT), (unsigned)c->nsplit);
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_col);
+    hipLaunchKernelGGL((k_gemm<T, EpiN<T>>), grid, dim3(256), 0, c->stream, (int)c->k, (int)c->f,
+                       (int)c->n, (const T *)c->W[widx], (int64_t)1, (int64_t)c->k,
+                       (const T *)c->Q, (int64_t)c->f, (int64_t)1, c->kchunk,
+                       (const DevState *)c->st, epi);
+    HIPCHK(hipGetLastError());
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    const int64_t count = c->k * c->f;
+    hipLaunchKernelGGL((k_sum_partials<T>), dim3(grid_for(count)), dim3(256), 0, c->stream,
+                       (const T *)c->Npart, (T *)c->numer, count, c->nsplit,
+                       (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
+template <typename T>
+void exact_H(klnmf_ctx *c) {
+    hipLaunchKernelGGL((k_update_H<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H,
+                       (const T *)c->numer, c->f, (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
+#define EXACT_CALL(c, fn, ...)                                         \
+    do {                                                               \
+        if ((c)->prec == KLNMF_PREC_F64) fn<double>(c, ##__VA_ARGS__); \
+        else fn<float>(c, ##__VA_ARGS__);                              \
+    } while (0)
+
+// ------------------------------------------------------------- loop pieces ---
+void reset_state(klnmf_ctx *c) {
+    hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(1), 0, c->stream, c->st);
+    HIPCHK(hipGetLastError());
+}
+
+void piece_rowpass(klnmf_ctx *c, int fit) {
+    (void)fit;   // the W rule is the same for fit and transform (nmf.py:251-253)
+    if (c->is_exact()) {
+        EXACT_CALL(c, exact_Q, 1);
+        EXACT_CALL(c, exact_W, c->Q, 1);
+    } else {
+        fast_rowpass(c, ROW_UPDATE);
+        hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
+                           (const float2 *)c->loss_part2, (int64_t)c->nrt, (const DevState *)c->st,
+                           c->loss_xchg);
+        HIPCHK(hipGetLastError());
+    }
+}
+
+void piece_decide(klnmf_ctx *c, double tol_abs) {
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, c->stream, c->st,
+                       (const double *)c->loss_xchg, tol_abs, c->errors, c->cap);
+    HIPCHK(hipGetLastError());
+}
+
+void piece_colpass(klnmf_ctx *c) {
+    if (c->is_exact()) EXACT_CALL(c, exact_N, c->cur ^ 1);
+    else fast_colpass(c);
+}
+
+void piece_update_H(klnmf_ctx *c) {
+    if (c->is_exact()) EXACT_CALL(c, exact_H);
+    else fast_pack_H(c, 1);
+}
+
+struct HostState {
+    DevState st;
+};
+
+void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopped) {
+    DevState hs{};
+    HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int64_t nd = hs.n_done;
+    if (nd > c->cap) nd = c->cap;
+    if (errors_out && nd > 0) {
+        HIPCHK(hipMemcpy(errors_out, c->errors, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    }
+    if (n_done) *n_done = hs.n_done;
+    if (stopped) *stopped = hs.stop;
+    // the current W is the one the last *executed* update wrote
+    c->cur = (c->loop_start_cur + (int)(hs.n_done & 1)) & 1;
+}
+
+// ---------------------------------------------------------------- uploads ---
+template <typename S>
+void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_t ld, int64_t row0,
+                 int64_t col0, double scale) {
+    const int64_t total = rows * cols;
+    const int grid = grid_for(total, 256, 8192);
+    switch (c->prec) {
+        case KLNMF_PREC_F64:
+            hipLaunchKernelGGL((k_place_V<double, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (double *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale);
+            break;
+        case KLNMF_PREC_F32:
+            hipLaunchKernelGGL((k_place_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (float *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale);
+            break;
+        case KLNMF_PREC_BF16:
+            hipLaunchKernelGGL((k_tile_V<__bf16, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (__bf16 *)c->VtA, (__bf16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
+                               ld, row0, col0, scale, c->st);
+            break;
+        default:
+            hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (float *)c->VtA, (float *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
+                               ld, row0, col0, scale, c->st);
+            break;
+    }
+    HIPCHK(hipGetLastError());
+}
+
+void check_block(klnmf_ctx *c, int64_t rows, int64_t cols, int64_t ld, int64_t row0, int64_t col0) {
+    if (rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || row0 + rows > c->n || col0 + cols > c->f ||
+        ld < cols)
+        fail(KLNMF_ERR_ARG, "V block out of range");
+}
+
+size_t dt_size(int dtype) {
+    if (dtype == KLNMF_DT_F32) return 4;
+    if (dtype == KLNMF_DT_F64) return 8;
+    fail(KLNMF_ERR_ARG, "unknown dtype");
+}
+
+// host [rows,cols] (dtype) -> device staging buffer; returns device pointer (freed by caller)
+void *stage_to_device(klnmf_ctx *c, const void *src, int dtype, int64_t count) {
+    void *d = nullptr;
+    const size_t bytes = (size_t)count * dt_size(dtype);
+    HIPCHK(hipMalloc(&d, bytes ? bytes : 16));
+    hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        fail(KLNMF_ERR_HIP, std::string("hipMemcpyAsync H2D: ") + hipGetErrorString(e));
+    }
+    return d;
+}
+
+// dense [rows,cols] host array -> device array of the context's element type / padded fp32
+void set_matrix(klnmf_ctx *c, const void *src, int dtype, int64_t rows, int64_t cols, void *exact_dst,
+                float *fast_dst, int64_t fast_ld) {
+    const int64_t count = rows * cols;
+    void *d = stage_to_device(c, src, dtype, count);
+    const int grid = grid_for(count, 256, 8192);
+    if (c->is_exact()) {
+        if (c->prec == KLNMF_PREC_F64) {
+            if (dtype == KLNMF_DT_F64)
+                hipLaunchKernelGGL((k_convert<double, double>), dim3(grid), dim3(256), 0, c->stream, (double *)exact_dst, (const double *)d, count);
+            else
+                hipLaunchKernelGGL((k_convert<double, float>), dim3(grid), dim3(256), 0, c->stream, (double *)exact_dst, (const float *)d, count);
+        } else {
+            if (dtype == KLNMF_DT_F64)
+                hipLaunchKernelGGL((k_convert<float, double>), dim3(grid), dim3(256), 0, c->stream, (float *)exact_dst, (const double *)d, count);
+            else
+                hipLaunchKernelGGL((k_convert<float, float>), dim3(grid), dim3(256), 0, c->stream, (float *)exact_dst, (const float *)d, count);
+        }
+    } else {
+        if (dtype == KLNMF_DT_F64)
+            hipLaunchKernelGGL((k_place_padded<double>), dim3(grid), dim3(256), 0, c->stream, fast_dst, fast_ld, (const double *)d, rows, cols);
+        else
+            hipLaunchKernelGGL((k_place_padded<float>), dim3(grid), dim3(256), 0, c->stream, fast_dst, fast_ld, (const float *)d, rows, cols);
+    }
+    hipError_t e = hipGetLastError();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
+    HIPCHK(e);
+}
+
+void get_matrix(klnmf_ctx *c, void *dst, int dtype, int64_t rows, int64_t cols, const void *exact_src,
+                const float *fast_src, int64_t fast_ld) {
+    const int64_t count = rows * cols;
+    void *d = nullptr;
+    const size_t bytes = (size_t)count * dt_size(dtype);
+    HIPCHK(hipMalloc(&d, bytes ? bytes : 16));
+    const int grid = grid_for(count, 256, 8192);
+    if (c->is_exact()) {
+        if (c->prec == KLNMF_PREC_F64) {
+            if (dtype == KLNMF_DT_F64)
+                hipLaunchKernelGGL((k_convert<double, double>), dim3(grid), dim3(256), 0, c->stream, (double *)d, (const double *)exact_src, count);
+            else
+                hipLaunchKernelGGL((k_convert<float, double>), dim3(grid), dim3(256), 0, c->stream, (float *)d, (const double *)exact_src, count);
+        } else {
+            if (dtype == KLNMF_DT_F64)
+                hipLaunchKernelGGL((k_convert<double, float>), dim3(grid), dim3(256), 0, c->stream, (double *)d, (const float *)exact_src, count);
+            else
+                hipLaunchKernelGGL((k_convert<float, float>), dim3(grid), dim3(256), 0, c->stream, (float *)d, (const float *)exact_src, count);
+        }
+    } else {
+        if (dtype == KLNMF_DT_F64)
+            hipLaunchKernelGGL((k_gather_padded<double>), dim3(grid), dim3(256), 0, c->stream, (double *)d, fast_src, fast_ld, rows, cols);
+        else
+            hipLaunchKernelGGL((k_gather_padded<float>), dim3(grid), dim3(256), 0, c->stream, (float *)d, fast_src, fast_ld, rows, cols);
+    }
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(e);
+    HIPCHK(e2);
+    HIPCHK(e3);
+}
+
+}  // namespace
+
+// =============================================================== exports ===
+extern "C" {
+
+int klnmf_version(void) { return KLNMF_VERSION; }
+
+const char *klnmf_last_error(void) { return g_err.c_str(); }
+
+int klnmf_device_info(int device, char *arch, int arch_len, int *cu_count, uint64_t *hbm_bytes) {
+    return guarded([&] {
+        hipDeviceProp_t p;
+        HIPCHK(hipGetDeviceProperties(&p, device));
+        if (arch && arch_len > 0) {
+            std::strncpy(arch, p.gcnArchName, arch_len - 1);
+            arch[arch_len - 1] = 0;
+        }
+        if (cu_count) *cu_count = p.multiProcessorCount;
+        if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    });
+}
+
+int klnmf_create(klnmf_ctx **out, int device, int precision, void *stream) {
+    return guarded([&] {
+        if (!out) fail(KLNMF_ERR_ARG, "null out pointer");
+        if (precision < KLNMF_PREC_F64 || precision > KLNMF_PREC_BF16_V32)
+            fail(KLNMF_ERR_ARG, "unknown precision mode");
+        int ndev = 0;
+        HIPCHK(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) fail(KLNMF_ERR_ARG, "no such device");
+        HIPCHK(hipSetDevice(device));
+        hipDeviceProp_t p;
+        HIPCHK(hipGetDeviceProperties(&p, device));
+        if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            fail(KLNMF_ERR_UNSUPP, std::string("this library is built for gfx950 only, device is ") + p.gcnArchName);
+        klnmf_ctx *c = new klnmf_ctx();
+        c->device = device;
+        c->prec = precision;
+        c->cu_count = p.multiProcessorCount;
+        if (stream) {
+            c->stream = (hipStream_t)stream;
+        } else {
+            hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                delete c;
+                HIPCHK(e);
+            }
+            c->own_stream = true;
+        }
+        *out = c;
+    });
+}
+
+int klnmf_destroy(klnmf_ctx *c) {
+    return guarded([&] {
+        if (!c) return;
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        c->free_all();
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+    });
+}
+
+int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap) {
+    return guarded([&] {
+        use(c);
+        if (n <= 0 || f <= 0 || k <= 0 || cap < 0) fail(KLNMF_ERR_ARG, "n, f, k must be positive");
+        if (n > (1LL << 30) || f > (1LL << 30) || k > (1LL << 20))
+            fail(KLNMF_ERR_UNSUPP, "dimension too large");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->free_all();
+        c->n = n; c->f = f; c->k = k; c->cap = cap;
+        c->cur = 0;
+        c->st = (DevState *)c->dalloc(sizeof(DevState));
+        c->errors = (double *)c->dalloc(sizeof(double) * (cap > 0 ? cap : 1));
+        c->loss_xchg = (double *)c->dalloc(sizeof(double) * 2);
+        if (c->is_exact()) {
+            const size_t es = c->esize();
+            c->V = c->dalloc((size_t)n * f * es);
+            c->Q = c->dalloc((size_t)n * f * es);
+            c->W[0] = c->dalloc((size_t)n * k * es);
+            c->W[1] = c->dalloc((size_t)n * k * es);
+            c->H = c->dalloc((size_t)k * f * es);
+            const int64_t tiles = ((k + GT - 1) / GT) * ((f + GT - 1) / GT);
+            int64_t s = (4 * (int64_t)c->cu_count + tiles - 1) / tiles;
+            const int64_t smax = (n + 255) / 256;
+            if (s > smax) s = smax;
+            if (s < 1) s = 1;
+            int64_t chunk = (n + s - 1) / s;
+            chunk = (chunk + GK - 1) / GK * GK;
+            s = (n + chunk - 1) / chunk;
+            c->nsplit = (int)s;
+            c->kchunk = (int)chunk;
+            c->Npart = c->dalloc((size_t)s * k * f * es);
+            c->numer = c->dalloc((size_t)k * f * es);
+            c->loss_part_count = ((f + GT - 1) / GT) * ((n + GT - 1) / GT);
+            c->loss_part = (double *)c->dalloc(sizeof(double) * c->loss_part_count);
+        } else {
+            c->KT = (int)((k + 31) / 32);
+            if (c->KT > 8) fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels; use KLNMF_PREC_F32/F64");
+            c->KP = 32 * c->KT;
+            c->ks = (int)((k + 15) / 16);
+            c->n_pad = (n + 31) / 32 * 32;
+            c->f_pad = (f + 31) / 32 * 32;
+            c->nrt = (int)(c->n_pad / 32);
+            c->nct = (int)(c->f_pad / 32);
+            c->nst = (c->nct + 1) / 2;
+            const int total_stages = (c->nrt + kStageRowTiles - 1) / kStageRowTiles;
+            // bf16 W images are streamed in 64-row stages by global_load_lds in 8 KiB rounds: pad the tail
+            c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + 64;
+            const size_t vs = c->vsize();
+            const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * vs;
+            c->VtA = c->dalloc(vbytes);
+            c->VtB = c->dalloc(vbytes);
+            for (int i = 0; i < 2; ++i) {
+                c->W32[i] = (float *)c->dalloc((size_t)c->n_pad * c->KP * 4);
+                c->Wb[i] = (__bf16 *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
+            }
+            c->H32 = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
+            c->Ht = (__bf16 *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
+            c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
+            // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
+            // multiple of 8 (XCD remap) and close to a multiple of the CU count
+            c->ncb = (c->nct + kWavesPerWG - 1) / kWavesPerWG;
+            int nch = 8;
+            while ((int64_t)nch * c->ncb < 2LL * c->cu_count && nch * 2 <= total_stages) nch += 8;
+            while (nch > 8 && ((int64_t)nch * c->ncb) % c->cu_count != 0 &&
+                   (int64_t)(nch - 8) * c->ncb >= c->cu_count) nch -= 8;
+            if (nch > total_stages) nch = total_stages > 0 ? ((total_stages + 7) / 8) * 8 : 8;
+            c->nchunks = nch;
+            c->stages_per_chunk = (total_stages + nch - 1) / nch;
+            c->NpartF = (float *)c->dalloc((size_t)nch * c->KP * c->f_pad * 4);
+            c->numerF = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
+            c->loss_part2 = (float2 *)c->dalloc(sizeof(float2) * c->nrt);
+        }
+        reset_state(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->have_problem = true;
+    });
+}
+
+int klnmf_upload_V(klnmf_ctx *c, const void *src, int dtype, int64_t rows, int64_t cols, int64_t ld,
+                   int64_t row0, int64_t col0, double scale) {
+    return guarded([&] {
+        need_problem(c);
+        if (!src) fail(KLNMF_ERR_ARG, "null source");
+        check_block(c, rows, cols, ld, row0, col0);
+        const size_t es = dt_size(dtype);
+        // stream the block through a bounded device staging buffer
+        int64_t rows_per = (int64_t)((256ull << 20) / (es * (size_t)ld));
+        if (rows_per < 1) rows_per = 1;
+        if (rows_per > rows) rows_per = rows;
+        void *d = nullptr;
+        HIPCHK(hipMalloc(&d, (size_t)rows_per * ld * es + 16));
+        try {
+            for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
+                const int64_t rr = std::min(rows_per, rows - r0);
+                const size_t bytes = ((size_t)(rr - 1) * ld + cols) * es;
+                HIPCHK(hipMemcpyAsync(d, (const char *)src + (size_t)r0 * ld * es, bytes,
+                                      hipMemcpyHostToDevice, c->stream));
+                if (dtype == KLNMF_DT_F64)
+                    place_block<double>(c, (const double *)d, rr, cols, ld, row0 + r0, col0, scale);
+                else
+                    place_block<float>(c, (const float *)d, rr, cols, ld, row0 + r0, col0, scale);
+                HIPCHK(hipStreamSynchronize(c->stream));
+            }
+        } catch (...) {
+            (void)hipFree(d);
+            throw;
+        }
+        (void)hipFree(d);
+    });
+}
+
+int klnmf_upload_V_device(klnmf_ctx *c, const float *dsrc, int64_t rows, int64_t cols, int64_t ld,
+                          int64_t row0, int64_t col0, double scale) {
+    return guarded([&] {
+        need_problem(c);
+        if (!dsrc) fail(KLNMF_ERR_ARG, "null source");
+        check_block(c, rows, cols, ld, row0, col0);
+        place_block<float>(c, dsrc, rows, cols, ld, row0, col0, scale);
+    });
+}
+
+int klnmf_set_H(klnmf_ctx *c, const void *src, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!src) fail(KLNMF_ERR_ARG, "null source");
+        if (!c->is_exact()) HIPCHK(hipMemsetAsync(c->H32, 0, (size_t)c->KP * c->f_pad * 4, c->stream));
+        set_matrix(c, src, dtype, c->k, c->f, c->H, c->H32, c->f_pad);
+        if (!c->is_exact()) fast_pack_H(c, 0);
+    });
+}
+
+int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!src) fail(KLNMF_ERR_ARG, "null source");
+        set_matrix(c, src, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP);
+        if (!c->is_exact()) {
+            hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n * c->KP, 256, 8192)), dim3(256), 0,
+                               c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n, c->KP,
+                               w_ld(c->KP));
+            HIPCHK(hipGetLastError());
+        }
+    });
+}
+
+int klnmf_set_Q(klnmf_ctx *c, const void *src, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "the ratio Q is never materialised in the bf16 modes");
+        if (!src) fail(KLNMF_ERR_ARG, "null source");
+        set_matrix(c, src, dtype, c->n, c->f, c->Q, nullptr, 0);
+    });
+}
+
+int klnmf_init_W(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        reset_state(c);
+        if (c->is_exact()) EXACT_CALL(c, exact_W, c->V, 0);
+        else fast_rowpass(c, ROW_INIT);
+        c->cur ^= 1;
+    });
+}
+
+int klnmf_loop_begin(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        reset_state(c);
+        c->loop_start_cur = c->cur;
+        c->loop_iters = 0;
+    });
+}
+
+int klnmf_iter_rowpass(klnmf_ctx *c, int fit) {
+    return guarded([&] {
+        need_problem(c);
+        piece_rowpass(c, fit);
+    });
+}
+
+int klnmf_iter_decide(klnmf_ctx *c, double tol_abs) {
+    return guarded([&] {
+        need_problem(c);
+        piece_decide(c, tol_abs);
+    });
+}
+
+int klnmf_iter_colpass(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        piece_colpass(c);
+    });
+}
+
+int klnmf_iter_update_H(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        piece_update_H(c);
+    });
+}
+
+/* The host calls this after enqueuing each iteration's pieces so the W
+ * ping-pong advances; kept separate from the pieces so transform (no H rule)
+ * and fit share them. */
+int klnmf_iter_advance(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        c->cur ^= 1;
+        c->loop_iters += 1;
+    });
+}
+
+int klnmf_loop_end(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopped) {
+    return guarded([&] {
+        need_problem(c);
+        fetch_results(c, errors_out, n_done, stopped);
+    });
+}
+
+int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *errors_out,
+              int64_t *n_done, int *stopped) {
+    return guarded([&] {
+        need_problem(c);
+        if (max_iter < 0) fail(KLNMF_ERR_ARG, "max_iter < 0");
+        if (max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter exceeds the capacity given to klnmf_set_problem");
+        reset_state(c);
+        c->loop_start_cur = c->cur;
+        for (int64_t it = 0; it < max_iter; ++it) {
+            piece_rowpass(c, fit);
+            piece_decide(c, tol_abs);
+            if (fit) {
+                piece_colpass(c);
+                piece_update_H(c);
+            }
+            c->cur ^= 1;
+            if (tol_abs > 0 && (it & 15) == 15) {
+                // the stop rule may already have fired: look, so that the remaining
+                // (no-op) iterations need not be enqueued
+                DevState hs{};
+                HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (hs.stop) break;
+            }
+        }
+        fetch_results(c, errors_out, n_done, stopped);
+    });
+}
+
+int klnmf_exchange_buffers(klnmf_ctx *c, void **loss_ptr, void **numer_ptr, int64_t *numer_count,
+                           int *numer_is_f64) {
+    return guarded([&] {
+        need_problem(c);
+        if (loss_ptr) *loss_ptr = c->loss_xchg;
+        if (c->is_exact()) {
+            if (numer_ptr) *numer_ptr = c->numer;
+            if (numer_count) *numer_count = c->k * c->f;
+            if (numer_is_f64) *numer_is_f64 = c->prec == KLNMF_PREC_F64;
+        } else {
+            if (numer_ptr) *numer_ptr = c->numerF;
+            if (numer_count) *numer_count = (int64_t)c->KP * c->f_pad;
+            if (numer_is_f64) *numer_is_f64 = 0;
+        }
+    });
+}
+
+int klnmf_bind_exchange(klnmf_ctx *c, void *loss_ptr, void *numer_ptr) {
+    return guarded([&] {
+        need_problem(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (loss_ptr) c->loss_xchg = (double *)loss_ptr;
+        if (numer_ptr) {
+            if (c->is_exact()) c->numer = numer_ptr;
+            else c->numerF = (float *)numer_ptr;
+        }
+    });
+}
+
+int klnmf_error(klnmf_ctx *c, double *loss) {
+    return guarded([&] {
+        need_problem(c);
+        reset_state(c);
+        if (c->is_exact()) {
+            EXACT_CALL(c, exact_Q, 0);
+        } else {
+            fast_rowpass(c, ROW_LOSS);
+            hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
+                               (const float2 *)c->loss_part2, (int64_t)c->nrt,
+                               (const DevState *)c->st, c->loss_xchg);
+            HIPCHK(hipGetLastError());
+        }
+        double h[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(h, c->loss_xchg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (loss) *loss = h[0];
+    });
+}
+
+int klnmf_update(klnmf_ctx *c, int fit) {
+    return guarded([&] {
+        need_problem(c);
+        reset_state(c);
+        piece_rowpass(c, fit);
+        if (fit) {
+            piece_colpass(c);
+            piece_update_H(c);
+        }
+        c->cur ^= 1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_step_Q(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "the ratio Q is never materialised in the bf16 modes");
+        reset_state(c);
+        EXACT_CALL(c, exact_Q, 1, c->ratio_eps);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_step_W(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "step API needs KLNMF_PREC_F64/F32");
+        reset_state(c);
+        EXACT_CALL(c, exact_W, c->Q, 1);
+        c->cur ^= 1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_step_H(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "step API needs KLNMF_PREC_F64/F32");
+        reset_state(c);
+        EXACT_CALL(c, exact_N, c->cur);
+        EXACT_CALL(c, exact_H);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_set_ratio_eps(klnmf_ctx *c, double eps) {
+    return guarded([&] {
+        use(c);
+        if (!(eps >= 0)) fail(KLNMF_ERR_ARG, "eps must be >= 0");
+        if (!c->is_exact() && eps != kEpsRatio)
+            fail(KLNMF_ERR_UNSUPP, "the bf16 kernels use the reference's fixed eps = 1e-8");
+        c->ratio_eps = eps;
+    });
+}
+
+int klnmf_generalized_kl(klnmf_ctx *c, const void *x, const void *y, int dtype, int64_t count,
+                         double eps, double *out) {
+    return guarded([&] {
+        use(c);
+        if (!x || !y || count < 0) fail(KLNMF_ERR_ARG, "bad arguments");
+        void *dx = stage_to_device(c, x, dtype, count);
+        void *dy = nullptr;
+        double *part = nullptr;
+        const int grid = grid_for(count, 256, 1024);
+        hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+        double host_part[1024];
+        try {
+            dy = stage_to_device(c, y, dtype, count);
+            HIPCHK(hipMalloc((void **)&part, sizeof(double) * grid));
+            if (dtype == KLNMF_DT_F64)
+                hipLaunchKernelGGL((k_gkl<double>), dim3(grid), dim3(256), 0, c->stream, (const double *)dx, (const double *)dy, count, eps, part);
+            else
+                hipLaunchKernelGGL((k_gkl<float>), dim3(grid), dim3(256), 0, c->stream, (const float *)dx, (const float *)dy, count, eps, part);
+            e1 = hipGetLastError();
+            e2 = hipMemcpyAsync(host_part, part, sizeof(double) * grid, hipMemcpyDeviceToHost, c->stream);
+            e3 = hipStreamSynchronize(c->stream);
+        } catch (...) {
+            (void)hipFree(dx);
+            if (dy) (void)hipFree(dy);
+            if (part) (void)hipFree(part);
+            throw;
+        }
+        (void)hipFree(dx);
+        (void)hipFree(dy);
+        (void)hipFree(part);
+        HIPCHK(e1);
+        HIPCHK(e2);
+        HIPCHK(e3);
+        double s = 0;
+        for (int i = 0; i < grid; ++i) s += host_part[i];
+        if (out) *out = s;
+    });
+}
+
+int klnmf_get_W(klnmf_ctx *c, void *dst, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!dst) fail(KLNMF_ERR_ARG, "null destination");
+        get_matrix(c, dst, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP);
+    });
+}
+
+int klnmf_get_H(klnmf_ctx *c, void *dst, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!dst) fail(KLNMF_ERR_ARG, "null destination");
+        get_matrix(c, dst, dtype, c->k, c->f, c->H, c->H32, c->f_pad);
+    });
+}
+
+int klnmf_get_Q(klnmf_ctx *c, void *dst, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "the ratio Q is never materialised in the bf16 modes");
+        if (!dst) fail(KLNMF_ERR_ARG, "null destination");
+        get_matrix(c, dst, dtype, c->n, c->f, c->Q, nullptr, 0);
+    });
+}
+
+int klnmf_profile_enable(klnmf_ctx *c, int on) {
+    return guarded([&] {
+        use(c);
+        c->profiling = on != 0;
+    });
+}
+
+int klnmf_profile_read(klnmf_ctx *c, int64_t *row_n, double *row_ms, int64_t *col_n, double *col_ms,
+                       int reset) {
+    return guarded([&] {
+        use(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        auto total = [&](std::vector<EventPair> &v, int64_t *n, double *ms) {
+            double s = 0;
+            for (auto &e : v) {
+                float t = 0;
+                HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+                s += t;
+            }
+            if (n) *n = (int64_t)v.size();
+            if (ms) *ms = s;
+            if (reset) {
+                for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+                v.clear();
+            }
+        };
+        total(c->ev_row, row_n, row_ms);
+        total(c->ev_col, col_n, col_ms);
+    });
+}
+
+int klnmf_synchronize(klnmf_ctx *c) {
+    return guarded([&] {
+        use(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_selftest(int device, int *failed) {
+    return guarded([&] {
+        HIPCHK(hipSetDevice(device));
+        const int bits = run_probes();
+        if (failed) *failed = bits;
+    });
+}
+
+}  // extern "C"

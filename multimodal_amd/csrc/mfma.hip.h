@@ -1,0 +1,550 @@
+// bf16-MFMA kernels of the KL-NMF update for gfx950 (CDNA4).
+//
+// One fit iteration = two streaming passes over V:
+//
+//   k_rowpass  a wave owns 32 sample rows (its W block stays in registers as the
+//              MFMA B operand) and streams the dictionary through LDS, 64 feature
+//              columns per stage.  Per 32x32 tile: (W.H)^T by MFMA -> ratio
+//              Q=(V+eps)/(WH+eps) and the loss terms in the accumulator registers
+//              -> Q (bf16, still in registers, "accumulator as next operand") is
+//              the B operand of the second MFMA chain G^T += H_tile . Q^T.  After
+//              the last stage W_new = W * G.        nmf.py:325-343, 297-310
+//   k_colpass  the mirror image: a wave owns 32 feature columns (its H block in
+//              registers) and streams W_old / W_new row tiles through LDS;
+//              recomputes Q from W_old (quirk q2: OLD Q, NEW W) and accumulates
+//              W_new^T . Q for its columns over a chunk of rows -> one fp32 slab
+//              per row chunk (deterministic two-stage reduction).   nmf.py:349
+//
+// Neither W.H nor Q ever goes to HBM.  V is stored twice, pre-tiled so that each
+// lane's 16 elements of a 32x32 tile are contiguous in exactly the MFMA
+// accumulator order of the pass that reads it (layout A: sample on the lane,
+// layout B: feature on the lane) -> every V load is a fully coalesced
+// 16-byte-per-lane stream straight to registers, no LDS round trip.
+//
+// MFMA: v_mfma_f32_32x32x16_bf16.  Operand maps (guide section 3):
+//   A[row = l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col = l&31], j = 0..7
+//   D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg = 0..15
+#pragma once
+#include "common.hip.h"
+
+namespace klnmf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define KL_LDS __attribute__((address_space(3)))
+#define KL_GLB __attribute__((address_space(1)))
+
+constexpr int kWavesPerWG = 8;
+constexpr int kThreads = 64 * kWavesPerWG;       // 512
+constexpr int kStageCols = 64;                   // feature columns per LDS stage (row pass)
+constexpr int kHRow = kStageCols + 4;            // padded image row, elements (136 B)
+constexpr int kHRowB = kHRow * 2;
+constexpr int kStageRowTiles = 2;                // 32-row tiles per LDS stage (column pass)
+constexpr int kGldsRound = kThreads * 16;        // bytes one global_load_lds round moves (8 KiB)
+
+__host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// bf16 W image row: KP + 8 elements -> (KP+8)/8 is odd -> ds_read_b128 conflict-free
+__host__ __device__ constexpr int w_ld(int kp) { return kp + 8; }
+__host__ __device__ constexpr int h_stage_bytes(int kp) { return kp * kHRowB; }
+__host__ __device__ constexpr int h_stage_lds(int kp) { return round_up(h_stage_bytes(kp), kGldsRound); }
+__host__ __device__ constexpr int w_stage_bytes(int kp) { return kStageRowTiles * 32 * w_ld(kp) * 2; }
+__host__ __device__ constexpr int w_stage_lds(int kp) { return round_up(w_stage_bytes(kp), kGldsRound); }
+
+enum RowMode { ROW_UPDATE = 0, ROW_INIT = 1, ROW_LOSS = 2 };
+
+// ---- small device helpers ---------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+    // two ds_read_b64_tr_b16: each gives this lane one column of a 4-row x 16-col block
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p1);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 b64_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+    s16x4 lo = *(const KL_LDS s16x4 *)p0;
+    s16x4 hi = *(const KL_LDS s16x4 *)p1;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(const float *q) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)q[j];
+    return r;
+}
+
+// 16 V elements of this lane for one 32x32 tile, as fp32.
+struct VRegsBf16 { u32x4 a, b; };
+struct VRegsF32 { f32x4 a, b, c, d; };
+template <typename VT> struct VTraits;
+template <> struct VTraits<__bf16> {
+    typedef VRegsBf16 Regs;
+    static constexpr int kLaneBytes = 32;
+    static __device__ __forceinline__ Regs load(const void *tile, int lane) {
+        const u32x4 *p = (const u32x4 *)((const unsigned char *)tile + lane * 32);
+        Regs r; r.a = p[0]; r.b = p[1]; return r;
+    }
+    static __device__ __forceinline__ void unpack(const Regs &r, float *x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[2 * i] = __uint_as_float(r.a[i] << 16);
+            x[2 * i + 1] = __uint_as_float(r.a[i] & 0xffff0000u);
+            x[8 + 2 * i] = __uint_as_float(r.b[i] << 16);
+            x[8 + 2 * i + 1] = __uint_as_float(r.b[i] & 0xffff0000u);
+        }
+    }
+};
+template <> struct VTraits<float> {
+    typedef VRegsF32 Regs;
+    static constexpr int kLaneBytes = 64;
+    static __device__ __forceinline__ Regs load(const void *tile, int lane) {
+        const f32x4 *p = (const f32x4 *)((const unsigned char *)tile + lane * 64);
+        Regs r; r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; return r;
+    }
+    static __device__ __forceinline__ void unpack(const Regs &r, float *x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = r.a[i]; x[4 + i] = r.b[i]; x[8 + i] = r.c[i]; x[12 + i] = r.d[i]; }
+    }
+};
+
+// Copy `rounds` x 8 KiB from global to LDS with global_load_lds_dwordx4 (LDS
+// image == global image; destination is wave-uniform base + lane*16).
+__device__ __forceinline__ void glds_copy(const unsigned char *gsrc, KL_LDS unsigned char *ldst,
+                                          int rounds, int tid) {
+    const int wave_base = (tid & ~63) * 16;
+    for (int r = 0; r < rounds; ++r) {
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kGldsRound + tid * 16),
+                                         (KL_LDS void *)(ldst + r * kGldsRound + wave_base), 16, 0, 0);
+    }
+}
+
+struct RowPassArgs {
+    const void *VtA;          // [nrt][nct][64 lanes][16] tiles, layout A
+    const __bf16 *Ht;         // [nst][KP][kHRow] dictionary stage images
+    const __bf16 *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
+    const float *W32_old;     // [n_pad][KP]
+    __bf16 *Wb_new;
+    float *W32_new;
+    float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
+    const DevState *st;
+    int nrt, nct, nst, ks;    // row tiles, col tiles, stages, MFMA1 k-steps = ceil(k/16)
+};
+
+template <int KT, int MODE, typename VT>
+__global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
+    constexpr int KP = 32 * KT;
+    constexpr int KS = 2 * KT;
+    constexpr int STG = h_stage_lds(KP);
+    constexpr int ROUNDS = STG / kGldsRound;
+    constexpr int WLD = w_ld(KP);
+    typedef VTraits<VT> VTr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (a.st->stop) return;
+    KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rt = blockIdx.x * kWavesPerWG + wave;
+    const bool active = rt < a.nrt;                       // wave-uniform
+
+    // per-lane LDS offsets (bytes) inside a stage image [KP][kHRow]
+    //  tr read (MFMA1 A operand): rows = components, this lane addresses row q, cols 4p..4p+3 of its 16-lane group's block
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    const int off_tr = (8 * h + tq) * kHRowB + (16 * half + 4 * tp) * 2;
+    //  row read (MFMA2 A operand): row = component r, cols 4h..4h+3
+    const int off_row = r * kHRowB + (4 * h) * 2;
+
+    bf16x8 wf[KS];
+    if (MODE != ROW_INIT) {
+        const __bf16 *wrow = a.Wb_old + (int64_t)(active ? rt * 32 + r : 0) * WLD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + 16 * s);
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+
+    const unsigned char *ht = (const unsigned char *)a.Ht;
+    const unsigned char *vt = (const unsigned char *)a.VtA +
+                              (int64_t)(active ? rt : 0) * a.nct * 64 * VTr::kLaneBytes;
+    // prologue: stage 0 into buffer 0, V tiles of stage 0
+    glds_copy(ht, smem, ROUNDS, tid);
+    typename VTr::Regs vcur[2], vnext[2];
+    vcur[0] = VTr::load(vt, lane);
+    vcur[1] = (a.nct > 1) ? VTr::load(vt + 64 * VTr::kLaneBytes, lane) : vcur[0];
+    vnext[0] = vcur[0]; vnext[1] = vcur[1];
+    __syncthreads();   // hipcc drains vmcnt before the barrier while a global_load_lds is in flight
+
+    for (int st = 0; st < a.nst; ++st) {
+        KL_LDS unsigned char *img = smem + (st & 1) * STG;
+        if (st + 1 < a.nst) {
+            glds_copy(ht + (int64_t)(st + 1) * h_stage_bytes(KP), smem + ((st + 1) & 1) * STG, ROUNDS, tid);
+            const int ct0 = 2 * (st + 1);
+            vnext[0] = VTr::load(vt + (int64_t)ct0 * 64 * VTr::kLaneBytes, lane);
+            if (ct0 + 1 < a.nct) vnext[1] = VTr::load(vt + (int64_t)(ct0 + 1) * 64 * VTr::kLaneBytes, lane);
+        }
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (2 * st + u < a.nct) {
+                    float x[16], q[16];
+                    VTr::unpack(vcur[u], x);
+                    if (MODE == ROW_INIT) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) q[e] = x[e];
+                    } else {
+                        f32x16 d;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) d[e] = 0.f;
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            if (s < a.ks) {
+                                const KL_LDS unsigned char *p = img + off_tr + (16 * s) * kHRowB + (32 * u) * 2;
+                                bf16x8 a1 = tr_pair(p, p + 4 * kHRowB);
+                                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[s], d, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float y = d[e];
+                            const float qq = (x[e] + (float)kEpsRatio) * __builtin_amdgcn_rcpf(y + (float)kEpsRatio);
+                            q[e] = qq;
+                            s2 += y;
+                            s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
+                        }
+                    }
+                    if (MODE != ROW_LOSS) {
+                        const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+#pragma unroll
+                        for (int m = 0; m < KT; ++m) {
+                            const KL_LDS unsigned char *p = img + off_row + (32 * m) * kHRowB + (32 * u) * 2;
+                            bf16x8 a20 = b64_pair(p, p + 16);
+                            bf16x8 a21 = b64_pair(p + 32, p + 48);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a20, b0, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a21, b1, acc[m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        vcur[0] = vnext[0]; vcur[1] = vnext[1];
+        __syncthreads();
+    }
+
+    if (!active) return;
+    if (MODE != ROW_INIT) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) a.loss_part[rt] = make_float2(s1, s2);
+    }
+    if (MODE != ROW_LOSS) {
+        // acc[m] reg (g,t): component 32m + 8g + 4h + t of sample row r
+        const int64_t row = (int64_t)rt * 32 + r;
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int comp = 32 * m + 8 * g + 4 * h;
+                f32x4 w;
+                if (MODE == ROW_UPDATE) {
+                    w = *(const f32x4 *)(a.W32_old + row * KP + comp);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[t] *= acc[m][4 * g + t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[t] = acc[m][4 * g + t];
+                }
+                *(f32x4 *)(a.W32_new + row * KP + comp) = w;
+                bf16x4 wb;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[t];
+                *(bf16x4 *)(a.Wb_new + row * WLD + comp) = wb;
+            }
+    }
+}
+
+struct ColPassArgs {
+    const void *VtB;          // [nct][nrt][64][16] tiles, layout B
+    const __bf16 *HTb;        // [f_pad][KP] transposed dictionary (this wave's B fragments)
+    const __bf16 *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
+    const __bf16 *Wb_new;
+    float *Npart;             // [nchunks][KP][f_pad]
+    const DevState *st;
+    int nrt, nct, ncb, nchunks, stages_per_chunk, ks;
+    int64_t f_pad;
+};
+
+template <int KT, typename VT>
+__global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
+    constexpr int KP = 32 * KT;
+    constexpr int KS = 2 * KT;
+    constexpr int WLD = w_ld(KP);
+    constexpr int WLDB = WLD * 2;
+    constexpr int IMG = w_stage_lds(KP);           // one image (W_old or W_new) of one stage
+    constexpr int ROUNDS = IMG / kGldsRound;
+    constexpr int RS = kStageRowTiles;
+    typedef VTraits<VT> VTr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (a.st->stop) return;
+    KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware block -> (row chunk, column block): blocks b and b+8 share an
+    // XCD; give each XCD a contiguous run of (chunk, cb) pairs so the column
+    // blocks that stream the same W rows share one L2 (speed only).
+    const int G = gridDim.x;
+    int lin = blockIdx.x;
+    if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = lin / a.ncb, cb = lin % a.ncb;
+    const int ct = cb * kWavesPerWG + wave;
+    const bool active = ct < a.nct;                  // wave-uniform
+    const int total_stages = (a.nrt + RS - 1) / RS;
+    const int sbeg = chunk * a.stages_per_chunk;
+    const int send = min(total_stages, sbeg + a.stages_per_chunk);
+
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    //  row read (MFMA1' A operand): W_old row r, components 8h..8h+7
+    const int off_row = r * WLDB + (8 * h) * 2;
+    //  tr read (MFMA3 A operand): rows = samples, cols = components
+    const int off_tr = (4 * h + tq) * WLDB + (16 * half + 4 * tp) * 2;
+
+    bf16x8 hf[KS];
+    {
+        const __bf16 *hrow = a.HTb + (int64_t)(active ? ct * 32 + r : 0) * KP + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) hf[s] = *(const bf16x8 *)(hrow + 16 * s);
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    const unsigned char *wo = (const unsigned char *)a.Wb_old;
+    const unsigned char *wn = (const unsigned char *)a.Wb_new;
+    const unsigned char *vt = (const unsigned char *)a.VtB +
+                              (int64_t)(active ? ct : 0) * a.nrt * 64 * VTr::kLaneBytes;
+    typename VTr::Regs vcur[RS], vnext[RS];
+    if (sbeg < send) {
+        const int64_t goff = (int64_t)sbeg * w_stage_bytes(KP);
+        glds_copy(wo + goff, smem, ROUNDS, tid);
+        glds_copy(wn + goff, smem + IMG, ROUNDS, tid);
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+            const int rtile = min(sbeg * RS + u, a.nrt - 1);
+            vcur[u] = VTr::load(vt + (int64_t)rtile * 64 * VTr::kLaneBytes, lane);
+            vnext[u] = vcur[u];
+        }
+    }
+    __syncthreads();
+
+    for (int sg = sbeg; sg < send; ++sg) {
+        const int b = (sg - sbeg) & 1;
+        KL_LDS unsigned char *img_old = smem + b * 2 * IMG;
+        KL_LDS unsigned char *img_new = img_old + IMG;
+        if (sg + 1 < send) {
+            const int64_t goff = (int64_t)(sg + 1) * w_stage_bytes(KP);
+            KL_LDS unsigned char *nb = smem + (b ^ 1) * 2 * IMG;
+            glds_copy(wo + goff, nb, ROUNDS, tid);
+            glds_copy(wn + goff, nb + IMG, ROUNDS, tid);
+#pragma unroll
+            for (int u = 0; u < RS; ++u) {
+                const int rtile = min((sg + 1) * RS + u, a.nrt - 1);
+                vnext[u] = VTr::load(vt + (int64_t)rtile * 64 * VTr::kLaneBytes, lane);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < RS; ++u) {
+                if (sg * RS + u < a.nrt) {
+                    float x[16], q[16];
+                    VTr::unpack(vcur[u], x);
+                    f32x16 d;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) d[e] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        if (s < a.ks) {
+                            bf16x8 a1 = *(const KL_LDS bf16x8 *)(img_old + off_row + (32 * u) * WLDB + (16 * s) * 2);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hf[s], d, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        q[e] = (x[e] + (float)kEpsRatio) * __builtin_amdgcn_rcpf(d[e] + (float)kEpsRatio);
+                    const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+#pragma unroll
+                    for (int m = 0; m < KT; ++m) {
+                        const KL_LDS unsigned char *p = img_new + off_tr + (32 * u) * WLDB + (32 * m) * 2;
+                        bf16x8 a30 = tr_pair(p, p + 8 * WLDB);
+                        bf16x8 a31 = tr_pair(p + 16 * WLDB, p + 24 * WLDB);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, b0, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, b1, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RS; ++u) vcur[u] = vnext[u];
+        __syncthreads();
+    }
+
+    if (!active) return;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            np[(int64_t)comp * a.f_pad] = acc[m][e];
+        }
+}
+
+// ---- dictionary / coefficient packing ----------------------------------------
+// One block per component row.  do_update: H <- H*num then row-normalise
+// (nmf.py:349-350); always (re)writes the bf16 stage images Ht and the transposed
+// copy HTb from the fp32 master.
+__global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
+                                                       __bf16 *HTb, int64_t f, int64_t f_pad, int kp,
+                                                       int do_update, const DevState *st) {
+    if (st && st->stop) return;
+    __shared__ double red[16];
+    __shared__ double total;
+    const int a = blockIdx.x;
+    float *row = H32 + (int64_t)a * f_pad;
+    if (do_update) {
+        const float *nrow = num + (int64_t)a * f_pad;
+        double s = 0;
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
+            const float v = row[j] * nrow[j];
+            row[j] = v;
+            s += (double)v;
+        }
+        const double t = block_sum(s, red);
+        if (threadIdx.x == 0) total = t;
+        __syncthreads();
+        const float d = (float)(kEpsNorm + total);
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
+        __syncthreads();
+    }
+    for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
+        const __bf16 v = (__bf16)row[j];
+        Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + (j % kStageCols)] = v;
+        HTb[j * kp + a] = v;
+    }
+}
+
+__global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wld) {
+    const int64_t total = n * kp;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / kp, c = e % kp;
+        Wb[i * wld + c] = (__bf16)W32[e];
+    }
+}
+
+// Scatter a host-layout fp32/fp64 [n,k] (or [k,f]) array into a padded fp32 master.
+template <typename S>
+__global__ void k_place_padded(float *dst, int64_t dld, const S *src, int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / cols, c = e % cols;
+        dst[i * dld + c] = (float)src[e];
+    }
+}
+template <typename D>
+__global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / cols, c = e % cols;
+        dst[e] = (D)src[i * sld + c];
+    }
+}
+
+// ---- V upload: scale, cast, tile (K6) ------------------------------------------
+// Writes both tiled copies.  Tile element maps (32x32 tile, i = row in tile,
+// c = col in tile):
+//   layout A: lane = i + 32*((c>>2)&1), e = 4*(c>>3) + (c&3)      (sample on lane)
+//   layout B: lane = c + 32*((i>>2)&1), e = 4*(i>>3) + (i&3)      (feature on lane)
+// Also accumulates sum(x~) and the storage-rounding correction
+//   C = sum( x~ ln x~ - x ln x - (x~ - x) )   (0 ln 0 = 0)
+// so that loss(x) ~= loss(x~) - C (see DESIGN.md "loss with rounded V").
+template <typename VT, typename S>
+__global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int nct, const S *src,
+                                                int64_t rows, int64_t cols, int64_t ld, int64_t row0,
+                                                int64_t col0, double scale, DevState *st) {
+    __shared__ double red[16];
+    const int64_t total = rows * cols;
+    double sx = 0, cc = 0;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ii = e / cols, jj = e % cols;
+        const double xv = scale * (double)src[ii * ld + jj];
+        const VT xs = (VT)(float)xv;
+        const double xt = (double)(float)xs;
+        const int64_t row = row0 + ii, col = col0 + jj;
+        const int64_t rt = row >> 5, ctile = col >> 5;
+        const int i = row & 31, c = col & 31;
+        const int laneA = i + 32 * ((c >> 2) & 1), eA = 4 * (c >> 3) + (c & 3);
+        const int laneB = c + 32 * ((i >> 2) & 1), eB = 4 * (i >> 3) + (i & 3);
+        VtA[((rt * nct + ctile) * 64 + laneA) * 16 + eA] = xs;
+        VtB[((ctile * nrt + rt) * 64 + laneB) * 16 + eB] = xs;
+        sx += xt;
+        const double t1 = xt > 0 ? xt * log(xt) : 0.0;
+        const double t0 = xv > 0 ? xv * log(xv) : 0.0;
+        cc += t1 - t0 - (xt - xv);
+    }
+    const double tsx = block_sum(sx, red);
+    const double tcc = block_sum(cc, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&st->sum_x, tsx);
+        atomicAdd(&st->corr_c, tcc);
+    }
+}
+
+// loss_local = ln2 * sum(s1) + sum(s2) - sum_x - C   (fixed summation order)
+__global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, int64_t count,
+                                                          const DevState *st, double *out) {
+    if (st->stop) return;
+    __shared__ double red[16];
+    double a = 0, b = 0;
+    for (int64_t e = threadIdx.x; e < count; e += blockDim.x) {
+        const float2 p = part[e];
+        a += (double)p.x;
+        b += (double)p.y;
+    }
+    const double ta = block_sum(a, red);
+    const double tb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        out[0] = kLn2 * ta + tb - st->sum_x - st->corr_c;
+        out[1] = 0;
+    }
+}
+
+__global__ void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
+                                   const DevState *st) {
+    if (st && st->stop) return;
+    const f32x4 *p = (const f32x4 *)part;
+    f32x4 *o = (f32x4 *)out;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < count4;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = p[e];
+        for (int z = 1; z < nslab; ++z) s += p[z * count4 + e];
+        o[e] = s;
+    }
+}
+
+}  // namespace klnmf

@@ -1,0 +1,148 @@
+"""Row-sharded KL-NMF across the GPUs of one node (one process per GPU).
+
+The reference has no parallelism; this is the
+one data-parallel strategy the algebra offers: samples (rows of V and W) are
+partitioned, the dictionary H is replicated.  Per fit iteration the ranks
+exchange exactly
+
+  * the k x f numerator of the H rule, W_new^T . Q   (nmf.py:349)  -- one
+    all-reduce(sum) over xGMI (RCCL; `torch.distributed` backend "nccl"), and
+  * the scalar loss (2 doubles)                       (nmf.py:214)  -- a second,
+    tiny all-reduce so every rank takes the same stop decision.
+
+The W rule (nmf.py:342) is row-local and needs no communication; a transform
+(`fit=False`) exchanges only the loss.  After the all-reduce every rank applies
+the H rule and the row normalisation to identical inputs, so the replicas stay
+bit-identical.
+
+The per-rank arithmetic is a `_native.Context`; this module only sequences the
+pieces of `include/klnmf.h` (klnmf_iter_*) around the collectives.  `backend` may
+be any object with the same methods (the CPU tests drive the sequencing with an
+oracle-backed double over gloo).
+"""
+import numpy as np
+
+
+def row_partition(n, world_size):
+    """Contiguous row ranges [start, stop) per rank; sizes differ by at most 1
+    block of 32 rows (the MFMA row-tile), the last rank takes the remainder."""
+    tiles = (n + 31) // 32
+    base, extra = divmod(tiles, world_size)
+    bounds = [0]
+    for r in range(world_size):
+        t = base + (1 if r < extra else 0)
+        bounds.append(min(n, bounds[-1] + 32 * t))
+    bounds[-1] = n
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+class ShardedKLNMF(object):
+    """The loop of nmf.py:212-222 over row shards.
+
+    Parameters
+    ----------
+    n_total, f, k : global problem shape (this rank holds `n_local` rows).
+    precision     : 'bf16' | 'bf16_v32' | 'f32' | 'f64'
+    group         : torch.distributed process group or None (single process).
+    backend       : context object; default = a HIP `_native.Context` on the
+                    current torch device / stream.
+    """
+
+    def __init__(self, n_total, n_local, f, k, max_iter, precision='bf16',
+                 group=None, backend=None, device=None):
+        import torch
+        self.torch = torch
+        self.n_total, self.n_local, self.f, self.k = n_total, n_local, f, k
+        self.max_iter = int(max_iter)
+        self.group = group
+        self.dist = None
+        self.world_size = 1
+        if group is not None or (torch.distributed.is_available()
+                                 and torch.distributed.is_initialized()):
+            self.dist = torch.distributed
+            self.world_size = self.dist.get_world_size(group)
+        if backend is None:
+            from . import _native
+            dev = torch.cuda.current_device() if device is None else device
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            backend = _native.Context(precision=precision, device=dev, stream=stream)
+            self.tensor_device = torch.device('cuda', dev)
+        else:
+            self.tensor_device = torch.device('cpu')
+        self.ctx = backend
+        self.ctx.set_problem(n_local, f, k, self.max_iter)
+        _, _, count, is64 = self.ctx.exchange_buffers()
+        # exchange buffers owned by torch so they can be handed to all_reduce
+        self.numer_t = torch.zeros(count, dtype=torch.float64 if is64 else torch.float32,
+                                   device=self.tensor_device)
+        self.loss_t = torch.zeros(2, dtype=torch.float64, device=self.tensor_device)
+        self.ctx.bind_exchange(self.loss_t.data_ptr(), self.numer_t.data_ptr())
+        self.iterations_enqueued = 0
+
+    # ---- data ----
+    def upload_V(self, block, row0=0, col0=0, scale=1.0):
+        self.ctx.upload_V(block, row0=row0, col0=col0, scale=scale)
+
+    def upload_V_device(self, tensor, row0=0, col0=0, scale=1.0):
+        """fp32 CUDA tensor [rows, cols] (row-major) already on this rank's GPU."""
+        assert tensor.dtype == self.torch.float32 and tensor.is_contiguous()
+        self.ctx.upload_V_device(tensor.data_ptr(), tensor.shape[0], tensor.shape[1],
+                                 tensor.stride(0), row0, col0, scale)
+
+    def set_H(self, H):
+        self.ctx.set_H(H)
+
+    def init_W(self):
+        self.ctx.init_W()
+
+    # ---- loop ----
+    def _all_reduce(self, t):
+        if self.dist is not None and self.world_size > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def begin(self):
+        self.ctx.loop_begin()
+        self.iterations_enqueued = 0
+
+    def iterate(self, fit=True, tol=0.0):
+        """Enqueue one iteration (no host synchronisation)."""
+        tol_abs = tol * self.n_total * self.f          # nmf.py:207 on the GLOBAL shape
+        self.ctx.iter_rowpass(fit)
+        self._all_reduce(self.loss_t)
+        self.ctx.iter_decide(tol_abs)
+        if fit:
+            self.ctx.iter_colpass()
+            self._all_reduce(self.numer_t)
+            self.ctx.iter_update_H()
+        self.ctx.iter_advance()
+        self.iterations_enqueued += 1
+
+    def end(self):
+        """Synchronise; returns (errors, n_done, stopped) -- identical on every rank."""
+        return self.ctx.loop_end(max(1, self.iterations_enqueued))
+
+    def run(self, max_iter=None, fit=True, tol=0.0):
+        max_iter = self.max_iter if max_iter is None else int(max_iter)
+        self.begin()
+        for _ in range(max_iter):
+            self.iterate(fit=fit, tol=tol)
+        return self.end()
+
+    # ---- results ----
+    def get_W_local(self, dtype=np.float64):
+        return self.ctx.get_W(dtype=dtype)
+
+    def get_H(self, dtype=np.float64):
+        return self.ctx.get_H(dtype=dtype)
+
+    def gather_W(self, dtype=np.float64):
+        """Full W on every rank (all-gather of the row shards; host side)."""
+        W = self.get_W_local(dtype=dtype)
+        if self.dist is None or self.world_size == 1:
+            return W
+        parts = [None] * self.world_size
+        self.dist.all_gather_object(parts, W, group=self.group)
+        return np.vstack(parts)
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,300 @@
+"""KL-divergence (I-divergence) NMF on MI355X -- host side.
+
+Same public surface as reference multimodal/lib/nmf.py (`KLdivNMF`, `_scale`,
+`_special_sparse_dot`, `check_non_negative`), so `multimodal/learner.py`,
+`experiment.py` and the sample scripts can use it unchanged.  All arithmetic of
+the path -- W0 = X.H0^T, the loss, the ratio Q, the W and H rules, the row
+normalisation and the stop rule of the loop -- runs in the HIP kernels of
+`csrc/` through the C-ABI of `include/klnmf.h`.  This module only validates
+input (the reference's ValueErrors are raised before anything is uploaded),
+moves arrays, and keeps the reference's object protocol (`components_`,
+`_init_dictionary`, `return_errors`, the stderr warning).
+
+There is no CPU implementation behind these calls: without the HIP extension or
+a gfx950 device they raise.
+
+Behaviour kept on purpose: `scale_W` passed to
+fit/fit_transform/transform is accepted and ignored (q1, nmf.py:222); the H
+rule pairs the ratio of the OLD W with the NEW W (q2, nmf.py:251-256, done that
+way inside the kernels); the random initial dictionary comes from the global
+`np.random` stream (q3, nmf.py:150); the loop's eps is the hard-coded 1e-8 (q4);
+the loss is recorded before each update and the breaking iteration's loss is not
+appended (q5, nmf.py:214-220).
+
+Extra (non-reference) constructor arguments: `precision` ('f64' default =
+the reference's float64 arithmetic; 'f32'; 'bf16' = MFMA fast path; 'bf16_v32'),
+`device`.  Environment: KLNMF_PRECISION, KLNMF_DEVICE.
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+from .array_utils import normalize_sum
+from .sklearn_utils import atleast2d_or_csr
+from .. import _native
+
+
+def _default_precision():
+    return os.environ.get('KLNMF_PRECISION', 'f64')
+
+
+def _default_device():
+    return int(os.environ.get('KLNMF_DEVICE', '0'))
+
+
+def check_non_negative(X, whom):
+    """ValueError on negative entries (reference nmf.py:23-26)."""
+    X = X.data if sp.issparse(X) else X
+    if (X < 0).any():
+        raise ValueError("Negative values in data passed to %s" % whom)
+
+
+def _scale(matrix, factors, axis=0):
+    """Scale the columns (axis=0) or the lines (axis=1) of a 2-D array by a
+    vector (reference nmf.py:29-49; host helper, not on the GPU loop)."""
+    if not (len(matrix.shape) == 2):
+        raise ValueError("Wrong array shape: %s, should have only 2 dimensions."
+                         % str(matrix.shape))
+    if axis not in (0, 1):
+        raise ValueError('Wrong axis, should be 0 (scaling lines) '
+                         'or 1 (scaling columns).')
+    factors = np.squeeze(np.asarray(factors))
+    if axis == 1:
+        factors = factors[:, np.newaxis]
+    return np.multiply(matrix, factors)
+
+
+def _special_sparse_dot(a, b, refmat):
+    """a.b sampled on the non-zeros of refmat, returned as CSR with refmat's
+    structure (reference nmf.py:52-70, including its `eliminate_zeros` side
+    effect on refmat).  Host scipy helper of the sparse branch, which is off
+    the GPU path (sparse input is densified before upload)."""
+    refmat.eliminate_zeros()
+    ii, jj = refmat.nonzero()
+    vals = np.einsum('ij,ij->i', a[ii, :], b.T[jj, :])
+    return sp.coo_matrix((vals, (ii, jj)), shape=refmat.shape).tocsr()
+
+
+def _dense(X):
+    """Dense ndarray of validated input (CSR is densified: the GPU path is
+    dense; Q off the non-zeros is ~1e-8/WH instead of exactly 0)."""
+    if sp.issparse(X):
+        return np.asarray(X.toarray())
+    return np.asarray(X)
+
+
+def _out_dtype(*arrays):
+    """The reference computes in float32 only if every operand is float32."""
+    if all(np.asarray(a).dtype == np.float32 for a in arrays):
+        return np.float32
+    return np.float64
+
+
+class KLdivNMF(object):
+    """Non negative factorization with Kullback Leibler divergence cost
+    (Lee & Seung multiplicative updates), GPU implementation of reference
+    nmf.py:73-351.
+
+    Parameters as in the reference: n_components, tol (1e-6), max_iter (200),
+    eps (1e-8; only used by `scale`), subit (unused), random_state (stored,
+    unused -- the reference never reads it either).
+    """
+
+    def __init__(self, n_components=None, tol=1e-6, max_iter=200, eps=1.e-8,
+                 subit=10, random_state=None, precision=None, device=None):
+        self.n_components = n_components
+        self._init_dictionary = None
+        self.random_state = random_state
+        self.tol = tol
+        self.max_iter = max_iter
+        self.eps = eps
+        self.subit = subit
+        self.precision = precision if precision is not None else _default_precision()
+        self.device = device if device is not None else _default_device()
+
+    # ------------------------------------------------------------ helpers ---
+    def _context(self, exact=False):
+        prec = self.precision
+        if exact and _native.PRECISIONS[prec] not in (_native.PREC_F64, _native.PREC_F32):
+            prec = 'f64'
+        return _native.Context(precision=prec, device=self.device)
+
+    @classmethod
+    def _exact_context(cls):
+        return _native.Context(precision=os.environ.get('KLNMF_STEP_PRECISION', 'f64'),
+                               device=_default_device())
+
+    def _init_H(self, n_features):
+        """Initial dictionary (reference nmf.py:149-155)."""
+        if self._init_dictionary is None:
+            return normalize_sum(np.abs(np.random.random(
+                (self.n_components, n_features))) + .01, axis=1)
+        assert(self._init_dictionary.shape ==
+               (self.n_components, n_features))
+        return self._init_dictionary
+
+    # --------------------------------------------------------------- loop ---
+    def fit_transform(self, X, y=None, weights=1., _fit=True,
+                      return_errors=False, scale_W=False):
+        """Learn a NMF model for X and return the transformed data
+        (reference nmf.py:159-230).  `y`, `weights`, `scale_W` are accepted and
+        ignored exactly as in the reference."""
+        X = atleast2d_or_csr(X)
+        check_non_negative(X, "NMF.fit")
+        return self._fit_blocks([X], [1.], _fit=_fit, return_errors=return_errors)
+
+    def _fit_blocks(self, blocks, coefs, _fit=True, return_errors=False):
+        """fit_transform of hstack([c * b for b, c in zip(blocks, coefs)])
+        without building the stacked matrix on the host: each modality block is
+        scaled, cast and placed by the upload kernel (learner.py:53-56 fused)."""
+        blocks = [_dense(b) for b in blocks]
+        n_samples = blocks[0].shape[0]
+        n_features = sum(b.shape[1] for b in blocks)
+        if not self.n_components:
+            self.n_components = n_features
+        H_init = self._init_H(n_features)
+        k = self.n_components
+        max_iter = int(self.max_iter)
+        out_dtype = _out_dtype(H_init, *blocks)
+
+        with self._context() as ctx:
+            ctx.set_problem(n_samples, n_features, k, max_iter)
+            col = 0
+            for b, c in zip(blocks, coefs):
+                ctx.upload_V(b, row0=0, col0=col, scale=c)
+                col += b.shape[1]
+            ctx.set_H(H_init)
+            ctx.init_W()                       # W0 = X . H_init^T (nmf.py:156)
+            if _fit:
+                self.components_ = H_init      # nmf.py:203-204
+            elif self.components_ is not H_init:
+                ctx.set_H(self.components_)    # loop runs on components_ (nmf.py:214)
+            tol_abs = self.tol * n_samples * n_features      # nmf.py:207
+            errors, n_done, stopped = ctx.run(max_iter, _fit, tol_abs)
+            W = ctx.get_W(dtype=out_dtype)
+            if _fit and n_done > 0:
+                self.components_ = ctx.get_H(dtype=out_dtype)
+
+        n_iter = n_done + 1 if stopped else max_iter
+        if max_iter > 0 and n_iter == max_iter and tol_abs > 0:   # nmf.py:224-225
+            sys.stderr.write("Warning: Iteration limit reached during fit\n")
+        if return_errors:
+            return W, errors
+        return W
+
+    def fit(self, X, y=None, **params):
+        """Learn a NMF model for X; returns self (reference nmf.py:259-273)."""
+        self.fit_transform(X, **params)
+        return self
+
+    def transform(self, X, **params):
+        """Coefficients of X for the fitted dictionary (reference
+        nmf.py:275-291; leaves `_init_dictionary` set, like the reference)."""
+        self._init_dictionary = self.components_
+        params['_fit'] = False
+        return self.fit_transform(X, **params)
+
+    def _transform_blocks(self, blocks, coefs, return_errors=False):
+        self._init_dictionary = self.components_
+        return self._fit_blocks(blocks, coefs, _fit=False, return_errors=return_errors)
+
+    # -------------------------------------------------------- single steps ---
+    def _update(self, X, W, _fit=True, scale_W=False, eps=1.e-8):
+        """One update iteration (reference nmf.py:232-257)."""
+        Xd = _dense(X)
+        if scale_W:
+            # dead from every caller in the reference (nmf.py:246-250), kept
+            W = _scale(normalize_sum(W, axis=1), np.asarray(X.sum(axis=1)).ravel(), axis=1)
+        if eps != 1.e-8 and _native.PRECISIONS[self.precision] >= _native.PREC_BF16:
+            raise ValueError("the bf16 kernels use the reference's fixed eps = 1e-8")
+        H = self.components_
+        with self._context() as ctx:
+            ctx.set_problem(Xd.shape[0], Xd.shape[1], H.shape[0], 1)
+            ctx.upload_V(Xd)
+            ctx.set_H(H)
+            ctx.set_W(W)
+            if eps != 1.e-8:
+                ctx.set_ratio_eps(eps)
+                ctx.step_Q()
+                ctx.step_W()
+                if _fit:
+                    ctx.step_H()
+            else:
+                ctx.update(_fit)
+            Wn = ctx.get_W(dtype=_out_dtype(Xd, W, H))
+            if _fit:
+                self.components_ = ctx.get_H(dtype=_out_dtype(Xd, W, H))
+        return Wn
+
+    def error(self, X, W, H=None, weights=1., eps=1.e-8):
+        """generalized_KL(X, W.H) (reference nmf.py:297-310; `weights` and `eps`
+        are ignored by the reference's dense branch too)."""
+        X = atleast2d_or_csr(X)
+        if H is None:
+            H = self.components_
+        Xd = _dense(X)
+        with self._context() as ctx:
+            ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
+            ctx.upload_V(Xd)
+            ctx.set_H(H)
+            ctx.set_W(W)
+            return ctx.error()
+
+    def scale(self, W, H, factors):
+        """Scale W columns and H rows inversely (reference nmf.py:314-321)."""
+        safe_factors = factors + self.eps
+        s_W = _scale(W, safe_factors, axis=0)
+        s_H = _scale(H, 1. / safe_factors, axis=1)
+        return s_W, s_H
+
+    @classmethod
+    def _Q(cls, X, W, H, eps=1.e-8):
+        """(X + eps) / (W.H + eps), element-wise (reference nmf.py:325-336).
+        CSR input gives a CSR result on X's structure, as in the reference."""
+        Xd = _dense(X)
+        with cls._exact_context() as ctx:
+            ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
+            ctx.upload_V(Xd)
+            ctx.set_H(H)
+            ctx.set_W(W)
+            ctx.set_ratio_eps(eps)
+            ctx.step_Q()
+            Q = ctx.get_Q(dtype=_out_dtype(Xd, W, H))
+        if sp.issparse(X):
+            Xc = X.tocsr(copy=True)
+            Xc.eliminate_zeros()
+            ii, jj = Xc.nonzero()
+            return sp.coo_matrix((Q[ii, jj], (ii, jj)), shape=Xc.shape).tocsr()
+        return Q
+
+    @classmethod
+    def _step(cls, X, W, H, Q, eps, which):
+        Xd = _dense(X)
+        with cls._exact_context() as ctx:
+            ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
+            ctx.upload_V(Xd)
+            ctx.set_H(H)
+            ctx.set_W(W)
+            if Q is None:
+                ctx.set_ratio_eps(eps)
+                ctx.step_Q()
+            else:
+                ctx.set_Q(_dense(Q))
+            dt = _out_dtype(Xd, W, H)
+            if which == 'W':
+                ctx.step_W()
+                return ctx.get_W(dtype=dt)
+            ctx.step_H()
+            return ctx.get_H(dtype=dt)
+
+    @classmethod
+    def _updated_W(cls, X, W, H, weights=1., Q=None, eps=1.e-8):
+        """W * (Q.H^T) (reference nmf.py:338-343)."""
+        return cls._step(X, W, H, Q, eps, 'W')
+
+    @classmethod
+    def _updated_H(cls, X, W, H, weights=1., Q=None, eps=1.e-8):
+        """normalize_rows(H * (W^T.Q)) (reference nmf.py:345-351)."""
+        return cls._step(X, W, H, Q, eps, 'H')

@@ -1,0 +1,395 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden vectors
+captured from the reference and against the fp64 oracle on seeded inputs.
+
+Tolerances (stated per mode):
+  f64   -- the reference's own arithmetic; only summation order differs:
+           rtol 1e-9 on W/H, 1e-10 on losses, identical iteration counts.
+  f32   -- fp32 everywhere: losses rtol 2e-5, W/H rtol 2e-3 (vs the fp32 run of
+           the reference, fixture G7, and vs the fp64 oracle).
+  bf16  -- bf16 MFMA operands (W, H, Q rounded to bf16, V stored bf16), fp32
+           accumulate and masters: final loss within 1e-4 relative of the fp64
+           oracle (the north-star tolerance), every recorded loss within 1e-3,
+           W/H within 3e-2 of the row/matrix max.
+"""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from numpy.testing import assert_allclose
+
+from oracle import klnmf_oracle as orc
+from tests import golden_inputs as gi
+from multimodal_amd import _native
+from multimodal_amd.lib import nmf
+from multimodal_amd.lib.metrics import generalized_KL
+from multimodal_amd.learner import MultimodalLearner, fit_coefficients
+
+pytestmark = pytest.mark.gpu
+
+
+def fit_gpu(X, H0, k, max_iter, tol, precision='f64', fit=True, components=None):
+    m = nmf.KLdivNMF(n_components=k, max_iter=max_iter, tol=tol, precision=precision)
+    m._init_dictionary = H0
+    if not fit:
+        m.components_ = components
+    buf = io.StringIO()
+    with contextlib.redirect_stderr(buf):
+        W, errors = m.fit_transform(X, return_errors=True, scale_W=True, _fit=fit)
+    return m, W, np.array(errors), buf.getvalue()
+
+
+def test_hardware_probes():
+    """MFMA operand/accumulator maps, ds_read_b64_tr_b16 addressing, accumulator
+    as next B operand, global_load_lds destination: bit-exact integer checks."""
+    assert _native.selftest(0) == 0
+    info = _native.device_info(0)
+    assert info['arch'].startswith('gfx950')
+
+
+# =============================================================== f64 mode ===
+
+@pytest.mark.parametrize('name', ['g1_20x30_k3', 'g1_37x53_k7', 'g1_500x1000_k10'])
+def test_f64_fit_matches_reference_golden(name):
+    g = gi.load(name)
+    k = int(g['k'])
+    X, H0 = gi.gen_inputs(int(g['seed']), int(g['n']), int(g['f']), k)
+    for it in g['iters']:
+        m, W, errors, _ = fit_gpu(X, H0, k, int(it), 0)
+        assert len(errors) == len(g['errors_%d' % it])
+        assert_allclose(errors, g['errors_%d' % it], rtol=1e-10)
+        assert_allclose(W, g['W_%d' % it], rtol=1e-9, atol=1e-13)
+        assert_allclose(m.components_, g['H_%d' % it], rtol=1e-9, atol=1e-15)
+        assert_allclose(m.error(X, W), g['final_%d' % it], rtol=1e-10)
+
+
+def test_f64_transform_matches_reference_golden():
+    g = gi.load('g2_transform')
+    X, H0, Xt = gi.g2_inputs(g)
+    t = nmf.KLdivNMF(n_components=int(g['k']), max_iter=25, tol=0)
+    t.components_ = g['H']
+    Wt, et = t.transform(Xt, return_errors=True, scale_W=True)
+    assert_allclose(Wt, g['Wt'], rtol=1e-9)
+    assert_allclose(et, g['errors_t'], rtol=1e-10)
+    assert t.components_ is g['H'] or (t.components_ == g['H']).all()
+    a, b = g['sl']
+    t2 = nmf.KLdivNMF(n_components=int(g['k']), max_iter=25, tol=0)
+    t2.components_ = g['H'][:, a:b]            # rows no longer sum to 1
+    Ws, es = t2.transform(Xt[:, a:b], return_errors=True, scale_W=True)
+    assert_allclose(Ws, g['Ws'], rtol=1e-9)
+    assert_allclose(es, g['errors_s'], rtol=1e-10)
+    # fit_coefficients is the same thing (learner.py:11-15)
+    assert_allclose(fit_coefficients(Xt, g['H'], iter_nmf=25), g['Wt'], rtol=1e-9)
+
+
+def test_f64_single_steps_match_reference_golden():
+    g = gi.load('g3_steps')
+    X, W, H = gi.g3_inputs(g)
+    m = nmf.KLdivNMF(n_components=int(g['k']))
+    m.components_ = H.copy()
+    Q = m._Q(X, W, H)
+    assert_allclose(Q, g['Q'], rtol=1e-12)
+    Wn = m._updated_W(X, W, H, Q=Q)
+    assert_allclose(Wn, g['Wn'], rtol=1e-12)
+    assert_allclose(m._updated_H(X, Wn, H, Q=Q), g['Hn'], rtol=1e-12)   # new W, old Q
+    assert_allclose(m._updated_H(X, W, H), g['Hn_noq'], rtol=1e-12)
+    assert_allclose(m._updated_W(X, W, H), g['Wn'], rtol=1e-12)
+    assert_allclose(m.error(X, W, H=H), g['err'], rtol=1e-12)
+    assert_allclose(m.error(X, W), g['err'], rtol=1e-12)                 # H defaults to components_
+    W_upd = m._update(X, W, _fit=True)
+    assert_allclose(W_upd, g['W_upd'], rtol=1e-12)
+    assert_allclose(m.components_, g['H_upd'], rtol=1e-12)
+    m2 = nmf.KLdivNMF(n_components=int(g['k']))
+    m2.components_ = H.copy()
+    W_s = m2._update(X, W, _fit=True, scale_W=True)
+    assert_allclose(W_s, g['W_upd_scaled'], rtol=1e-12)
+    assert_allclose(m2.components_, g['H_upd_scaled'], rtol=1e-12)
+    # _fit=False: dictionary untouched, bit for bit (tests/test_nmf_kl.py:132-134)
+    m3 = nmf.KLdivNMF(n_components=int(g['k']))
+    m3.components_ = H
+    m3._update(X, W, _fit=False)
+    assert (m3.components_ == H).all()
+    # custom eps is honoured by _Q (nmf.py:325)
+    assert_allclose(m._Q(X, W, H, eps=1e-3), (X + 1e-3) / (W.dot(H) + 1e-3), rtol=1e-12)
+
+
+def test_f64_stop_rule_and_warning_match_reference_golden():
+    g = gi.load('g4_tol')
+    k = int(g['k'])
+    X, H0 = gi.gen_inputs(int(g['seed']), int(g['n']), int(g['f']), k)
+    for sfx, it, tol in [('', 200, 1e-6), ('2', 200, 1e-3), ('3', 4, 1e-9)]:
+        m, W, errors, msg = fit_gpu(X, H0, k, it, tol)
+        assert len(errors) == len(g['errors' + sfx])      # same early-stop iteration
+        assert_allclose(errors, g['errors' + sfx], rtol=1e-10)
+        assert_allclose(W, g['W' + sfx], rtol=1e-8)
+        assert_allclose(m.components_, g['H' + sfx], rtol=1e-8)
+        assert bool(msg) == bool(g['warned' + sfx])
+        if msg:
+            assert msg == str(g['msg3'])
+    m4, W4, e4, _ = fit_gpu(g['Xf'], g['H0f'], 3, 200, 1e-6)
+    assert len(e4) == len(g['errors4'])
+    assert_allclose(e4, g['errors4'], rtol=1e-6, atol=1e-13)
+    assert e4[-1] < e4[0] * 1e-3
+
+
+@pytest.mark.parametrize('name', ['g5_learner2', 'g5_learner3'])
+def test_f64_learner_matches_reference_golden(name):
+    g = gi.load(name)
+    blocks, dims, H0, test = gi.g5_inputs(g)
+    coefs = [float(c) for c in g['coefs']]
+    mods = ['m%d' % i for i in range(len(dims))]
+    k = int(g['k'])
+    lr = MultimodalLearner(mods, dims, coefs, k)
+    # inject H0 (train() draws it from np.random in the reference)
+    import multimodal_amd.learner as L
+    orig = L.NMF
+
+    def factory(**kw):
+        m = orig(**kw)
+        m._init_dictionary = H0.copy()
+        return m
+    L.NMF = factory
+    try:
+        lr.train(blocks, 20)
+    finally:
+        L.NMF = orig
+    assert_allclose(lr.dico, g['dico'], rtol=1e-9)
+    assert_allclose(lr.stack_data(mods, blocks).sum(axis=0), g['stacked_sum'], rtol=1e-12)
+    for i, mname in enumerate(mods):
+        assert_allclose(lr.get_dico(mname), g['dico_%d' % i], rtol=1e-9)
+        assert_allclose(lr.reconstruct_internal(mname, test[i], 15),
+                        g['internal_%d' % i], rtol=1e-8)
+    assert_allclose(lr.reconstruct_internal_multi(mods[:2], test[:2], 15),
+                    g['internal_01'], rtol=1e-8)
+    assert_allclose(lr.modality_to_modality(mods[0], mods[1], test[0], 15),
+                    g['m2m_0_to_1'], rtol=1e-8)
+
+
+def test_f64_sparse_input_is_densified():
+    g = gi.load('g6_sparse')
+    dense, W, H = gi.g6_inputs(g)
+    X = sp.csr_matrix(dense)
+    m = nmf.KLdivNMF(n_components=int(g['k']))
+    m.components_ = H.copy()
+    assert_allclose(m.error(X, W, H=H), g['err'], rtol=1e-7)
+    Q = m._Q(X, W, H)
+    assert sp.isspmatrix_csr(Q)
+    assert_allclose(np.asarray(Q.todense())[dense != 0], g['Q_dense'][dense != 0], rtol=1e-12)
+    Wn = m._update(X, W, _fit=True)
+    assert_allclose(Wn, g['Wn'], rtol=1e-5)
+    assert_allclose(m.components_, g['Hn'], rtol=1e-5)
+
+
+def test_f64_known_answers_and_edges():
+    g = gi.load('g8_known')
+    x = np.array([[1., 2.], [3., 4.]])
+    y = np.array([[2., 2.], [1., 4.]])
+    assert_allclose(generalized_KL(x, y), g['gkl'], rtol=1e-13)
+    assert_allclose(generalized_KL(x, y, axis=0), g['gkl_axis0'], rtol=1e-13)
+    assert_allclose(generalized_KL(x, y, axis=1), g['gkl_axis1'], rtol=1e-13)
+    # reference tests/test_metrics.py:48-54
+    xz = np.zeros((4, 2))
+    xz[1, 1] = 1
+    assert_allclose(generalized_KL(xz, .5 * np.ones((4, 2))), np.log(2.) + 3., atol=1e-6)
+    assert generalized_KL(x, x) == 0
+    # all-zero row / column stay finite; zero row gives W row == 0 exactly
+    X, H0 = gi.g8_edge_inputs()
+    m, W, errors, _ = fit_gpu(X, H0, 3, 10, 0)
+    assert_allclose(W, g['edge_W'], rtol=1e-9, atol=1e-300)
+    assert_allclose(m.components_, g['edge_H'], rtol=1e-9, atol=1e-300)
+    assert_allclose(errors, g['edge_errors'], rtol=1e-10)
+    assert np.all(W[4] == 0) and np.all(np.isfinite(m.components_))
+
+
+def test_f64_reference_property_tests():
+    """The unseeded property tests of reference tests/test_nmf_kl.py:104-172."""
+    rs = np.random.RandomState(7)
+    X = np.abs(rs.random_sample((20, 30)))
+    W = np.abs(rs.random_sample((20, 3)))
+    H = np.abs(rs.random_sample((3, 30)))
+    m = nmf.KLdivNMF(n_components=3, tol=1e-4, max_iter=200, eps=1.e-8, subit=10)
+    m.components_ = H
+    assert np.all(m._updated_W(X, W, H) >= 0)
+    assert np.all(m._updated_H(X, W, H) >= 0)
+    before = m.error(X, W)
+    Wn = m._update(X, W, _fit=True)
+    assert before > m.error(X, Wn)
+    # test_cv / test_no_compenents_update
+    m2 = nmf.KLdivNMF(n_components=3, tol=1e-6, max_iter=200)
+    Xs = np.abs(rs.random_sample((10, 5)))
+    with contextlib.redirect_stderr(io.StringIO()):
+        _, errors = m2.fit_transform(Xs, return_errors=True)
+    assert abs(errors[-1] - errors[-2]) < errors[0] * 1.e-2
+    comps = np.abs(rs.random_sample((3, 5)))
+    m2.components_ = comps
+    m2._init_dictionary = None
+    with contextlib.redirect_stderr(io.StringIO()):
+        m2.fit_transform(np.abs(rs.random_sample((10, 5))), comps, _fit=False)
+    assert (m2.components_ == comps).all()
+    # integer input and nested lists are accepted (promoted to float64)
+    m3 = nmf.KLdivNMF(n_components=2, max_iter=3, tol=0)
+    assert m3.fit_transform([[1, 2, 3], [4, 5, 6]]).shape == (2, 2)
+
+
+# =============================================================== f32 mode ===
+
+def test_f32_matches_reference_float32_run():
+    g = gi.load('g7_float32')
+    k = int(g['k'])
+    X, H0 = gi.gen_inputs(int(g['seed']), int(g['n']), int(g['f']), k)
+    m, W, errors, _ = fit_gpu(X.astype(np.float32), H0.astype(np.float32), k, 40, 0,
+                              precision='f32')
+    assert W.dtype == np.float32
+    assert len(errors) == len(g['errors'])
+    assert_allclose(errors, g['errors'], rtol=2e-5)
+    assert_allclose(W, g['W'], rtol=2e-3, atol=1e-5)
+    assert_allclose(m.components_, g['H'], rtol=2e-3, atol=1e-7)
+
+
+# ============================================================== bf16 modes ===
+
+def _rel_to_max(a, b):
+    return np.max(np.abs(a - b)) / np.max(np.abs(b))
+
+
+BF16_CASES = [
+    # n, f, k, iters           (k -> KT = ceil(k/32); odd/even MFMA k-steps; ragged n, f)
+    (37, 53, 7, 10),
+    (64, 64, 32, 5),
+    (500, 1000, 10, 50),       # BASELINE config 1 shape
+    (300, 257, 33, 8),         # KT=2, 3 k-steps
+    (1000, 520, 50, 20),       # config-2 k
+    (700, 384, 100, 8),
+    (520, 1030, 200, 12),      # config-3/4 k: KT=7, 13 k-steps
+    (260, 300, 256, 5),        # largest k the MFMA kernels take
+]
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'bf16_v32'])
+@pytest.mark.parametrize('n,f,k,iters', BF16_CASES)
+def test_bf16_fit_matches_oracle(n, f, k, iters, prec):
+    X = orc.synthetic_V(1234, n, f, k)
+    H0 = orc.synthetic_H0(1234, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision=prec)
+    assert len(errors) == len(eo) == iters
+    assert_allclose(errors, eo, rtol=1e-3)
+    final_o = orc.kl_error(X, Wo, Ho)
+    final_g = m.error(X, W)
+    assert abs(final_g - final_o) <= 1e-4 * abs(final_o), (final_g, final_o)
+    assert np.all(W >= 0) and np.all(m.components_ >= 0)
+    assert_allclose(m.components_.sum(axis=1), 1.0, rtol=1e-5)
+    assert _rel_to_max(W, Wo) < 3e-2
+    assert _rel_to_max(m.components_, Ho) < 3e-2
+
+
+def test_bf16_pieces_match_oracle():
+    n, f, k = 200, 333, 70
+    X = orc.synthetic_V(99, n, f, k)
+    H = orc.synthetic_H0(99, f, k)
+    with _native.Context('bf16') as ctx:
+        ctx.set_problem(n, f, k, 4)
+        ctx.upload_V(X)
+        ctx.set_H(H)
+        ctx.init_W()
+        W0 = ctx.get_W()
+        assert_allclose(W0, X.dot(H.T), rtol=2e-2, atol=1e-6)      # bf16 operands
+        loss = ctx.error()
+        assert_allclose(loss, orc.kl_error(X, W0, H), rtol=1e-4)
+        ctx.update(True)
+        W1, H1 = ctx.get_W(), ctx.get_H()
+    Wo, Ho = orc.update_step(X, W0, H, fit=True)
+    assert _rel_to_max(W1, Wo) < 1e-2
+    assert _rel_to_max(H1, Ho) < 1e-2
+
+
+def test_bf16_transform_and_learner():
+    rs = np.random.RandomState(3)
+    dims = (96, 40)
+    n, k = 150, 12
+    blocks = [np.abs(rs.random_sample((n, d))) for d in dims]
+    coefs = [float(1. / np.mean(np.sum(b, axis=1))) for b in blocks]
+    H0 = orc.synthetic_H0(5, sum(dims), k)
+    dico_o, _ = orc.learner_train(blocks, coefs, k, 15, H0)
+    import multimodal_amd.learner as L
+    orig = L.NMF
+
+    def factory(**kw):
+        kw['precision'] = 'bf16'
+        m = orig(**kw)
+        if m._init_dictionary is None and kw.get('n_components') == k and not hasattr(factory, 'done'):
+            m._init_dictionary = H0.copy()
+            factory.done = True
+        return m
+    L.NMF = factory
+    try:
+        lr = MultimodalLearner(['a', 'b'], list(dims), coefs, k)
+        lr.train(blocks, 15)
+        assert _rel_to_max(lr.dico, dico_o) < 3e-2
+        test = [np.abs(rs.random_sample((9, d))) for d in dims]
+        Wi = lr.reconstruct_internal('a', test[0], 10)
+    finally:
+        L.NMF = orig
+    Wo = orc.learner_internal([test[0]], [coefs[0]], [lr.dico[:, :dims[0]]], 10)
+    assert _rel_to_max(Wi, Wo) < 3e-2
+
+
+def test_bf16_stop_rule_fires_like_oracle():
+    g = gi.load('g4_tol')
+    k = int(g['k'])
+    X, H0 = gi.gen_inputs(int(g['seed']), int(g['n']), int(g['f']), k)
+    m, W, errors, msg = fit_gpu(X, H0, k, 200, 1e-3, precision='bf16')
+    # loose tolerance: stops within a couple of iterations of the fp64 run
+    assert abs(len(errors) - len(g['errors2'])) <= 2
+    assert not msg
+
+
+def test_bf16_edge_cases():
+    X, H0 = gi.g8_edge_inputs()          # an all-zero row and an all-zero column
+    m, W, errors, _ = fit_gpu(X, H0, 3, 10, 0, precision='bf16')
+    assert np.all(np.isfinite(W)) and np.all(np.isfinite(m.components_))
+    assert np.all(W[4] == 0)
+    Wo, Ho, eo = orc.fit_transform(X, k=3, H0=H0, max_iter=10, tol=0)
+    assert_allclose(errors, eo, rtol=2e-3)
+    with pytest.raises(RuntimeError):    # k > 256 is refused loudly, not emulated
+        fit_gpu(np.ones((8, 300)), orc.synthetic_H0(1, 300, 257), 257, 1, 0, precision='bf16')
+
+
+# ==================================================== full-size properties ===
+
+def test_config2_shape_properties_bf16():
+    """BASELINE config 2 shape (50k x 4096, k=50) at full size: size-independent
+    properties (monotone loss, row-stochastic H, non-negativity) + the loss of a
+    row sample checked against the oracle."""
+    n, f, k = 50000, 4096, 50
+    X = orc.synthetic_V(1234, n, f, k).astype(np.float32)
+    H0 = orc.synthetic_H0(1234, f, k)
+    m, W, errors, _ = fit_gpu(X, H0, k, 6, 0, precision='bf16')
+    assert len(errors) == 6
+    assert np.all(np.diff(errors) < 0)
+    assert np.all(np.isfinite(W)) and np.all(W >= 0)
+    assert_allclose(m.components_.sum(axis=1), 1.0, rtol=1e-5)
+    # additivity of the loss over row blocks: sample 2000 rows on the CPU
+    idx = np.arange(0, n, 25)
+    Xs = X[idx].astype(np.float64)
+    ls = orc.kl_error(Xs, W[idx], m.components_)
+    with _native.Context('bf16') as ctx:
+        ctx.set_problem(len(idx), f, k, 1)
+        ctx.upload_V(Xs)
+        ctx.set_H(m.components_)
+        ctx.set_W(W[idx])
+        assert_allclose(ctx.error(), ls, rtol=1e-4)
+
+
+def test_config4_k_and_f_at_reduced_rows_bf16():
+    """Config 4's f=4096, k=200 with 8192 rows: 3 iterations against the oracle."""
+    n, f, k = 8192, 4096, 200
+    X = orc.synthetic_V(1234, n, f, k)
+    H0 = orc.synthetic_H0(1234, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=3, tol=0)
+    m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
+    assert_allclose(errors, eo, rtol=1e-3)
+    fo, fg = orc.kl_error(X, Wo, Ho), m.error(X, W)
+    assert abs(fg - fo) <= 1e-4 * abs(fo)
+    assert _rel_to_max(m.components_, Ho) < 3e-2
