@@ -59,6 +59,18 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192):
     g.manual_seed(seed)                       # Ht identical on every rank
     Ht = torch._standard_gamma(torch.full((k, f), 0.5, device=dev), generator=g)
     g.manual_seed(seed + 1000 * (rank + 1))
+    # the 16-bit storage factor needs the global max before the first upload:
+    # generate once for the max, then regenerate the identical stream for the upload
+    state = g.get_state()
+    vmax = 0.0
+    for r0 in range(0, n_local, block):
+        rows = min(block, n_local - r0)
+        Wt = torch._standard_gamma(torch.ones((rows, k), device=dev), generator=g)
+        Vb = torch.rand((rows, f), device=dev, generator=g).mul_(0.05)
+        Vb.addmm_(Wt, Ht, alpha=1.0 / k)
+        vmax = max(vmax, float(Vb.max().item()))
+    model.set_v_max(vmax)
+    g.set_state(state)
     for r0 in range(0, n_local, block):
         rows = min(block, n_local - r0)
         Wt = torch._standard_gamma(torch.ones((rows, k), device=dev), generator=g)
@@ -107,7 +119,7 @@ def gpu_parity_on_sample(args, sample):
     X, H0, iters, losses, final = sample
     with _native.Context(args.precision, device=0) as ctx:
         ctx.set_problem(X.shape[0], X.shape[1], args.k, iters)
-        ctx.upload_V(X)
+        ctx.upload_blocks([X])
         ctx.set_H(H0)
         ctx.init_W()
         errs, n_done, stopped = ctx.run(iters, True, 0.0)

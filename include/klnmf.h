@@ -38,7 +38,7 @@ extern "C" {
 /* arithmetic modes */
 #define KLNMF_PREC_F64      0        /* fp64 everywhere (reference arithmetic)      */
 #define KLNMF_PREC_F32      1        /* fp32 everywhere                              */
-#define KLNMF_PREC_BF16     2        /* bf16 MFMA operands, fp32 accumulate/masters, V stored bf16 */
+#define KLNMF_PREC_BF16     2        /* bf16 MFMA operands, fp32 accumulate/masters, V stored 16-bit (scaled fp16) */
 #define KLNMF_PREC_BF16_V32 3        /* as BF16 but V stored fp32                    */
 
 /* host element types for uploads / downloads */
@@ -68,6 +68,11 @@ int klnmf_set_problem(klnmf_ctx *ctx, int64_t n, int64_t f, int64_t k,
                       int64_t max_iter_capacity);
 
 /* ---- data in ------------------------------------------------------------ */
+/* KLNMF_PREC_BF16 stores V as fp16 of c*V with c the power of two that puts
+ * c*vmax in [2^14, 2^15); call this with vmax >= max(scale * src) over ALL
+ * blocks (and all ranks: the factor must be common) before the first upload.
+ * Without it c = 1 (fine for data in fp16's range).  No-op in the other modes. */
+int klnmf_set_v_max(klnmf_ctx *ctx, double vmax);
 /* Upload the sub-block V[row0:row0+rows, col0:col0+cols] = scale * src, src a
  * host array with leading dimension ld (elements).  One call per modality
  * block replaces learner.py:53-56 (`safe_hstack([c * m ...])`): the scale,

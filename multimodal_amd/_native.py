@@ -33,6 +33,7 @@ SIGNATURES = {
     'klnmf_create': (_c.c_int, [_c.POINTER(_ctx_p), _c.c_int, _c.c_int, _c.c_void_p]),
     'klnmf_destroy': (_c.c_int, [_ctx_p]),
     'klnmf_set_problem': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64]),
+    'klnmf_set_v_max': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_upload_V': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64, _i64, _i64,
                                   _i64, _i64, _c.c_double]),
     'klnmf_upload_V_device': (_c.c_int, [_ctx_p, _c.c_void_p, _i64, _i64, _i64, _i64,
@@ -187,6 +188,9 @@ class Context(object):
         _check(self._lib.klnmf_set_problem(self._h, n, f, k, max(1, max_iter_capacity)))
         self.n, self.f, self.k, self.cap = n, f, k, max(1, max_iter_capacity)
 
+    def set_v_max(self, vmax):
+        _check(self._lib.klnmf_set_v_max(self._h, float(vmax)))
+
     def upload_V(self, block, row0=0, col0=0, scale=1.0):
         """V[row0:, col0:] block = scale * block (any strides; row-major view
         is uploaded without a host copy when rows are contiguous)."""
@@ -204,6 +208,21 @@ class Context(object):
         _check(self._lib.klnmf_upload_V(self._h, a.ctypes.data, _np_dtype_code(a),
                                         a.shape[0], a.shape[1], ld, row0, col0,
                                         float(scale)))
+
+    def upload_blocks(self, blocks, scales=None):
+        """Upload hstack([s * b ...]) block by block (one fused scale/cast/place
+        kernel per block) after fixing the 16-bit storage factor from the
+        global maximum."""
+        scales = [1.0] * len(blocks) if scales is None else scales
+        vmax = 0.0
+        for b, s in zip(blocks, scales):
+            if b.size:
+                vmax = max(vmax, float(s) * float(np.max(b)))
+        self.set_v_max(vmax)
+        col = 0
+        for b, s in zip(blocks, scales):
+            self.upload_V(b, row0=0, col0=col, scale=s)
+            col += b.shape[1]
 
     def upload_V_device(self, dev_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
         _check(self._lib.klnmf_upload_V_device(self._h, _c.c_void_p(dev_ptr), rows, cols, ld,

@@ -108,6 +108,8 @@ struct klnmf_ctx {
 
     // profiling
     double ratio_eps = kEpsRatio;   // only the step API honours a non-default value
+    double v_scale = 1.0;           // storage factor c of the 16-bit V (power of two)
+    bool v_uploaded = false;
 
     bool profiling = false;
     std::vector<EventPair> ev_row, ev_col;
@@ -156,20 +158,26 @@ EventPair begin_event(klnmf_ctx *c, std::vector<EventPair> &v) {
 }
 
 // ---------------------------------------------------------------- dispatch ---
+template <int KT, int ODD, int MODE, typename VT>
+void launch_rowpass_one(klnmf_ctx *c, const RowPassArgs &a, int grid) {
+    auto kern = k_rowpass<KT, ODD, MODE, VT>;
+    const int lds = row_lds_bytes<VT>(32 * KT);
+    static thread_local int attr_dev = -1;
+    if (attr_dev != c->device) {
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_dev = c->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);
+}
+
 template <int MODE, typename VT>
 void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
-#define KL_ROW_CASE(KTV)                                                                        \
-    case KTV: {                                                                                 \
-        auto kern = k_rowpass<KTV, MODE, VT>;                                                   \
-        const int lds = 2 * h_stage_lds(32 * KTV);                                              \
-        static thread_local int attr_dev = -1;                                                  \
-        if (attr_dev != c->device) {                                                            \
-            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr_dev = c->device;                                                               \
-        }                                                                                       \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);                \
-        break;                                                                                  \
-    }
+    const int odd = 2 * c->KT - c->ks;
+#define KL_ROW_CASE(KTV)                                                        \
+    case KTV:                                                                   \
+        if (odd) launch_rowpass_one<KTV, 1, MODE, VT>(c, a, grid);              \
+        else launch_rowpass_one<KTV, 0, MODE, VT>(c, a, grid);                  \
+        break;
     switch (c->KT) {
         KL_ROW_CASE(1) KL_ROW_CASE(2) KL_ROW_CASE(3) KL_ROW_CASE(4)
         KL_ROW_CASE(5) KL_ROW_CASE(6) KL_ROW_CASE(7) KL_ROW_CASE(8)
@@ -179,20 +187,26 @@ void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
     HIPCHK(hipGetLastError());
 }
 
+template <int KT, int ODD, typename VT>
+void launch_colpass_one(klnmf_ctx *c, const ColPassArgs &a, int grid) {
+    auto kern = k_colpass<KT, ODD, VT>;
+    const int lds = 4 * w_stage_lds(32 * KT);
+    static thread_local int attr_dev = -1;
+    if (attr_dev != c->device) {
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_dev = c->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);
+}
+
 template <typename VT>
 void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
-#define KL_COL_CASE(KTV)                                                                        \
-    case KTV: {                                                                                 \
-        auto kern = k_colpass<KTV, VT>;                                                         \
-        const int lds = 4 * w_stage_lds(32 * KTV);                                              \
-        static thread_local int attr_dev = -1;                                                  \
-        if (attr_dev != c->device) {                                                            \
-            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr_dev = c->device;                                                               \
-        }                                                                                       \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);                \
-        break;                                                                                  \
-    }
+    const int odd = 2 * c->KT - c->ks;
+#define KL_COL_CASE(KTV)                                                        \
+    case KTV:                                                                   \
+        if (odd) launch_colpass_one<KTV, 1, VT>(c, a, grid);                    \
+        else launch_colpass_one<KTV, 0, VT>(c, a, grid);                        \
+        break;
     switch (c->KT) {
         KL_COL_CASE(1) KL_COL_CASE(2) KL_COL_CASE(3) KL_COL_CASE(4)
         KL_COL_CASE(5) KL_COL_CASE(6) KL_COL_CASE(7) KL_COL_CASE(8)
@@ -215,20 +229,20 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     a.nrt = c->nrt;
     a.nct = c->nct;
     a.nst = c->nst;
-    a.ks = c->ks;
+    a.eps = (float)(kEpsRatio * c->v_scale);
     const int grid = (c->nrt + kWavesPerWG - 1) / kWavesPerWG;
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
     const bool v16 = c->prec == KLNMF_PREC_BF16;
     switch (mode) {
         case ROW_UPDATE:
-            v16 ? launch_rowpass_kt<ROW_UPDATE, __bf16>(c, a, grid) : launch_rowpass_kt<ROW_UPDATE, float>(c, a, grid);
+            v16 ? launch_rowpass_kt<ROW_UPDATE, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_UPDATE, float>(c, a, grid);
             break;
         case ROW_INIT:
-            v16 ? launch_rowpass_kt<ROW_INIT, __bf16>(c, a, grid) : launch_rowpass_kt<ROW_INIT, float>(c, a, grid);
+            v16 ? launch_rowpass_kt<ROW_INIT, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_INIT, float>(c, a, grid);
             break;
         default:
-            v16 ? launch_rowpass_kt<ROW_LOSS, __bf16>(c, a, grid) : launch_rowpass_kt<ROW_LOSS, float>(c, a, grid);
+            v16 ? launch_rowpass_kt<ROW_LOSS, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_LOSS, float>(c, a, grid);
             break;
     }
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
@@ -247,12 +261,12 @@ void fast_colpass(klnmf_ctx *c) {
     a.ncb = c->ncb;
     a.nchunks = c->nchunks;
     a.stages_per_chunk = c->stages_per_chunk;
-    a.ks = c->ks;
     a.f_pad = c->f_pad;
+    a.eps = (float)(kEpsRatio * c->v_scale);
     const int grid = c->ncb * c->nchunks;
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_col);
-    if (c->prec == KLNMF_PREC_BF16) launch_colpass_kt<__bf16>(c, a, grid);
+    if (c->prec == KLNMF_PREC_BF16) launch_colpass_kt<_Float16>(c, a, grid);
     else launch_colpass_kt<float>(c, a, grid);
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     const int64_t count = (int64_t)c->KP * c->f_pad;
@@ -347,7 +361,7 @@ void piece_rowpass(klnmf_ctx *c, int fit) {
         fast_rowpass(c, ROW_UPDATE);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const float2 *)c->loss_part2, (int64_t)c->nrt, (const DevState *)c->st,
-                           c->loss_xchg);
+                           1.0 / c->v_scale, c->loss_xchg);
         HIPCHK(hipGetLastError());
     }
 }
@@ -403,9 +417,9 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
                                (float *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale);
             break;
         case KLNMF_PREC_BF16:
-            hipLaunchKernelGGL((k_tile_V<__bf16, S>), dim3(grid), dim3(256), 0, c->stream,
-                               (__bf16 *)c->VtA, (__bf16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
-                               ld, row0, col0, scale, c->st);
+            hipLaunchKernelGGL((k_tile_V<_Float16, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (_Float16 *)c->VtA, (_Float16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
+                               ld, row0, col0, scale * c->v_scale, c->st);
             break;
         default:
             hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
@@ -414,6 +428,7 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
             break;
     }
     HIPCHK(hipGetLastError());
+    c->v_uploaded = true;
 }
 
 void check_block(klnmf_ctx *c, int64_t rows, int64_t cols, int64_t ld, int64_t row0, int64_t col0) {
@@ -443,7 +458,7 @@ void *stage_to_device(klnmf_ctx *c, const void *src, int dtype, int64_t count) {
 
 // dense [rows,cols] host array -> device array of the context's element type / padded fp32
 void set_matrix(klnmf_ctx *c, const void *src, int dtype, int64_t rows, int64_t cols, void *exact_dst,
-                float *fast_dst, int64_t fast_ld) {
+                float *fast_dst, int64_t fast_ld, double mul = 1.0) {
     const int64_t count = rows * cols;
     void *d = stage_to_device(c, src, dtype, count);
     const int grid = grid_for(count, 256, 8192);
@@ -461,9 +476,9 @@ void set_matrix(klnmf_ctx *c, const void *src, int dtype, int64_t rows, int64_t 
         }
     } else {
         if (dtype == KLNMF_DT_F64)
-            hipLaunchKernelGGL((k_place_padded<double>), dim3(grid), dim3(256), 0, c->stream, fast_dst, fast_ld, (const double *)d, rows, cols);
+            hipLaunchKernelGGL((k_place_padded<double>), dim3(grid), dim3(256), 0, c->stream, fast_dst, fast_ld, (const double *)d, rows, cols, mul);
         else
-            hipLaunchKernelGGL((k_place_padded<float>), dim3(grid), dim3(256), 0, c->stream, fast_dst, fast_ld, (const float *)d, rows, cols);
+            hipLaunchKernelGGL((k_place_padded<float>), dim3(grid), dim3(256), 0, c->stream, fast_dst, fast_ld, (const float *)d, rows, cols, mul);
     }
     hipError_t e = hipGetLastError();
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -472,7 +487,7 @@ void set_matrix(klnmf_ctx *c, const void *src, int dtype, int64_t rows, int64_t 
 }
 
 void get_matrix(klnmf_ctx *c, void *dst, int dtype, int64_t rows, int64_t cols, const void *exact_src,
-                const float *fast_src, int64_t fast_ld) {
+                const float *fast_src, int64_t fast_ld, double mul = 1.0) {
     const int64_t count = rows * cols;
     void *d = nullptr;
     const size_t bytes = (size_t)count * dt_size(dtype);
@@ -492,9 +507,9 @@ void get_matrix(klnmf_ctx *c, void *dst, int dtype, int64_t rows, int64_t cols, 
         }
     } else {
         if (dtype == KLNMF_DT_F64)
-            hipLaunchKernelGGL((k_gather_padded<double>), dim3(grid), dim3(256), 0, c->stream, (double *)d, fast_src, fast_ld, rows, cols);
+            hipLaunchKernelGGL((k_gather_padded<double>), dim3(grid), dim3(256), 0, c->stream, (double *)d, fast_src, fast_ld, rows, cols, mul);
         else
-            hipLaunchKernelGGL((k_gather_padded<float>), dim3(grid), dim3(256), 0, c->stream, (float *)d, fast_src, fast_ld, rows, cols);
+            hipLaunchKernelGGL((k_gather_padded<float>), dim3(grid), dim3(256), 0, c->stream, (float *)d, fast_src, fast_ld, rows, cols, mul);
     }
     hipError_t e = hipGetLastError();
     hipError_t e2 = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, c->stream);
@@ -608,12 +623,15 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             if (c->KT > 8) fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels; use KLNMF_PREC_F32/F64");
             c->KP = 32 * c->KT;
             c->ks = (int)((k + 15) / 16);
-            c->n_pad = (n + 31) / 32 * 32;
-            c->f_pad = (f + 31) / 32 * 32;
+            // both passes work on 64-row / 64-column stages: pad to 64 (zero padding is inert)
+            c->n_pad = (n + 63) / 64 * 64;
+            c->f_pad = (f + 63) / 64 * 64;
             c->nrt = (int)(c->n_pad / 32);
             c->nct = (int)(c->f_pad / 32);
-            c->nst = (c->nct + 1) / 2;
-            const int total_stages = (c->nrt + kStageRowTiles - 1) / kStageRowTiles;
+            c->nst = c->nct / 2;
+            c->v_scale = 1.0;
+            c->v_uploaded = false;
+            const int total_stages = c->nrt / kStageRowTiles;
             // bf16 W images are streamed in 64-row stages by global_load_lds in 8 KiB rounds: pad the tail
             c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + 64;
             const size_t vs = c->vsize();
@@ -644,6 +662,21 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         reset_state(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_problem = true;
+    });
+}
+
+int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
+    return guarded([&] {
+        need_problem(c);
+        if (!(vmax >= 0) || !std::isfinite(vmax)) fail(KLNMF_ERR_ARG, "vmax must be finite and >= 0");
+        if (c->v_uploaded) fail(KLNMF_ERR_ARG, "klnmf_set_v_max must precede the first upload");
+        if (c->prec != KLNMF_PREC_BF16 || vmax == 0) {
+            c->v_scale = 1.0;
+            return;
+        }
+        int e = 0;
+        (void)std::frexp(vmax, &e);             // vmax = m * 2^e, m in [0.5, 1)
+        c->v_scale = std::ldexp(1.0, 15 - e);   // c * vmax in [2^14, 2^15)
     });
 }
 
@@ -704,7 +737,7 @@ int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
     return guarded([&] {
         need_problem(c);
         if (!src) fail(KLNMF_ERR_ARG, "null source");
-        set_matrix(c, src, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP);
+        set_matrix(c, src, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP, c->v_scale);
         if (!c->is_exact()) {
             hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n * c->KP, 256, 8192)), dim3(256), 0,
                                c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n, c->KP,
@@ -856,7 +889,7 @@ int klnmf_error(klnmf_ctx *c, double *loss) {
             fast_rowpass(c, ROW_LOSS);
             hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                                (const float2 *)c->loss_part2, (int64_t)c->nrt,
-                               (const DevState *)c->st, c->loss_xchg);
+                               (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg);
             HIPCHK(hipGetLastError());
         }
         double h[2] = {0, 0};
@@ -965,7 +998,7 @@ int klnmf_get_W(klnmf_ctx *c, void *dst, int dtype) {
     return guarded([&] {
         need_problem(c);
         if (!dst) fail(KLNMF_ERR_ARG, "null destination");
-        get_matrix(c, dst, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP);
+        get_matrix(c, dst, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP, 1.0 / c->v_scale);
     });
 }
 

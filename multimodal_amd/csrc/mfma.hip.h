@@ -15,11 +15,19 @@
 //              W_new^T . Q for its columns over a chunk of rows -> one fp32 slab
 //              per row chunk (deterministic two-stage reduction).   nmf.py:349
 //
+// V storage: 16-bit modes keep V as fp16 of c*V, c a power of two chosen from
+// max(V) (klnmf_set_v_max) so that c*max(V) is in [2^14, 2^15): same bytes as
+// bf16 but 3 more significand bits (the loss is evaluated on V as stored, see
+// DESIGN.md "loss with rounded V").  The whole problem then runs in scaled units
+// (W' = cW, eps' = c*eps; H and Q are scale-free) and W / the loss are divided
+// by c on the way out -- exact, c is a power of two.
+//
 // Neither W.H nor Q ever goes to HBM.  V is stored twice, pre-tiled so that each
 // lane's 16 elements of a 32x32 tile are contiguous in exactly the MFMA
 // accumulator order of the pass that reads it (layout A: sample on the lane,
-// layout B: feature on the lane) -> every V load is a fully coalesced
-// 16-byte-per-lane stream straight to registers, no LDS round trip.
+// layout B: feature on the lane) -> every V access is a fully coalesced
+// 16-byte-per-lane stream (row pass: global_load_lds into a wave-private LDS
+// slot one stage ahead; column pass: straight to registers).
 //
 // MFMA: v_mfma_f32_32x32x16_bf16.  Operand maps (guide section 3):
 //   A[row = l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col = l&31], j = 0..7
@@ -80,24 +88,27 @@ __device__ __forceinline__ bf16x8 pack8(const float *q) {
 }
 
 // 16 V elements of this lane for one 32x32 tile, as fp32.
-struct VRegsBf16 { u32x4 a, b; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct VRegsF16 { f16x8 a, b; };
 struct VRegsF32 { f32x4 a, b, c, d; };
 template <typename VT> struct VTraits;
-template <> struct VTraits<__bf16> {
-    typedef VRegsBf16 Regs;
+template <> struct VTraits<_Float16> {
+    typedef VRegsF16 Regs;
     static constexpr int kLaneBytes = 32;
     static __device__ __forceinline__ Regs load(const void *tile, int lane) {
-        const u32x4 *p = (const u32x4 *)((const unsigned char *)tile + lane * 32);
+        const f16x8 *p = (const f16x8 *)((const unsigned char *)tile + lane * 32);
         Regs r; r.a = p[0]; r.b = p[1]; return r;
+    }
+    // tile image in LDS as written by stage_v_tile(): two 1 KiB halves, lane-linear
+    static __device__ __forceinline__ Regs load_lds(const KL_LDS unsigned char *tile, int lane) {
+        Regs r;
+        r.a = *(const KL_LDS f16x8 *)(tile + lane * 16);
+        r.b = *(const KL_LDS f16x8 *)(tile + 1024 + lane * 16);
+        return r;
     }
     static __device__ __forceinline__ void unpack(const Regs &r, float *x) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[2 * i] = __uint_as_float(r.a[i] << 16);
-            x[2 * i + 1] = __uint_as_float(r.a[i] & 0xffff0000u);
-            x[8 + 2 * i] = __uint_as_float(r.b[i] << 16);
-            x[8 + 2 * i + 1] = __uint_as_float(r.b[i] & 0xffff0000u);
-        }
+        for (int i = 0; i < 8; ++i) { x[i] = (float)r.a[i]; x[8 + i] = (float)r.b[i]; }
     }
 };
 template <> struct VTraits<float> {
@@ -106,6 +117,14 @@ template <> struct VTraits<float> {
     static __device__ __forceinline__ Regs load(const void *tile, int lane) {
         const f32x4 *p = (const f32x4 *)((const unsigned char *)tile + lane * 64);
         Regs r; r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; return r;
+    }
+    static __device__ __forceinline__ Regs load_lds(const KL_LDS unsigned char *tile, int lane) {
+        Regs r;
+        r.a = *(const KL_LDS f32x4 *)(tile + lane * 16);
+        r.b = *(const KL_LDS f32x4 *)(tile + 1024 + lane * 16);
+        r.c = *(const KL_LDS f32x4 *)(tile + 2048 + lane * 16);
+        r.d = *(const KL_LDS f32x4 *)(tile + 3072 + lane * 16);
+        return r;
     }
     static __device__ __forceinline__ void unpack(const Regs &r, float *x) {
 #pragma unroll
@@ -124,6 +143,15 @@ __device__ __forceinline__ void glds_copy(const unsigned char *gsrc, KL_LDS unsi
     }
 }
 
+// One wave-private V tile (64 lanes x kLaneBytes) -> LDS, lane-linear 1 KiB pieces.
+template <int LANE_BYTES>
+__device__ __forceinline__ void stage_v_tile(const unsigned char *gtile, KL_LDS unsigned char *ldst, int lane) {
+#pragma unroll
+    for (int p = 0; p < LANE_BYTES / 16; ++p)
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gtile + lane * LANE_BYTES + 16 * p),
+                                         (KL_LDS void *)(ldst + 1024 * p), 16, 0, 0);
+}
+
 struct RowPassArgs {
     const void *VtA;          // [nrt][nct][64 lanes][16] tiles, layout A
     const __bf16 *Ht;         // [nst][KP][kHRow] dictionary stage images
@@ -133,28 +161,42 @@ struct RowPassArgs {
     float *W32_new;
     float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
     const DevState *st;
-    int nrt, nct, nst, ks;    // row tiles, col tiles, stages, MFMA1 k-steps = ceil(k/16)
+    int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
+    float eps;                // c * 1e-8 (scaled units)
 };
 
-template <int KT, int MODE, typename VT>
+// LDS per stage buffer: [dictionary image | V tiles of the 8 waves (16-bit V only)]
+template <typename VT> __host__ __device__ constexpr int row_v_area() {
+    return sizeof(VT) == 2 ? kWavesPerWG * 2 * 64 * 32 : 0;
+}
+template <typename VT> __host__ __device__ constexpr int row_lds_bytes(int kp) {
+    return 2 * (h_stage_lds(kp) + row_v_area<VT>());
+}
+
+// KS = 2*KT - ODD MFMA k-steps cover ceil(k/16) blocks of 16 components.
+template <int KT, int ODD, int MODE, typename VT>
 __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     constexpr int KP = 32 * KT;
-    constexpr int KS = 2 * KT;
+    constexpr int KS = 2 * KT - ODD;
     constexpr int STG = h_stage_lds(KP);
     constexpr int ROUNDS = STG / kGldsRound;
     constexpr int WLD = w_ld(KP);
     typedef VTraits<VT> VTr;
+    constexpr bool VIA_LDS = sizeof(VT) == 2;
+    constexpr int TB = 64 * VTr::kLaneBytes;            // bytes of one V tile
+    constexpr int BUF = STG + row_v_area<VT>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (a.st->stop) return;
     KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int rt = blockIdx.x * kWavesPerWG + wave;
-    const bool active = rt < a.nrt;                       // wave-uniform
+    const int rt_raw = blockIdx.x * kWavesPerWG + wave;
+    const bool active = rt_raw < a.nrt;                   // wave-uniform
+    const int rt = active ? rt_raw : a.nrt - 1;           // idle waves redo the last tile, store nothing
 
     // per-lane LDS offsets (bytes) inside a stage image [KP][kHRow]
-    //  tr read (MFMA1 A operand): rows = components, this lane addresses row q, cols 4p..4p+3 of its 16-lane group's block
+    //  tr read (MFMA1 A operand): rows = components; this lane addresses row q, cols 4p..4p+3 of its 16-lane group's block
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
     const int off_tr = (8 * h + tq) * kHRowB + (16 * half + 4 * tp) * 2;
     //  row read (MFMA2 A operand): row = component r, cols 4h..4h+3
@@ -162,7 +204,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 
     bf16x8 wf[KS];
     if (MODE != ROW_INIT) {
-        const __bf16 *wrow = a.Wb_old + (int64_t)(active ? rt * 32 + r : 0) * WLD + 8 * h;
+        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + 16 * s);
     }
@@ -172,71 +214,84 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
     float s1 = 0.f, s2 = 0.f;
+    const float eps = a.eps;
 
     const unsigned char *ht = (const unsigned char *)a.Ht;
-    const unsigned char *vt = (const unsigned char *)a.VtA +
-                              (int64_t)(active ? rt : 0) * a.nct * 64 * VTr::kLaneBytes;
-    // prologue: stage 0 into buffer 0, V tiles of stage 0
+    const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
+    KL_LDS unsigned char *vl = smem + STG + wave * 2 * TB;      // this wave's V tiles in buffer 0
+
+    // prologue: stage 0
     glds_copy(ht, smem, ROUNDS, tid);
-    typename VTr::Regs vcur[2], vnext[2];
-    vcur[0] = VTr::load(vt, lane);
-    vcur[1] = (a.nct > 1) ? VTr::load(vt + 64 * VTr::kLaneBytes, lane) : vcur[0];
-    vnext[0] = vcur[0]; vnext[1] = vcur[1];
+    typename VTr::Regs vreg[2];
+    if (VIA_LDS) {
+        stage_v_tile<VTr::kLaneBytes>(vt, vl, lane);
+        stage_v_tile<VTr::kLaneBytes>(vt + TB, vl + TB, lane);
+    } else {
+        vreg[0] = VTr::load(vt, lane);
+        vreg[1] = VTr::load(vt + TB, lane);
+    }
     __syncthreads();   // hipcc drains vmcnt before the barrier while a global_load_lds is in flight
 
     for (int st = 0; st < a.nst; ++st) {
-        KL_LDS unsigned char *img = smem + (st & 1) * STG;
+        KL_LDS unsigned char *img = smem + (st & 1) * BUF;
+        const KL_LDS unsigned char *vcur = vl + (st & 1) * BUF;
+        typename VTr::Regs vnext[2];
         if (st + 1 < a.nst) {
-            glds_copy(ht + (int64_t)(st + 1) * h_stage_bytes(KP), smem + ((st + 1) & 1) * STG, ROUNDS, tid);
-            const int ct0 = 2 * (st + 1);
-            vnext[0] = VTr::load(vt + (int64_t)ct0 * 64 * VTr::kLaneBytes, lane);
-            if (ct0 + 1 < a.nct) vnext[1] = VTr::load(vt + (int64_t)(ct0 + 1) * 64 * VTr::kLaneBytes, lane);
+            KL_LDS unsigned char *nb = smem + ((st + 1) & 1) * BUF;
+            glds_copy(ht + (int64_t)(st + 1) * h_stage_bytes(KP), nb, ROUNDS, tid);
+            const unsigned char *vn = vt + (int64_t)(2 * st + 2) * TB;
+            if (VIA_LDS) {
+                stage_v_tile<VTr::kLaneBytes>(vn, nb + STG + wave * 2 * TB, lane);
+                stage_v_tile<VTr::kLaneBytes>(vn + TB, nb + STG + wave * 2 * TB + TB, lane);
+            } else {
+                vnext[0] = VTr::load(vn, lane);
+                vnext[1] = VTr::load(vn + TB, lane);
+            }
         }
-        if (active) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (2 * st + u < a.nct) {
-                    float x[16], q[16];
-                    VTr::unpack(vcur[u], x);
-                    if (MODE == ROW_INIT) {
+        for (int u = 0; u < 2; ++u) {
+            float x[16], q[16];
+            if (VIA_LDS) {
+                const typename VTr::Regs vr = VTr::load_lds(vcur + u * TB, lane);
+                VTr::unpack(vr, x);
+            } else {
+                VTr::unpack(vreg[u], x);
+            }
+            if (MODE == ROW_INIT) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) q[e] = x[e];
-                    } else {
-                        f32x16 d;
+                for (int e = 0; e < 16; ++e) q[e] = x[e];
+            } else {
+                f32x16 d;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) d[e] = 0.f;
+                for (int e = 0; e < 16; ++e) d[e] = 0.f;
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            if (s < a.ks) {
-                                const KL_LDS unsigned char *p = img + off_tr + (16 * s) * kHRowB + (32 * u) * 2;
-                                bf16x8 a1 = tr_pair(p, p + 4 * kHRowB);
-                                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[s], d, 0, 0, 0);
-                            }
-                        }
+                for (int s = 0; s < KS; ++s) {
+                    const KL_LDS unsigned char *p = img + off_tr + (16 * s) * kHRowB + (32 * u) * 2;
+                    const bf16x8 a1 = tr_pair(p, p + 4 * kHRowB);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[s], d, 0, 0, 0);
+                }
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float y = d[e];
-                            const float qq = (x[e] + (float)kEpsRatio) * __builtin_amdgcn_rcpf(y + (float)kEpsRatio);
-                            q[e] = qq;
-                            s2 += y;
-                            s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
-                        }
-                    }
-                    if (MODE != ROW_LOSS) {
-                        const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+                for (int e = 0; e < 16; ++e) {
+                    const float y = d[e];
+                    const float qq = (x[e] + eps) * __builtin_amdgcn_rcpf(y + eps);
+                    q[e] = qq;
+                    s2 += y;
+                    s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
+                }
+            }
+            if (MODE != ROW_LOSS) {
+                const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
 #pragma unroll
-                        for (int m = 0; m < KT; ++m) {
-                            const KL_LDS unsigned char *p = img + off_row + (32 * m) * kHRowB + (32 * u) * 2;
-                            bf16x8 a20 = b64_pair(p, p + 16);
-                            bf16x8 a21 = b64_pair(p + 32, p + 48);
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a20, b0, acc[m], 0, 0, 0);
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a21, b1, acc[m], 0, 0, 0);
-                        }
-                    }
+                for (int m = 0; m < KT; ++m) {
+                    const KL_LDS unsigned char *p = img + off_row + (32 * m) * kHRowB + (32 * u) * 2;
+                    const bf16x8 a20 = b64_pair(p, p + 16);
+                    const bf16x8 a21 = b64_pair(p + 32, p + 48);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a20, b0, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a21, b1, acc[m], 0, 0, 0);
                 }
             }
         }
-        vcur[0] = vnext[0]; vcur[1] = vnext[1];
+        if (!VIA_LDS) { vreg[0] = vnext[0]; vreg[1] = vnext[1]; }
         __syncthreads();
     }
 
@@ -279,20 +334,22 @@ struct ColPassArgs {
     const __bf16 *Wb_new;
     float *Npart;             // [nchunks][KP][f_pad]
     const DevState *st;
-    int nrt, nct, ncb, nchunks, stages_per_chunk, ks;
+    int nrt, nct, ncb, nchunks, stages_per_chunk;   // nrt even; a stage = 2 row tiles
     int64_t f_pad;
+    float eps;
 };
 
-template <int KT, typename VT>
+template <int KT, int ODD, typename VT>
 __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     constexpr int KP = 32 * KT;
-    constexpr int KS = 2 * KT;
+    constexpr int KS = 2 * KT - ODD;
     constexpr int WLD = w_ld(KP);
     constexpr int WLDB = WLD * 2;
     constexpr int IMG = w_stage_lds(KP);           // one image (W_old or W_new) of one stage
     constexpr int ROUNDS = IMG / kGldsRound;
     constexpr int RS = kStageRowTiles;
     typedef VTraits<VT> VTr;
+    constexpr int TB = 64 * VTr::kLaneBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (a.st->stop) return;
     KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
@@ -306,9 +363,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     int lin = blockIdx.x;
     if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int chunk = lin / a.ncb, cb = lin % a.ncb;
-    const int ct = cb * kWavesPerWG + wave;
-    const bool active = ct < a.nct;                  // wave-uniform
-    const int total_stages = (a.nrt + RS - 1) / RS;
+    const int ct_raw = cb * kWavesPerWG + wave;
+    const bool active = ct_raw < a.nct;              // wave-uniform
+    const int ct = active ? ct_raw : a.nct - 1;
+    const int total_stages = a.nrt / RS;
     const int sbeg = chunk * a.stages_per_chunk;
     const int send = min(total_stages, sbeg + a.stages_per_chunk);
 
@@ -320,7 +378,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 
     bf16x8 hf[KS];
     {
-        const __bf16 *hrow = a.HTb + (int64_t)(active ? ct * 32 + r : 0) * KP + 8 * h;
+        const __bf16 *hrow = a.HTb + (int64_t)(ct * 32 + r) * KP + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) hf[s] = *(const bf16x8 *)(hrow + 16 * s);
     }
@@ -329,11 +387,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    const float eps = a.eps;
 
     const unsigned char *wo = (const unsigned char *)a.Wb_old;
     const unsigned char *wn = (const unsigned char *)a.Wb_new;
-    const unsigned char *vt = (const unsigned char *)a.VtB +
-                              (int64_t)(active ? ct : 0) * a.nrt * 64 * VTr::kLaneBytes;
+    const unsigned char *vt = (const unsigned char *)a.VtB + (int64_t)ct * a.nrt * TB;
     typename VTr::Regs vcur[RS], vnext[RS];
     if (sbeg < send) {
         const int64_t goff = (int64_t)sbeg * w_stage_bytes(KP);
@@ -341,8 +399,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
         glds_copy(wn + goff, smem + IMG, ROUNDS, tid);
 #pragma unroll
         for (int u = 0; u < RS; ++u) {
-            const int rtile = min(sbeg * RS + u, a.nrt - 1);
-            vcur[u] = VTr::load(vt + (int64_t)rtile * 64 * VTr::kLaneBytes, lane);
+            vcur[u] = VTr::load(vt + (int64_t)(sbeg * RS + u) * TB, lane);
             vnext[u] = vcur[u];
         }
     }
@@ -358,40 +415,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
             glds_copy(wo + goff, nb, ROUNDS, tid);
             glds_copy(wn + goff, nb + IMG, ROUNDS, tid);
 #pragma unroll
-            for (int u = 0; u < RS; ++u) {
-                const int rtile = min((sg + 1) * RS + u, a.nrt - 1);
-                vnext[u] = VTr::load(vt + (int64_t)rtile * 64 * VTr::kLaneBytes, lane);
-            }
+            for (int u = 0; u < RS; ++u)
+                vnext[u] = VTr::load(vt + (int64_t)((sg + 1) * RS + u) * TB, lane);
         }
-        if (active) {
 #pragma unroll
-            for (int u = 0; u < RS; ++u) {
-                if (sg * RS + u < a.nrt) {
-                    float x[16], q[16];
-                    VTr::unpack(vcur[u], x);
-                    f32x16 d;
+        for (int u = 0; u < RS; ++u) {
+            float x[16], q[16];
+            VTr::unpack(vcur[u], x);
+            f32x16 d;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) d[e] = 0.f;
+            for (int e = 0; e < 16; ++e) d[e] = 0.f;
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        if (s < a.ks) {
-                            bf16x8 a1 = *(const KL_LDS bf16x8 *)(img_old + off_row + (32 * u) * WLDB + (16 * s) * 2);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hf[s], d, 0, 0, 0);
-                        }
-                    }
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a1 = *(const KL_LDS bf16x8 *)(img_old + off_row + (32 * u) * WLDB + (16 * s) * 2);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hf[s], d, 0, 0, 0);
+            }
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        q[e] = (x[e] + (float)kEpsRatio) * __builtin_amdgcn_rcpf(d[e] + (float)kEpsRatio);
-                    const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+            for (int e = 0; e < 16; ++e)
+                q[e] = (x[e] + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
+            const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
 #pragma unroll
-                    for (int m = 0; m < KT; ++m) {
-                        const KL_LDS unsigned char *p = img_new + off_tr + (32 * u) * WLDB + (32 * m) * 2;
-                        bf16x8 a30 = tr_pair(p, p + 8 * WLDB);
-                        bf16x8 a31 = tr_pair(p + 16 * WLDB, p + 24 * WLDB);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, b0, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, b1, acc[m], 0, 0, 0);
-                    }
-                }
+            for (int m = 0; m < KT; ++m) {
+                const KL_LDS unsigned char *p = img_new + off_tr + (32 * u) * WLDB + (32 * m) * 2;
+                const bf16x8 a30 = tr_pair(p, p + 8 * WLDB);
+                const bf16x8 a31 = tr_pair(p + 16 * WLDB, p + 24 * WLDB);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, b0, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, b1, acc[m], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -456,21 +505,23 @@ __global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wl
 
 // Scatter a host-layout fp32/fp64 [n,k] (or [k,f]) array into a padded fp32 master.
 template <typename S>
-__global__ void k_place_padded(float *dst, int64_t dld, const S *src, int64_t rows, int64_t cols) {
+__global__ void k_place_padded(float *dst, int64_t dld, const S *src, int64_t rows, int64_t cols,
+                               double mul) {
     const int64_t total = rows * cols;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / cols, c = e % cols;
-        dst[i * dld + c] = (float)src[e];
+        dst[i * dld + c] = (float)(mul * (double)src[e]);
     }
 }
 template <typename D>
-__global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t rows, int64_t cols) {
+__global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t rows, int64_t cols,
+                                double mul) {
     const int64_t total = rows * cols;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / cols, c = e % cols;
-        dst[e] = (D)src[i * sld + c];
+        dst[e] = (D)(mul * (double)src[i * sld + c]);
     }
 }
 
@@ -492,9 +543,9 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ii = e / cols, jj = e % cols;
-        const double xv = scale * (double)src[ii * ld + jj];
-        const VT xs = (VT)(float)xv;
-        const double xt = (double)(float)xs;
+        const double xv = scale * (double)src[ii * ld + jj];   // scale includes the storage factor c
+        const VT xs = (VT)xv;
+        const double xt = (double)xs;
         const int64_t row = row0 + ii, col = col0 + jj;
         const int64_t rt = row >> 5, ctile = col >> 5;
         const int i = row & 31, c = col & 31;
@@ -515,9 +566,10 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
     }
 }
 
-// loss_local = ln2 * sum(s1) + sum(s2) - sum_x - C   (fixed summation order)
+// loss_local = (ln2 * sum(s1) + sum(s2) - sum_x - C) / c   (fixed summation order)
 __global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, int64_t count,
-                                                          const DevState *st, double *out) {
+                                                          const DevState *st, double inv_c,
+                                                          double *out) {
     if (st->stop) return;
     __shared__ double red[16];
     double a = 0, b = 0;
@@ -529,7 +581,7 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, in
     const double ta = block_sum(a, red);
     const double tb = block_sum(b, red);
     if (threadIdx.x == 0) {
-        out[0] = kLn2 * ta + tb - st->sum_x - st->corr_c;
+        out[0] = (kLn2 * ta + tb - st->sum_x - st->corr_c) * inv_c;
         out[1] = 0;
     }
 }

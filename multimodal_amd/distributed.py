@@ -80,6 +80,15 @@ class ShardedKLNMF(object):
         self.iterations_enqueued = 0
 
     # ---- data ----
+    def set_v_max(self, local_max):
+        """Fix the 16-bit storage factor of V from the GLOBAL maximum (all ranks
+        must use the same factor because they share H); call before uploading."""
+        t = self.torch.tensor([float(local_max)], dtype=self.torch.float64,
+                              device=self.tensor_device)
+        if self.dist is not None and self.world_size > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.ctx.set_v_max(float(t.item()))
+
     def upload_V(self, block, row0=0, col0=0, scale=1.0):
         self.ctx.upload_V(block, row0=row0, col0=col0, scale=scale)
 

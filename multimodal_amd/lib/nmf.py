@@ -22,7 +22,8 @@ the loss is recorded before each update and the breaking iteration's loss is not
 appended (q5, nmf.py:214-220).
 
 Extra (non-reference) constructor arguments: `precision` ('f64' default =
-the reference's float64 arithmetic; 'f32'; 'bf16' = MFMA fast path; 'bf16_v32'),
+the reference's float64 arithmetic; 'f32'; 'bf16' = MFMA fast path with V stored
+as power-of-two-scaled fp16; 'bf16_v32' = same kernels with V stored fp32),
 `device`.  Environment: KLNMF_PRECISION, KLNMF_DEVICE.
 """
 import os
@@ -161,10 +162,7 @@ class KLdivNMF(object):
 
         with self._context() as ctx:
             ctx.set_problem(n_samples, n_features, k, max_iter)
-            col = 0
-            for b, c in zip(blocks, coefs):
-                ctx.upload_V(b, row0=0, col0=col, scale=c)
-                col += b.shape[1]
+            ctx.upload_blocks(blocks, coefs)
             ctx.set_H(H_init)
             ctx.init_W()                       # W0 = X . H_init^T (nmf.py:156)
             if _fit:
@@ -212,7 +210,7 @@ class KLdivNMF(object):
         H = self.components_
         with self._context() as ctx:
             ctx.set_problem(Xd.shape[0], Xd.shape[1], H.shape[0], 1)
-            ctx.upload_V(Xd)
+            ctx.upload_blocks([Xd])
             ctx.set_H(H)
             ctx.set_W(W)
             if eps != 1.e-8:
@@ -237,7 +235,7 @@ class KLdivNMF(object):
         Xd = _dense(X)
         with self._context() as ctx:
             ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
-            ctx.upload_V(Xd)
+            ctx.upload_blocks([Xd])
             ctx.set_H(H)
             ctx.set_W(W)
             return ctx.error()
