@@ -531,8 +531,11 @@ __global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t r
 //   layout A: lane = i + 32*((c>>2)&1), e = 4*(c>>3) + (c&3)      (sample on lane)
 //   layout B: lane = c + 32*((i>>2)&1), e = 4*(i>>3) + (i&3)      (feature on lane)
 // Also accumulates sum(x~) and the storage-rounding correction
-//   C = sum( x~ ln x~ - x ln x - (x~ - x) )   (0 ln 0 = 0)
-// so that loss(x) ~= loss(x~) - C (see DESIGN.md "loss with rounded V").
+//   C = KL(x~ || x) = sum( x~ ln(x~/x) - x~ + x )        (0 ln 0 = 0)
+// With x~ the value as stored:  KL(x||y) = KL(x~||y) - C + sum (x~-x) ln(y/x)
+// exactly; the kernels evaluate KL(x~||y), the host-visible loss is
+// KL(x~||y) - C, and the dropped last term is zero-mean, second order in the
+// rounding error and scale-free (DESIGN.md "loss with rounded V").
 template <typename VT, typename S>
 __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int nct, const S *src,
                                                 int64_t rows, int64_t cols, int64_t ld, int64_t row0,
@@ -554,9 +557,7 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
         VtA[((rt * nct + ctile) * 64 + laneA) * 16 + eA] = xs;
         VtB[((ctile * nrt + rt) * 64 + laneB) * 16 + eB] = xs;
         sx += xt;
-        const double t1 = xt > 0 ? xt * log(xt) : 0.0;
-        const double t0 = xv > 0 ? xv * log(xv) : 0.0;
-        cc += t1 - t0 - (xt - xv);
+        cc += (xt > 0 && xv > 0) ? xt * log(xt / xv) - (xt - xv) : (xv - xt);
     }
     const double tsx = block_sum(sx, red);
     const double tcc = block_sum(cc, red);
