@@ -160,14 +160,8 @@ EventPair begin_event(klnmf_ctx *c, std::vector<EventPair> &v) {
 // ---------------------------------------------------------------- dispatch ---
 template <int KT, int ODD, int MODE, typename VT>
 void launch_rowpass_one(klnmf_ctx *c, const RowPassArgs &a, int grid) {
-    auto kern = k_rowpass<KT, ODD, MODE, VT>;
-    const int lds = row_lds_bytes<VT>(32 * KT);
-    static thread_local int attr_dev = -1;
-    if (attr_dev != c->device) {
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_dev = c->device;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);
+    // LDS is static (two distinct stage buffers, see mfma.hip.h)
+    hipLaunchKernelGGL((k_rowpass<KT, ODD, MODE, VT>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 
 template <int MODE, typename VT>
@@ -189,14 +183,7 @@ void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
 
 template <int KT, int ODD, typename VT>
 void launch_colpass_one(klnmf_ctx *c, const ColPassArgs &a, int grid) {
-    auto kern = k_colpass<KT, ODD, VT>;
-    const int lds = 4 * w_stage_lds(32 * KT);
-    static thread_local int attr_dev = -1;
-    if (attr_dev != c->device) {
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_dev = c->device;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, c->stream, a);
+    hipLaunchKernelGGL((k_colpass<KT, ODD, VT>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 
 template <typename VT>

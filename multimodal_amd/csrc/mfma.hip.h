@@ -184,10 +184,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     typedef VTraits<VT> VTr;
     constexpr bool VIA_LDS = sizeof(VT) == 2;
     constexpr int TB = 64 * VTr::kLaneBytes;            // bytes of one V tile
-    constexpr int BUF = STG + row_v_area<VT>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int BUF = STG + row_v_area<VT>();         // one stage buffer
+    // Two DISTINCT LDS objects, one per stage buffer: hipcc can then prove that the
+    // ds_reads of the current stage do not alias the global_load_lds writes of the
+    // next one and does not drain vmcnt before every read (one dynamic array would).
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[BUF];
     if (a.st->stop) return;
-    KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -218,41 +221,43 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 
     const unsigned char *ht = (const unsigned char *)a.Ht;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
-    KL_LDS unsigned char *vl = smem + STG + wave * 2 * TB;      // this wave's V tiles in buffer 0
-
-    // prologue: stage 0
-    glds_copy(ht, smem, ROUNDS, tid);
+    const int voff = STG + wave * 2 * TB;                 // this wave's V tiles inside a buffer
     typename VTr::Regs vreg[2];
-    if (VIA_LDS) {
-        stage_v_tile<VTr::kLaneBytes>(vt, vl, lane);
-        stage_v_tile<VTr::kLaneBytes>(vt + TB, vl + TB, lane);
-    } else {
-        vreg[0] = VTr::load(vt, lane);
-        vreg[1] = VTr::load(vt + TB, lane);
-    }
-    __syncthreads();   // hipcc drains vmcnt before the barrier while a global_load_lds is in flight
 
-    for (int st = 0; st < a.nst; ++st) {
-        KL_LDS unsigned char *img = smem + (st & 1) * BUF;
-        const KL_LDS unsigned char *vcur = vl + (st & 1) * BUF;
-        typename VTr::Regs vnext[2];
-        if (st + 1 < a.nst) {
-            KL_LDS unsigned char *nb = smem + ((st + 1) & 1) * BUF;
-            glds_copy(ht + (int64_t)(st + 1) * h_stage_bytes(KP), nb, ROUNDS, tid);
-            const unsigned char *vn = vt + (int64_t)(2 * st + 2) * TB;
-            if (VIA_LDS) {
-                stage_v_tile<VTr::kLaneBytes>(vn, nb + STG + wave * 2 * TB, lane);
-                stage_v_tile<VTr::kLaneBytes>(vn + TB, nb + STG + wave * 2 * TB + TB, lane);
-            } else {
-                vnext[0] = VTr::load(vn, lane);
-                vnext[1] = VTr::load(vn + TB, lane);
-            }
+    // issue the copies of stage `st` into `buf`
+    auto stage_in = [&](KL_LDS unsigned char *buf, int st) {
+        glds_copy(ht + (int64_t)st * h_stage_bytes(KP), buf, ROUNDS, tid);
+        const unsigned char *vn = vt + (int64_t)(2 * st) * TB;
+        if (VIA_LDS) {
+            stage_v_tile<VTr::kLaneBytes>(vn, buf + voff, lane);
+            stage_v_tile<VTr::kLaneBytes>(vn + TB, buf + voff + TB, lane);
         }
+    };
+    // the two 32x32 tiles of the stage resident in `img`
+    auto compute = [&](const KL_LDS unsigned char *img) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            // The tile consumes a fixed sequence of LDS operand fragments: KS for
+            // MFMA1 (transposed reads), then 2*KT for MFMA2 (row reads).  Reads run
+            // two MFMAs ahead of their consumer through a 3-slot register ring.
+            const KL_LDS unsigned char *p1 = img + off_tr + (32 * u) * 2;
+            const KL_LDS unsigned char *p2 = img + off_row + (32 * u) * 2;
+            constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
+            constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
+            bf16x8 ring[3];
+            auto fetch = [&](int idx) {                    // idx is a compile-time constant after unrolling
+                if (idx < N1) {
+                    ring[idx % 3] = tr_pair(p1 + (16 * idx) * kHRowB, p1 + (16 * idx + 4) * kHRowB);
+                } else if (idx < N1 + N2) {
+                    const int j = idx - N1, m = j >> 1, hh = j & 1;
+                    ring[idx % 3] = b64_pair(p2 + (32 * m) * kHRowB + 32 * hh, p2 + (32 * m) * kHRowB + 32 * hh + 16);
+                }
+            };
+            fetch(0);
+            fetch(1);
             float x[16], q[16];
             if (VIA_LDS) {
-                const typename VTr::Regs vr = VTr::load_lds(vcur + u * TB, lane);
+                const typename VTr::Regs vr = VTr::load_lds(img + voff + u * TB, lane);
                 VTr::unpack(vr, x);
             } else {
                 VTr::unpack(vreg[u], x);
@@ -266,9 +271,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 for (int e = 0; e < 16; ++e) d[e] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const KL_LDS unsigned char *p = img + off_tr + (16 * s) * kHRowB + (32 * u) * 2;
-                    const bf16x8 a1 = tr_pair(p, p + 4 * kHRowB);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[s], d, 0, 0, 0);
+                    fetch(s + 2);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3], wf[s], d, 0, 0, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -282,17 +286,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
             if (MODE != ROW_LOSS) {
                 const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
 #pragma unroll
-                for (int m = 0; m < KT; ++m) {
-                    const KL_LDS unsigned char *p = img + off_row + (32 * m) * kHRowB + (32 * u) * 2;
-                    const bf16x8 a20 = b64_pair(p, p + 16);
-                    const bf16x8 a21 = b64_pair(p + 32, p + 48);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a20, b0, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a21, b1, acc[m], 0, 0, 0);
+                for (int j = 0; j < N2; ++j) {
+                    fetch(N1 + j + 2);
+                    acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(N1 + j) % 3], (j & 1) ? b1 : b0,
+                                                                          acc[j >> 1], 0, 0, 0);
                 }
             }
         }
-        if (!VIA_LDS) { vreg[0] = vnext[0]; vreg[1] = vnext[1]; }
-        __syncthreads();
+    };
+    // one stage: start the next stage's copies into the other buffer, compute on this one
+    auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int st) {
+        typename VTr::Regs vnext[2];
+        const bool more = st + 1 < a.nst;
+        if (more) {
+            stage_in(nxt, st + 1);
+            if (!VIA_LDS) {
+                const unsigned char *vn = vt + (int64_t)(2 * st + 2) * TB;
+                vnext[0] = VTr::load(vn, lane);
+                vnext[1] = VTr::load(vn + TB, lane);
+            }
+        }
+        compute(cur);
+        if (!VIA_LDS && more) { vreg[0] = vnext[0]; vreg[1] = vnext[1]; }
+        __syncthreads();   // drains the copies (hipcc adds vmcnt(0)) and frees `cur` for reuse
+    };
+
+    KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
+    KL_LDS unsigned char *B = (KL_LDS unsigned char *)bufB;
+    stage_in(A, 0);
+    if (!VIA_LDS) {
+        vreg[0] = VTr::load(vt, lane);
+        vreg[1] = VTr::load(vt + TB, lane);
+    }
+    __syncthreads();
+    for (int st = 0; st < a.nst; st += 2) {
+        stage(A, B, st);
+        if (st + 1 < a.nst) stage(B, A, st + 1);
     }
 
     if (!active) return;
@@ -305,25 +334,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
         // acc[m] reg (g,t): component 32m + 8g + 4h + t of sample row r
         const int64_t row = (int64_t)rt * 32 + r;
 #pragma unroll
-        for (int m = 0; m < KT; ++m)
+        for (int m = 0; m < KT; ++m) {
+            f32x4 w[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                 // the 4 loads of this component tile go out together
+                const int comp = 32 * m + 8 * g + 4 * h;
+                if (MODE == ROW_UPDATE) {
+                    w[g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[g][t] = 1.f;
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int comp = 32 * m + 8 * g + 4 * h;
-                f32x4 w;
-                if (MODE == ROW_UPDATE) {
-                    w = *(const f32x4 *)(a.W32_old + row * KP + comp);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) w[t] *= acc[m][4 * g + t];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) w[t] = acc[m][4 * g + t];
-                }
-                *(f32x4 *)(a.W32_new + row * KP + comp) = w;
+                for (int t = 0; t < 4; ++t) w[g][t] *= acc[m][4 * g + t];
+                *(f32x4 *)(a.W32_new + row * KP + comp) = w[g];
                 bf16x4 wb;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[t];
+                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[g][t];
                 *(bf16x4 *)(a.Wb_new + row * WLD + comp) = wb;
             }
+        }
     }
 }
 
@@ -350,9 +384,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     constexpr int RS = kStageRowTiles;
     typedef VTraits<VT> VTr;
     constexpr int TB = 64 * VTr::kLaneBytes;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // two distinct LDS objects (see k_rowpass): [W_old image | W_new image] per stage
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[2 * IMG];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[2 * IMG];
     if (a.st->stop) return;
-    KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -392,34 +427,34 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     const unsigned char *wo = (const unsigned char *)a.Wb_old;
     const unsigned char *wn = (const unsigned char *)a.Wb_new;
     const unsigned char *vt = (const unsigned char *)a.VtB + (int64_t)ct * a.nrt * TB;
-    typename VTr::Regs vcur[RS], vnext[RS];
-    if (sbeg < send) {
-        const int64_t goff = (int64_t)sbeg * w_stage_bytes(KP);
-        glds_copy(wo + goff, smem, ROUNDS, tid);
-        glds_copy(wn + goff, smem + IMG, ROUNDS, tid);
-#pragma unroll
-        for (int u = 0; u < RS; ++u) {
-            vcur[u] = VTr::load(vt + (int64_t)(sbeg * RS + u) * TB, lane);
-            vnext[u] = vcur[u];
-        }
-    }
-    __syncthreads();
+    typename VTr::Regs vcur[RS];
 
-    for (int sg = sbeg; sg < send; ++sg) {
-        const int b = (sg - sbeg) & 1;
-        KL_LDS unsigned char *img_old = smem + b * 2 * IMG;
-        KL_LDS unsigned char *img_new = img_old + IMG;
-        if (sg + 1 < send) {
-            const int64_t goff = (int64_t)(sg + 1) * w_stage_bytes(KP);
-            KL_LDS unsigned char *nb = smem + (b ^ 1) * 2 * IMG;
-            glds_copy(wo + goff, nb, ROUNDS, tid);
-            glds_copy(wn + goff, nb + IMG, ROUNDS, tid);
-#pragma unroll
-            for (int u = 0; u < RS; ++u)
-                vnext[u] = VTr::load(vt + (int64_t)((sg + 1) * RS + u) * TB, lane);
-        }
+    auto stage_in = [&](KL_LDS unsigned char *buf, int sg) {
+        const int64_t goff = (int64_t)sg * w_stage_bytes(KP);
+        glds_copy(wo + goff, buf, ROUNDS, tid);
+        glds_copy(wn + goff, buf + IMG, ROUNDS, tid);
+    };
+    auto compute = [&](const KL_LDS unsigned char *img_old) {
+        const KL_LDS unsigned char *img_new = img_old + IMG;
 #pragma unroll
         for (int u = 0; u < RS; ++u) {
+            // fragment sequence: KS row reads of W_old (MFMA1'), then 2*KT transposed
+            // reads of W_new (MFMA3); reads run two MFMAs ahead (3-slot ring)
+            const KL_LDS unsigned char *p1 = img_old + off_row + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p3 = img_new + off_tr + (32 * u) * WLDB;
+            constexpr int N3 = 2 * KT;
+            bf16x8 ring[3];
+            auto fetch = [&](int idx) {
+                if (idx < KS) {
+                    ring[idx % 3] = *(const KL_LDS bf16x8 *)(p1 + 32 * idx);
+                } else if (idx < KS + N3) {
+                    const int j = idx - KS, m = j >> 1, hh = j & 1;
+                    ring[idx % 3] = tr_pair(p3 + (16 * hh) * WLDB + (32 * m) * 2,
+                                            p3 + (16 * hh + 8) * WLDB + (32 * m) * 2);
+                }
+            };
+            fetch(0);
+            fetch(1);
             float x[16], q[16];
             VTr::unpack(vcur[u], x);
             f32x16 d;
@@ -427,25 +462,50 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
             for (int e = 0; e < 16; ++e) d[e] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 a1 = *(const KL_LDS bf16x8 *)(img_old + off_row + (32 * u) * WLDB + (16 * s) * 2);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hf[s], d, 0, 0, 0);
+                fetch(s + 2);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3], hf[s], d, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 q[e] = (x[e] + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
             const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
 #pragma unroll
-            for (int m = 0; m < KT; ++m) {
-                const KL_LDS unsigned char *p = img_new + off_tr + (32 * u) * WLDB + (32 * m) * 2;
-                const bf16x8 a30 = tr_pair(p, p + 8 * WLDB);
-                const bf16x8 a31 = tr_pair(p + 16 * WLDB, p + 24 * WLDB);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a30, b0, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a31, b1, acc[m], 0, 0, 0);
+            for (int j = 0; j < N3; ++j) {
+                fetch(KS + j + 2);
+                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(KS + j) % 3], (j & 1) ? b1 : b0,
+                                                                      acc[j >> 1], 0, 0, 0);
             }
         }
+    };
+    auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int sg) {
+        typename VTr::Regs vnext[RS];
+        const bool more = sg + 1 < send;
+        if (more) {
+            stage_in(nxt, sg + 1);
 #pragma unroll
-        for (int u = 0; u < RS; ++u) vcur[u] = vnext[u];
+            for (int u = 0; u < RS; ++u)
+                vnext[u] = VTr::load(vt + (int64_t)((sg + 1) * RS + u) * TB, lane);
+        }
+        compute(cur);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < RS; ++u) vcur[u] = vnext[u];
+        }
         __syncthreads();
+    };
+
+    KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
+    KL_LDS unsigned char *B = (KL_LDS unsigned char *)bufB;
+    if (sbeg < send) {
+        stage_in(A, sbeg);
+#pragma unroll
+        for (int u = 0; u < RS; ++u)
+            vcur[u] = VTr::load(vt + (int64_t)(sbeg * RS + u) * TB, lane);
+    }
+    __syncthreads();
+    for (int sg = sbeg; sg < send; sg += 2) {
+        stage(A, B, sg);
+        if (sg + 1 < send) stage(B, A, sg + 1);
     }
 
     if (!active) return;

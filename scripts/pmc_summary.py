@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc CSVs: per kernel (short name), mean counter value
+per dispatch and mean duration from the kernel trace of the same pass."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V')
+
+
+def short(name):
+    m = re.search(r'k_[a-zA-Z_]+', name)
+    base = m.group(0) if m else name[:40]
+    if 'k_rowpass' in name:
+        mm = re.search(r'k_rowpassILi(\d+)ELi(\d+)ELi(\d+)', name) or re.search(r'k_rowpass<(\d+), (\d+), (\d+)', name)
+        if mm:
+            base += '<KT=%s,odd=%s,mode=%s>' % mm.groups()
+    return base
+
+
+vals = defaultdict(lambda: defaultdict(list))
+durs = defaultdict(list)
+for f in sorted(glob.glob(os.path.join(root, 'p*', '**', '*counter_collection.csv'), recursive=True)):
+    for row in csv.DictReader(open(f)):
+        name = row.get('Kernel_Name', '')
+        if not pat.search(name):
+            continue
+        vals[short(name)][row['Counter_Name']].append(float(row['Counter_Value']))
+for f in sorted(glob.glob(os.path.join(root, 'p*', '**', '*kernel_trace.csv'), recursive=True)):
+    for row in csv.DictReader(open(f)):
+        name = row.get('Kernel_Name', '')
+        if not pat.search(name):
+            continue
+        durs[short(name)].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e6)
+
+for k in sorted(vals):
+    d = durs.get(k, [])
+    print('== %s   dispatches/pass~%d   mean duration under PMC %.3f ms' % (
+        k, len(d) // max(1, len(glob.glob(os.path.join(root, 'p*.log')))), sum(d) / max(1, len(d))))
+    for cname in sorted(vals[k]):
+        v = vals[k][cname]
+        print('   %-32s %18.1f  (n=%d)' % (cname, sum(v) / len(v), len(v)))
