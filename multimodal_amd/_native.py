@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libklnmf.so')
+LIB_PATH = os.environ.get('KLNMF_LIB') or os.path.join(_HERE, 'csrc', 'libklnmf.so')   # KLNMF_LIB: A/B builds
 
 PREC_F64, PREC_F32, PREC_BF16, PREC_BF16_V32 = 0, 1, 2, 3
 PRECISIONS = {'f64': PREC_F64, 'fp64': PREC_F64, 'float64': PREC_F64,

@@ -103,6 +103,7 @@ struct klnmf_ctx {
     __bf16 *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
     __bf16 *Ht = nullptr, *HTb = nullptr;
+    float *hsum = nullptr;
     float *NpartF = nullptr, *numerF = nullptr;
     float2 *loss_part2 = nullptr;
 
@@ -212,6 +213,7 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     a.Wb_new = c->Wb[c->cur ^ 1];
     a.W32_new = c->W32[c->cur ^ 1];
     a.loss_part = c->loss_part2;
+    a.hsum = c->hsum;
     a.st = c->st;
     a.nrt = c->nrt;
     a.nct = c->nct;
@@ -265,7 +267,7 @@ void fast_colpass(klnmf_ctx *c) {
 
 void fast_pack_H(klnmf_ctx *c, int do_update) {
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
-                       (const float *)c->numerF, c->Ht, c->HTb, c->f, c->f_pad, c->KP, do_update,
+                       (const float *)c->numerF, c->Ht, c->HTb, c->hsum, c->f, c->f_pad, c->KP, do_update,
                        do_update ? (const DevState *)c->st : (const DevState *)nullptr);
     HIPCHK(hipGetLastError());
 }
@@ -632,6 +634,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->H32 = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
             c->Ht = (__bf16 *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
             c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
+            c->hsum = (float *)c->dalloc((size_t)c->KP * 4);
             // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
             c->ncb = (c->nct + kWavesPerWG - 1) / kWavesPerWG;

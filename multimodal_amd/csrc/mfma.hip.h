@@ -160,6 +160,7 @@ struct RowPassArgs {
     __bf16 *Wb_new;
     float *W32_new;
     float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
+    const float *hsum;        // [KP] row sums of the bf16-rounded dictionary (for sum(W.H))
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
     float eps;                // c * 1e-8 (scaled units)
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) q[e] = x[e];
             } else {
-                f32x16 d;
+                f32x16 d;   // (starting the accumulator at eps would save an add per element but
+                            //  costs 16 live VGPRs for the splat: spills at KT=7, measured -25 %)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) d[e] = 0.f;
 #pragma unroll
@@ -276,10 +278,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float y = d[e];
-                    const float qq = (x[e] + eps) * __builtin_amdgcn_rcpf(y + eps);
+                    const float qq = (x[e] + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
                     q[e] = qq;
-                    s2 += y;
                     s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
                 }
             }
@@ -326,6 +326,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 
     if (!active) return;
     if (MODE != ROW_INIT) {
+        // sum_j (W.H)_ij = sum_a W_ia * rowsum(H)_a (the reference's sparse branch uses the
+        // same identity, nmf.py:303-304); with the bf16 operands the MFMA sees, so it equals
+        // the accumulated W.H up to fp32 summation order.  Lane (r,h) holds W[r][16s+8h+j].
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], a.hsum[16 * s + 8 * h + j], s2);
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (lane == 0) a.loss_part[rt] = make_float2(s1, s2);
@@ -525,8 +532,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 // (nmf.py:349-350); always (re)writes the bf16 stage images Ht and the transposed
 // copy HTb from the fp32 master.
 __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
-                                                       __bf16 *HTb, int64_t f, int64_t f_pad, int kp,
-                                                       int do_update, const DevState *st) {
+                                                       __bf16 *HTb, float *hsum, int64_t f,
+                                                       int64_t f_pad, int kp, int do_update,
+                                                       const DevState *st) {
     if (st && st->stop) return;
     __shared__ double red[16];
     __shared__ double total;
@@ -547,11 +555,15 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
         for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
         __syncthreads();
     }
+    double hs = 0;
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
         const __bf16 v = (__bf16)row[j];
         Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + (j % kStageCols)] = v;
         HTb[j * kp + a] = v;
+        hs += (double)(float)v;
     }
+    const double ths = block_sum(hs, red);
+    if (threadIdx.x == 0) hsum[a] = (float)ths;
 }
 
 __global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wld) {
