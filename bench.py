@@ -42,6 +42,7 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-rows', type=int, default=8192)
     p.add_argument('--seed', type=int, default=1234)
+    p.add_argument('--tol', type=float, default=0.0, help='stop-rule tolerance (ablation builds pass a negative value)')
     return p.parse_args()
 
 
@@ -165,12 +166,12 @@ def main():
 
     model.begin()
     for _ in range(args.warmup):
-        model.iterate(fit=True, tol=0.0)
+        model.iterate(fit=True, tol=args.tol)
     model.ctx.profile_enable(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.iterate(fit=True, tol=0.0)
+        model.iterate(fit=True, tol=args.tol)
     fence()
     elapsed = time.perf_counter() - t0
     prof = model.ctx.profile_read(reset=True)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -97,7 +98,7 @@ struct klnmf_ctx {
     // bf16 modes
     int KT = 0, KP = 0, ks = 0;
     int64_t n_pad = 0, f_pad = 0, w_rows = 0;
-    int nrt = 0, nct = 0, nst = 0, ncb = 0, nchunks = 0, stages_per_chunk = 0;
+    int nrt = 0, nct = 0, nct_used = 0, nst = 0, ncb = 0, nchunks = 0, stages_per_chunk = 0;
     void *VtA = nullptr, *VtB = nullptr;
     float *W32[2] = {nullptr, nullptr};
     __bf16 *Wb[2] = {nullptr, nullptr};
@@ -161,7 +162,7 @@ EventPair begin_event(klnmf_ctx *c, std::vector<EventPair> &v) {
 // ---------------------------------------------------------------- dispatch ---
 template <int KT, int ODD, int MODE, typename VT>
 void launch_rowpass_one(klnmf_ctx *c, const RowPassArgs &a, int grid) {
-    // LDS is static (two distinct stage buffers, see mfma.hip.h)
+    // LDS is static (distinct stage objects, see mfma.hip.h / mfma2.hip.h)
     hipLaunchKernelGGL((k_rowpass<KT, ODD, MODE, VT>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 
@@ -246,7 +247,7 @@ void fast_colpass(klnmf_ctx *c) {
     a.Npart = c->NpartF;
     a.st = c->st;
     a.nrt = c->nrt;
-    a.nct = c->nct;
+    a.nct = c->nct_used;
     a.ncb = c->ncb;
     a.nchunks = c->nchunks;
     a.stages_per_chunk = c->stages_per_chunk;
@@ -617,6 +618,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->f_pad = (f + 63) / 64 * 64;
             c->nrt = (int)(c->n_pad / 32);
             c->nct = (int)(c->f_pad / 32);
+            c->nct_used = (int)((f + 63) / 64 * 2);      // column tiles that hold data (column pass)
             c->nst = c->nct / 2;
             c->v_scale = 1.0;
             c->v_uploaded = false;
@@ -637,7 +639,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->hsum = (float *)c->dalloc((size_t)c->KP * 4);
             // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
-            c->ncb = (c->nct + kWavesPerWG - 1) / kWavesPerWG;
+            c->ncb = (c->nct_used + kWavesPerWG - 1) / kWavesPerWG;
             int nch = 8;
             while ((int64_t)nch * c->ncb < 2LL * c->cu_count && nch * 2 <= total_stages) nch += 8;
             while (nch > 8 && ((int64_t)nch * c->ncb) % c->cu_count != 0 &&

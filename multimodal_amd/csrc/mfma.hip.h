@@ -227,8 +227,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 
     // issue the copies of stage `st` into `buf`
     auto stage_in = [&](KL_LDS unsigned char *buf, int st) {
+#ifdef KL_ABL_NOHDMA      // ablation build: dictionary images copied for the first stages only (timing only)
+        if (st < 2)
+#endif
         glds_copy(ht + (int64_t)st * h_stage_bytes(KP), buf, ROUNDS, tid);
         const unsigned char *vn = vt + (int64_t)(2 * st) * TB;
+#ifdef KL_ABL_NOVDMA
+        if (st < 2)
+#endif
         if (VIA_LDS) {
             stage_v_tile<VTr::kLaneBytes>(vn, buf + voff, lane);
             stage_v_tile<VTr::kLaneBytes>(vn + TB, buf + voff + TB, lane);
@@ -247,6 +253,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
             constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
             bf16x8 ring[3];
             auto fetch = [&](int idx) {                    // idx is a compile-time constant after unrolling
+#ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
+                if (idx < N1 + N2) { ring[idx % 3] = wf[idx % KS]; asm volatile("" : "+v"(ring[idx % 3])); }
+                return;
+#endif
                 if (idx < N1) {
                     ring[idx % 3] = tr_pair(p1 + (16 * idx) * kHRowB, p1 + (16 * idx + 4) * kHRowB);
                 } else if (idx < N1 + N2) {
@@ -278,9 +288,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
+#ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
+                    q[e] = x[e] + d[e];
+#else
                     const float qq = (x[e] + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
                     q[e] = qq;
                     s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
+#endif
                 }
             }
             if (MODE != ROW_LOSS) {
