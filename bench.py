@@ -81,6 +81,24 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192):
     torch.cuda.synchronize()
 
 
+def measured_traffic(args, n_local):
+    """HBM bytes per row-pass launch from the committed PMC run of this exact workload
+    (profiles/r01_pmc_traffic.json, produced by scripts/pmc_profile.sh); None if the
+    workload differs -- the counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    w = d.get('workload', {})
+    if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) != (n_local, args.f, args.k, args.precision):
+        return None
+    for name, v in d.get('kernels', {}).items():
+        if 'k_rowpass' in name:
+            return v['hbm_bytes_per_launch']
+    return None
+
+
 def cpu_baseline(args):
     """The oracle (numpy restatement of the reference loop, fp64, same redundant
     work) timed on this host's cores on a bounded row sample of the workload."""
@@ -221,7 +239,7 @@ def main():
                 'peak': PEAK_BF16_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': (flops_row / (row_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if row_ms > 0 else None,
-                'traffic': None,
+                'traffic': measured_traffic(args, n_local),
                 'avg_launch_ms': row_ms,
                 'launches': prof['rowpass_launches'],
                 'algorithmic_flops_per_launch': flops_row,

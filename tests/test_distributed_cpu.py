@@ -1,0 +1,163 @@
+"""Row-sharded driver (multimodal_amd/distributed.py) over gloo, world_size 2,
+on CPU.  The per-rank arithmetic is an oracle-backed double with the same
+interface as `_native.Context` (the HIP kernels need a GPU); what is tested is
+the N>1 path itself: row partition, the sequencing of the klnmf_iter_* pieces
+around the two all-reduces (loss, k x f numerator), the common stop decision,
+and that the sharded result equals the single-process oracle fit."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import klnmf_oracle as orc
+from multimodal_amd.distributed import ShardedKLNMF, row_partition
+
+
+class OracleContext(object):
+    """CPU double of _native.Context for one row shard (fp64)."""
+
+    def __init__(self):
+        self.loss = self.numer = None
+
+    def set_problem(self, n, f, k, cap):
+        self.n, self.f, self.k = n, f, k
+        self.V = np.zeros((n, f))
+        self.W = np.zeros((n, k))
+        self.H = np.zeros((k, f))
+
+    def exchange_buffers(self):
+        return None, None, self.k * self.f, True
+
+    def bind_exchange(self, loss_ptr, numer_ptr):
+        self.loss = np.ctypeslib.as_array((ctypes.c_double * 2).from_address(loss_ptr))
+        self.numer = np.ctypeslib.as_array(
+            (ctypes.c_double * (self.k * self.f)).from_address(numer_ptr)).reshape(self.k, self.f)
+
+    def set_v_max(self, vmax):
+        self.vmax = vmax
+
+    def upload_V(self, block, row0=0, col0=0, scale=1.0):
+        b = np.asarray(block, dtype=np.float64)
+        self.V[row0:row0 + b.shape[0], col0:col0 + b.shape[1]] = scale * b
+
+    def set_H(self, H):
+        self.H = np.array(H, dtype=np.float64)
+
+    def init_W(self):
+        self.W = self.V.dot(self.H.T)
+
+    # ---- the loop in pieces (device semantics: no-ops once stopped) ----
+    def loop_begin(self):
+        self.prev, self.stop, self.errors = np.inf, False, []
+
+    def iter_rowpass(self, fit):
+        if self.stop:
+            return
+        self.loss[0] = orc.kl_error(self.V, self.W, self.H)
+        self.loss[1] = 0.0
+        self.Q = orc.ratio_q(self.V, self.W, self.H)
+        self.W_new = orc.updated_w(self.V, self.W, self.H, Q=self.Q)
+
+    def iter_decide(self, tol_abs):
+        if self.stop:
+            return
+        err = float(self.loss[0])
+        if self.prev - err < tol_abs:
+            self.stop = True
+            return
+        self.prev = err
+        self.errors.append(err)
+        self.commit = True
+
+    def iter_colpass(self):
+        if self.stop:
+            return
+        self.numer[...] = self.W_new.T.dot(self.Q)
+
+    def iter_update_H(self):
+        if self.stop:
+            return
+        self.H = orc.normalize_sum(self.H * self.numer, axis=1)
+
+    def iter_advance(self):
+        if not self.stop:
+            self.W = self.W_new
+
+    def loop_end(self, cap):
+        return list(self.errors), len(self.errors), self.stop
+
+    def get_W(self, dtype=np.float64):
+        return self.W.astype(dtype)
+
+    def get_H(self, dtype=np.float64):
+        return self.H.astype(dtype)
+
+    def close(self):
+        pass
+
+
+def test_row_partition():
+    assert row_partition(100, 1) == [(0, 100)]
+    parts = row_partition(1000000, 8)
+    assert parts[0][0] == 0 and parts[-1][1] == 1000000
+    assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    sizes = [b - a for a, b in parts]
+    assert max(sizes) - min(sizes) <= 32 and all(s % 32 == 0 for s in sizes[:-1])
+    assert row_partition(37, 2) == [(0, 32), (32, 37)]
+    assert sum(b - a for a, b in row_partition(5, 4)) == 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, f, k, iters, tol, fit, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        X = orc.synthetic_V(77, n, f, k)
+        H0 = orc.synthetic_H0(77, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=iters, backend=OracleContext())
+        m.set_v_max(X[r0:r1].max())
+        m.upload_V(X[r0:r1])
+        m.set_H(H0)
+        m.init_W()
+        errors, n_done, stopped = m.run(iters, fit=fit, tol=tol)
+        W = m.gather_W()
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), W=W, H=m.get_H(),
+                 errors=np.array(errors), n_done=n_done, stopped=stopped)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('iters,tol,fit', [(8, 0.0, True), (200, 1e-4, True), (6, 0.0, False)])
+def test_sharded_equals_single_process(tmp_path, iters, tol, fit):
+    import torch.multiprocessing as mp
+    n, f, k, world = 75, 40, 6, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, f, k, iters, tol, fit, str(tmp_path)), nprocs=world, join=True)
+    X = orc.synthetic_V(77, n, f, k)
+    H0 = orc.synthetic_H0(77, f, k)
+    if fit:
+        Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=tol, warn=False)
+    else:
+        Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=tol, fit=False,
+                                       components=H0, warn=False)
+    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    for r in res:
+        assert int(r['n_done']) == len(eo)                       # same stop iteration on every rank
+        np.testing.assert_allclose(r['errors'], eo, rtol=1e-11)
+        np.testing.assert_allclose(r['W'], Wo, rtol=1e-9)
+        np.testing.assert_allclose(r['H'], Ho, rtol=1e-9)
+    np.testing.assert_array_equal(res[0]['H'], res[1]['H'])      # replicas stay bit-identical
+    if tol > 0:
+        assert bool(res[0]['stopped']) and len(eo) < iters
