@@ -16,6 +16,7 @@
 #include "common.hip.h"
 #include "exact.hip.h"
 #include "mfma.hip.h"
+#include "mfma4.hip.h"
 #include "probe.hip.h"
 
 using namespace klnmf;
@@ -103,8 +104,10 @@ struct klnmf_ctx {
     float *W32[2] = {nullptr, nullptr};
     __bf16 *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
-    __bf16 *Ht = nullptr, *HTb = nullptr;
+    __bf16 *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
+    int row_gen = 4;
     float *hsum = nullptr;
+    unsigned long long *stamps = nullptr;   // diagnostic builds only
     float *NpartF = nullptr, *numerF = nullptr;
     float2 *loss_part2 = nullptr;
 
@@ -183,6 +186,23 @@ void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
     HIPCHK(hipGetLastError());
 }
 
+template <int MODE>
+void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
+    const int odd = 2 * c->KT - c->ks;
+#define KL_ROW4_CASE(KTV)                                                                                       \
+    case KTV:                                                                                                   \
+        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
+        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);       \
+        break;
+    switch (c->KT) {
+        KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
+        KL_ROW4_CASE(5) KL_ROW4_CASE(6) KL_ROW4_CASE(7)
+        default: fail(KLNMF_ERR_UNSUPP, "ping-pong row pass: k > 224 runs on the generation-1 kernel");
+    }
+#undef KL_ROW4_CASE
+    HIPCHK(hipGetLastError());
+}
+
 template <int KT, int ODD, typename VT>
 void launch_colpass_one(klnmf_ctx *c, const ColPassArgs &a, int grid) {
     hipLaunchKernelGGL((k_colpass<KT, ODD, VT>), dim3(grid), dim3(kThreads), 0, c->stream, a);
@@ -215,6 +235,7 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     a.W32_new = c->W32[c->cur ^ 1];
     a.loss_part = c->loss_part2;
     a.hsum = c->hsum;
+    a.stamps = c->stamps;
     a.st = c->st;
     a.nrt = c->nrt;
     a.nct = c->nct;
@@ -224,6 +245,16 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
     const bool v16 = c->prec == KLNMF_PREC_BF16;
+    if (v16 && c->row_gen == 4 && c->KT <= 7) {        // KT = 8 would spill (scratch traffic breaks the counted vmcnt waits)                       // ping-pong schedule (mfma4.hip.h), fp16 V only
+        RowPass4Args a4{a, c->Ht4};
+        switch (mode) {
+            case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid); break;
+            case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid); break;
+            default: launch_rowpass4_kt<ROW_LOSS>(c, a4, grid); break;
+        }
+        if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+        return;
+    }
     switch (mode) {
         case ROW_UPDATE:
             v16 ? launch_rowpass_kt<ROW_UPDATE, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_UPDATE, float>(c, a, grid);
@@ -268,7 +299,7 @@ void fast_colpass(klnmf_ctx *c) {
 
 void fast_pack_H(klnmf_ctx *c, int do_update) {
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
-                       (const float *)c->numerF, c->Ht, c->HTb, c->hsum, c->f, c->f_pad, c->KP, do_update,
+                       (const float *)c->numerF, c->Ht, c->Ht4, c->HTb, c->hsum, c->f, c->f_pad, c->KP, do_update,
                        do_update ? (const DevState *)c->st : (const DevState *)nullptr);
     HIPCHK(hipGetLastError());
 }
@@ -568,6 +599,23 @@ int klnmf_destroy(klnmf_ctx *c) {
         if (!c) return;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+#ifdef KL_STAMPS
+        if (c->stamps && c->nrt > 0) {
+            std::vector<unsigned long long> hs((size_t)c->nrt * 8);
+            (void)hipMemcpy(hs.data(), c->stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+            double sum[8] = {0};
+            for (int i = 0; i < c->nrt; ++i) for (int j = 0; j < 8; ++j) sum[j] += (double)hs[(size_t)i * 8 + j];
+            const double tiles = (double)c->nct;
+            if (c->row_gen == 4 && c->prec == KLNMF_PREC_BF16 && c->KT <= 7)
+                std::fprintf(stderr, "[stamps4] per tile per wave (cycles): M segment %.0f | E segment %.0f | copy wait %.0f | barrier after M %.0f | barrier after E %.0f || kernel %.0f cycles, %d tiles\n",
+                             sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles,
+                             sum[4] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
+            else
+            std::fprintf(stderr, "[stamps] per tile per wave (cycles): prime+V %.0f | MFMA1 %.0f | epilogue %.0f | MFMA2 %.0f || per stage: barrier wait %.0f, compute %.0f || kernel %.0f cycles, %d stages\n",
+                         sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles,
+                         sum[4] / c->nrt / c->nst, sum[5] / c->nrt / c->nst, sum[6] / c->nrt, c->nst);
+        }
+#endif
         c->free_all();
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
@@ -615,7 +663,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->ks = (int)((k + 15) / 16);
             // both passes work on 64-row / 64-column stages: pad to 64 (zero padding is inert)
             c->n_pad = (n + 63) / 64 * 64;
-            c->f_pad = (f + 63) / 64 * 64;
+            c->f_pad = (f + 127) / 128 * 128;            // the ping-pong row pass walks 4 column tiles per loop body
             c->nrt = (int)(c->n_pad / 32);
             c->nct = (int)(c->f_pad / 32);
             c->nct_used = (int)((f + 63) / 64 * 2);      // column tiles that hold data (column pass)
@@ -635,8 +683,13 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             }
             c->H32 = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
             c->Ht = (__bf16 *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
+            c->Ht4 = (__bf16 *)c->dalloc((size_t)c->nct * h4_tile_bytes(c->KP) + kObj4);
             c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
+            if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
             c->hsum = (float *)c->dalloc((size_t)c->KP * 4);
+#ifdef KL_STAMPS
+            c->stamps = (unsigned long long *)c->dalloc((size_t)c->nrt * 8 * 8);
+#endif
             // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
             c->ncb = (c->nct_used + kWavesPerWG - 1) / kWavesPerWG;

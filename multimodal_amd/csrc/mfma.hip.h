@@ -51,8 +51,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int kWavesPerWG = 8;
 constexpr int kThreads = 64 * kWavesPerWG;       // 512
 constexpr int kStageCols = 64;                   // feature columns per LDS stage (row pass)
-constexpr int kHRow = kStageCols + 4;            // padded image row, elements (136 B)
-constexpr int kHRowB = kHRow * 2;
+constexpr int kHRow = kStageCols + 8;            // padded image row: 144 B = 36 dwords (4 x odd:
+constexpr int kHRowB = kHRow * 2;                //   16 rows read with ds_read_b128 hit 16 distinct bank quads)
+// Dictionary stage image [component][64 columns]: inside every group of 16 columns the
+// four 4-column blocks are stored in the order 0,2,1,3, so that the MFMA-2 A fragment of
+// lane half h (logical columns 4h..4h+3 and 8+4h..8+4h+3 of the group) is 16 contiguous
+// bytes -> one ds_read_b128.  (Two 8-byte reads get fused into ds_read2_b64, which costs
+// 2-4x the LDS cycles per byte and saturated the LDS array: profiles/r01_*.)  The MFMA-1
+// transposed reads address 4-column blocks individually, so they just follow the permutation.
+__host__ __device__ constexpr int h_col_perm(int c) {           // logical column (0..63) -> physical
+    return (c & ~15) | ((((c >> 2) & 1) << 1 | ((c >> 3) & 1)) << 2) | (c & 3);
+}
 constexpr int kStageRowTiles = 2;                // 32-row tiles per LDS stage (column pass)
 constexpr int kGldsRound = kThreads * 16;        // bytes one global_load_lds round moves (8 KiB)
 
@@ -65,6 +74,28 @@ __host__ __device__ constexpr int w_stage_bytes(int kp) { return kStageRowTiles 
 __host__ __device__ constexpr int w_stage_lds(int kp) { return round_up(w_stage_bytes(kp), kGldsRound); }
 
 enum RowMode { ROW_UPDATE = 0, ROW_INIT = 1, ROW_LOSS = 2 };
+
+// The two waves that share a SIMD (wave w and w+4 of the 8-wave workgroup) run the same
+// barrier-synchronised program; with equal priority they alternate on the matrix pipe, so each
+// MFMA phase takes twice its pipe time and the VALU-heavy epilogues collide as well (in-kernel
+// stamps: MFMA-1 827 cycles for 416 of pipe work).  A static priority for waves 4-7 lets their
+// phase run first and the partner fill the gaps: the pair drifts half a phase apart.
+// s_setprio ignores EXEC, so the condition must be provably wave-uniform (readfirstlane).
+// depth of the LDS operand-fragment ring of the row pass (reads run KL_RING-1 MFMAs ahead)
+#ifndef KL_RING
+#define KL_RING 3
+#endif
+#ifndef KL_SKEW
+#define KL_SKEW 0
+#endif
+#ifndef KL_PRIO
+#define KL_PRIO 1
+#endif
+#define KL_WAVE_PRIORITY()                                                                  \
+    do {                                                                                    \
+        if (KL_PRIO > 0 && __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256)         \
+            __builtin_amdgcn_s_setprio(KL_PRIO);                                            \
+    } while (0)
 
 // ---- small device helpers ---------------------------------------------------
 __device__ __forceinline__ bf16x8 tr_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
@@ -152,6 +183,17 @@ __device__ __forceinline__ void stage_v_tile(const unsigned char *gtile, KL_LDS 
                                          (KL_LDS void *)(ldst + 1024 * p), 16, 0, 0);
 }
 
+#ifdef KL_STAMPS
+#define KL_STAMP(var)                                                                   \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define KL_STAMP(var) do { } while (0)
+#endif
+
 struct RowPassArgs {
     const void *VtA;          // [nrt][nct][64 lanes][16] tiles, layout A
     const __bf16 *Ht;         // [nst][KP][kHRow] dictionary stage images
@@ -161,6 +203,7 @@ struct RowPassArgs {
     float *W32_new;
     float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
     const float *hsum;        // [KP] row sums of the bf16-rounded dictionary (for sum(W.H))
+    unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
     float eps;                // c * 1e-8 (scaled units)
@@ -192,6 +235,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char bufA[BUF];
     __shared__ __attribute__((aligned(16))) unsigned char bufB[BUF];
     if (a.st->stop) return;
+    KL_WAVE_PRIORITY();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -202,9 +246,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     // per-lane LDS offsets (bytes) inside a stage image [KP][kHRow]
     //  tr read (MFMA1 A operand): rows = components; this lane addresses row q, cols 4p..4p+3 of its 16-lane group's block
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
-    const int off_tr = (8 * h + tq) * kHRowB + (16 * half + 4 * tp) * 2;
-    //  row read (MFMA2 A operand): row = component r, cols 4h..4h+3
-    const int off_row = r * kHRowB + (4 * h) * 2;
+    const int off_tr = (8 * h + tq) * kHRowB + h_col_perm(16 * half + 4 * tp) * 2;
+    //  row read (MFMA2 A operand): row = component r, 16 contiguous bytes of its 16-column group
+    const int off_row = r * kHRowB + 16 * h;
 
     bf16x8 wf[KS];
     if (MODE != ROW_INIT) {
@@ -224,6 +268,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
     const int voff = STG + wave * 2 * TB;                 // this wave's V tiles inside a buffer
     typename VTr::Regs vreg[2];
+#ifdef KL_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk0; KL_STAMP(tk0);
+#endif
 
     // issue the copies of stage `st` into `buf`
     auto stage_in = [&](KL_LDS unsigned char *buf, int st) {
@@ -251,21 +299,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
             const KL_LDS unsigned char *p2 = img + off_row + (32 * u) * 2;
             constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
             constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
-            bf16x8 ring[3];
+            bf16x8 ring[KL_RING];
             auto fetch = [&](int idx) {                    // idx is a compile-time constant after unrolling
 #ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
-                if (idx < N1 + N2) { ring[idx % 3] = wf[idx % KS]; asm volatile("" : "+v"(ring[idx % 3])); }
+                if (idx < N1 + N2) { ring[idx % KL_RING] = wf[idx % KS]; asm volatile("" : "+v"(ring[idx % KL_RING])); }
                 return;
 #endif
                 if (idx < N1) {
-                    ring[idx % 3] = tr_pair(p1 + (16 * idx) * kHRowB, p1 + (16 * idx + 4) * kHRowB);
+                    ring[idx % KL_RING] = tr_pair(p1 + (16 * idx) * kHRowB, p1 + (16 * idx + 4) * kHRowB);
                 } else if (idx < N1 + N2) {
                     const int j = idx - N1, m = j >> 1, hh = j & 1;
-                    ring[idx % 3] = b64_pair(p2 + (32 * m) * kHRowB + 32 * hh, p2 + (32 * m) * kHRowB + 32 * hh + 16);
+                    ring[idx % KL_RING] = *(const KL_LDS bf16x8 *)(p2 + (32 * m) * kHRowB + 32 * hh);
                 }
             };
-            fetch(0);
-            fetch(1);
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+            KL_STAMP(t0);
+#pragma unroll
+            for (int i = 0; i < KL_RING - 1; ++i) fetch(i);
             float x[16], q[16];
             if (VIA_LDS) {
                 const typename VTr::Regs vr = VTr::load_lds(img + voff + u * TB, lane);
@@ -273,6 +323,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
             } else {
                 VTr::unpack(vreg[u], x);
             }
+            KL_STAMP(t1);
             if (MODE == ROW_INIT) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) q[e] = x[e];
@@ -283,9 +334,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 for (int e = 0; e < 16; ++e) d[e] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    fetch(s + 2);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3], wf[s], d, 0, 0, 0);
+                    fetch(s + KL_RING - 1);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % KL_RING], wf[s], d, 0, 0, 0);
                 }
+                KL_STAMP(t2);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
 #ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
@@ -299,13 +351,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
             }
             if (MODE != ROW_LOSS) {
                 const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+                KL_STAMP(t3);
 #pragma unroll
                 for (int j = 0; j < N2; ++j) {
-                    fetch(N1 + j + 2);
-                    acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(N1 + j) % 3], (j & 1) ? b1 : b0,
+                    fetch(N1 + j + KL_RING - 1);
+                    acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(N1 + j) % KL_RING], (j & 1) ? b1 : b0,
                                                                           acc[j >> 1], 0, 0, 0);
                 }
+                KL_STAMP(t4);
             }
+#ifdef KL_STAMPS
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+#endif
         }
     };
     // one stage: start the next stage's copies into the other buffer, compute on this one
@@ -320,9 +377,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 vnext[1] = VTr::load(vn + TB, lane);
             }
         }
+        unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
+        KL_STAMP(tb0);
+#if KL_SKEW > 0
+        // phase skew: waves 4-7 start each stage KL_SKEW*64 cycles late so that their MFMA
+        // blocks fall into the partner wave's epilogue instead of colliding with its MFMAs
+        if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_sleep(KL_SKEW);
+#endif
         compute(cur);
         if (!VIA_LDS && more) { vreg[0] = vnext[0]; vreg[1] = vnext[1]; }
+        KL_STAMP(tb1);
         __syncthreads();   // drains the copies (hipcc adds vmcnt(0)) and frees `cur` for reuse
+        KL_STAMP(tb2);
+#ifdef KL_STAMPS
+        ph[4] += tb2 - tb1; ph[5] += tb1 - tb0;
+#endif
     };
 
     KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
@@ -338,6 +407,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
         if (st + 1 < a.nst) stage(B, A, st + 1);
     }
 
+#ifdef KL_STAMPS
+    {
+        unsigned long long tk1; KL_STAMP(tk1);
+        ph[6] = tk1 - tk0;
+        if (a.stamps && lane == 0 && active)
+            for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
+    }
+#endif
     if (!active) return;
     if (MODE != ROW_INIT) {
         // sum_j (W.H)_ij = sum_a W_ia * rowsum(H)_a (the reference's sparse branch uses the
@@ -409,6 +486,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char bufA[2 * IMG];
     __shared__ __attribute__((aligned(16))) unsigned char bufB[2 * IMG];
     if (a.st->stop) return;
+    KL_WAVE_PRIORITY();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -546,7 +624,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 // (nmf.py:349-350); always (re)writes the bf16 stage images Ht and the transposed
 // copy HTb from the fp32 master.
 __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
-                                                       __bf16 *HTb, float *hsum, int64_t f,
+                                                       __bf16 *Ht4, __bf16 *HTb, float *hsum, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
                                                        const DevState *st) {
     if (st && st->stop) return;
@@ -572,7 +650,8 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     double hs = 0;
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
         const __bf16 v = (__bf16)row[j];
-        Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + (j % kStageCols)] = v;
+        Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + h_col_perm((int)(j % kStageCols))] = v;
+        if (Ht4) Ht4[(j / 32) * (int64_t)kp * 40 + (int64_t)a * 40 + h_col_perm((int)(j % 32))] = v;   // mfma4.hip.h tile images
         HTb[j * kp + a] = v;
         hs += (double)(float)v;
     }

@@ -1,0 +1,344 @@
+// Row pass, ping-pong schedule (generation 4).
+//
+// Measured on generation 1 (mfma.hip.h; profiles/r01_*, in-kernel stamps): per
+// 32x32 tile a wave spends 827 cycles in MFMA-1 (416 of matrix-pipe work), 974 in
+// the ratio/log epilogue and 762 in MFMA-2 (448) -- per SIMD the time is the SUM of
+// the MFMA time and the VALU time of its two waves: nothing overlaps, because both
+// partners run the same barrier-synchronised phases at the same time.
+//
+// Here the two wave groups of the workgroup (waves 0-3 = X, waves 4-7 = Y; wave w
+// and w+4 share a SIMD) alternate ROLES per barrier interval, the scheme the CDNA
+// guide describes for tuned 8-wave kernels:
+//
+//   interval   0      1      2      3      4
+//   X         M(0)   E(0)   M(1)   E(1)   M(2)  ...      M(t) = MFMA-2(t-1) + MFMA-1(t)   (27 MFMAs)
+//   Y          -     M(0)   E(0)   M(1)   E(1)  ...      E(t) = ratio / log epilogue of tile t (VALU)
+//
+// Every interval ends with one s_barrier for all 8 waves, so on each SIMD exactly
+// one wave owns the matrix pipe while its partner owns the VALU.  Both groups run
+// the same code; Y is shifted by one interval (one extra barrier up front).
+//
+// Stages are single 32-column tiles: dictionary image [KP][32+8] (80-byte rows) and
+// the 8 waves' V tiles, in 4 rotating pairs of DISTINCT LDS objects (static indices:
+// the loop body covers 4 tiles), filled by global_load_lds two tiles ahead; each
+// wave waits for its own copies with a counted vmcnt (the younger stage stays in
+// flight) before the barrier that precedes the first read.
+#pragma once
+#include <type_traits>
+
+#include "mfma.hip.h"
+
+namespace klnmf {
+
+constexpr int kRow4 = 32 + 8;                    // image row, elements (80 B = 20 dwords = 4 x odd)
+constexpr int kRow4B = kRow4 * 2;
+constexpr int kObj4 = 3 * kGldsRound;            // LDS bytes of one dictionary image object (3 copy rounds)
+constexpr int kVObj4 = kWavesPerWG * 2048;       // the 8 waves' fp16 V tiles of one stage
+constexpr int kDma4 = 5;                         // VMEM instructions per wave per stage copy (3 image rounds + 2 V pieces)
+__host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
+// logical column (0..31) of a tile -> physical position (16-column groups stored 0,2,1,3 as in mfma.hip.h)
+__host__ __device__ constexpr int h4_col_perm(int c) { return h_col_perm(c); }
+
+struct RowPass4Args {
+    RowPassArgs base;
+    const __bf16 *Ht4;        // [nct][KP][kRow4] per-tile dictionary images
+};
+
+// prefetch distance of the operand-fragment stream, in fragments (ring = KL_PF + 1 registers sets)
+#ifndef KL_PF
+#define KL_PF 3
+#endif
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// LDS reads the compiler does not see as memory accesses: its wait-count pass would otherwise
+// drain ALL outstanding global_load_lds copies (vmcnt(0)) before any read of an object a copy
+// was ever issued into.  Completion is awaited with explicit counted lgkmcnt waits that carry
+// the destination as an in/out operand, so no use can be scheduled above its wait.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(bf16x8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(f16x8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void lds_read_tr_pair(bf16x8 &dst, unsigned addr) {
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF1));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    dst = __builtin_bit_cast(bf16x8, v);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8 &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+template <int KT, int ODD, int MODE>
+__global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
+    const RowPassArgs &a = aa.base;
+    constexpr int KP = 32 * KT;
+    constexpr int KS = 2 * KT - ODD;
+    constexpr int WLD = w_ld(KP);
+    constexpr int TB = 2048;
+    constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
+    constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
+    constexpr int NF = N1 + N2;              // fragments (= MFMAs) per M segment
+    constexpr int D = KL_PF < NF - 1 ? KL_PF : NF - 1;      // reads run D fragments ahead of their MFMA
+    constexpr int R = D + 1;
+    constexpr int DP = D < N2 ? D : N2;      // fragments of the lead that are MFMA-2 reads (issued one segment early)
+    static_assert(KP * kRow4B <= kObj4, "dictionary tile image exceeds its LDS object");
+    __shared__ __attribute__((aligned(16))) unsigned char h0[kObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char h1[kObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char h2[kObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char h3[kObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char v0[kVObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char v1[kVObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char v2[kVObj4];
+    __shared__ __attribute__((aligned(16))) unsigned char v3[kVObj4];
+    if (a.st->stop) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bool grpY = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;     // wave-uniform (SGPR)
+    const int rt_raw = blockIdx.x * kWavesPerWG + wave;
+    const bool active = rt_raw < a.nrt;
+    const int rt = active ? rt_raw : a.nrt - 1;
+
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    const unsigned off_tr = (8 * h + tq) * kRow4B + h4_col_perm(16 * half + 4 * tp) * 2;   // MFMA-1 transposed reads
+    const unsigned off_row = r * kRow4B + 16 * h;                                          // MFMA-2 row reads (b128)
+    const unsigned voff = wave * TB + lane * 16;
+
+    bf16x8 wf[KS > 0 ? KS : 1];
+    if (MODE != ROW_INIT) {
+        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + 16 * s);
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    const float eps = a.eps;
+
+    const unsigned char *ht = (const unsigned char *)aa.Ht4;
+    const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
+
+    auto Hobj = [&](int o) -> KL_LDS unsigned char * {      // o in 0..3 (static after unrolling)
+        return (KL_LDS unsigned char *)(o == 0 ? h0 : (o == 1 ? h1 : (o == 2 ? h2 : h3)));
+    };
+    auto Vobj = [&](int o) -> KL_LDS unsigned char * {
+        return (KL_LDS unsigned char *)(o == 0 ? v0 : (o == 1 ? v1 : (o == 2 ? v2 : v3)));
+    };
+    auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
+    // copies of tile `tg` (global index, clamped) into the objects of slot o
+    auto dma = [&](int o, int tg) {
+        tg = min(tg, a.nct - 1);
+        glds_copy(ht + (int64_t)tg * h4_tile_bytes(KP), Hobj(o), 3, tid);
+        stage_v_tile<32>(vt + (int64_t)tg * TB, Vobj(o) + wave * TB, lane);
+    };
+    auto wait_older = [&]() {      // all but this wave's newest stage copy have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma4) : "memory");
+    };
+    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
+
+#ifdef KL_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk0; KL_STAMP(tk0);
+#endif
+    bf16x8 ring[R];
+    f32x16 d;                       // W.H of the tile between its M and E segments
+    bf16x8 b0, b1;                  // Q operands of the tile between its E segment and the next M segment
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d[e] = 0.f;
+
+    // Fragment P of the M segment of tile slot TS: [0,N2) MFMA-2 of the previous tile (row reads of ITS image),
+    // [N2,NF) MFMA-1 of this tile (transposed reads).  ra / ta: per-lane base addresses in the two objects.
+    auto issue = [&](auto P, unsigned ra, unsigned ta) {
+        constexpr int p = decltype(P)::value;
+        if constexpr (p < N2) {
+            lds_read_b128<(32 * (p >> 1)) * kRow4B + 32 * (p & 1)>(ring[p % R], ra);
+        } else if constexpr (p < NF) {
+            constexpr int s = p - N2;
+            lds_read_tr_pair<(16 * s) * kRow4B, (16 * s + 4) * kRow4B>(ring[p % R], ta);
+        }
+    };
+    // M segment of tile slot TS (global tile tg).  Uniform for every tile: before the first tile the "previous"
+    // operands are zeros (b0 = b1 = 0 and a zero-filled image object); after the last one MFMA-1 runs on the
+    // clamped copy and is discarded.
+    auto seg_M = [&](auto TS, int tg) {
+        constexpr int ts = decltype(TS)::value;
+#ifdef KL_STAMPS
+        unsigned long long t0, t1, t2, t3; KL_STAMP(t0);
+#endif
+        if (!grpY) dma((ts + 2) % 4, tg + 2);
+        const unsigned ra = lds_addr(Hobj((ts + 3) % 4)) + off_row;
+        const unsigned ta = lds_addr(Hobj(ts % 4)) + off_tr;
+        static_for<DP, D>([&](auto P) { issue(P, ra, ta); });      // the part of the lead the E segment could not issue
+        static_for<0, NF>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            issue(std::integral_constant<int, p + D>{}, ra, ta);
+            // LGKM operations younger than fragment p's: fragments p+1 .. min(p+D, NF-1)
+            constexpr int last = (p + D < NF - 1) ? p + D : NF - 1;
+            constexpr int n_b128 = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
+            constexpr int n_tr = (last - p) - n_b128;
+            lds_wait<n_b128 + 2 * n_tr>(ring[p % R]);
+            if constexpr (p < N2) {
+                acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+            } else {
+                if constexpr (p == N2) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) d[e] = 0.f;
+                }
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % R], wf[p - N2], d, 0, 0, 0);
+            }
+        });
+#ifdef KL_STAMPS
+        KL_STAMP(t1);
+#endif
+        if (grpY) wait_older();
+#ifdef KL_STAMPS
+        KL_STAMP(t2);
+#endif
+        barrier();
+#ifdef KL_STAMPS
+        KL_STAMP(t3);
+        ph[0] += t1 - t0; ph[2] += t2 - t1; ph[3] += t3 - t2;
+#endif
+    };
+    // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
+    auto seg_E = [&](auto TS, int tg) {
+        constexpr int ts = decltype(TS)::value;
+#ifdef KL_STAMPS
+        unsigned long long t0, t1, t2, t3; KL_STAMP(t0);
+#endif
+        if (grpY) dma((ts + 3) % 4, tg + 3);
+        const unsigned va_addr = lds_addr(Vobj(ts % 4)) + voff;
+        f16x8 va, vb;
+        lds_read_b128<0>(va, va_addr);
+        lds_read_b128<1024>(vb, va_addr);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb));
+        float q[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float x = (float)(e < 8 ? va[e & 7] : vb[e & 7]);
+            if (MODE == ROW_INIT) {
+                q[e] = x;
+            } else {
+                q[e] = (x + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
+                s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
+            }
+        }
+        b0 = pack8(q);
+        b1 = pack8(q + 8);
+        asm volatile("" : "+v"(s1));                        // keep the loss terms inside this segment
+        if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
+            const unsigned ra = lds_addr(Hobj(ts % 4)) + off_row;
+            static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
+        }
+#ifdef KL_STAMPS
+        KL_STAMP(t1);
+#endif
+        if (!grpY) wait_older();
+#ifdef KL_STAMPS
+        KL_STAMP(t2);
+#endif
+        barrier();
+#ifdef KL_STAMPS
+        KL_STAMP(t3);
+        ph[1] += t1 - t0; ph[2] += t2 - t1; ph[4] += t3 - t2;
+#endif
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight; the object of "tile -1" zero-filled; tile 0 (and W) landed
+    dma(0, 0);
+    dma(1, 1);
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int e = tid; e < kObj4 / 16; e += kThreads) ((KL_LDS u32x4 *)h3)[e] = z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
+    }
+    wait_older();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+    if constexpr (N2 > 0) {         // what the E segment of "tile -1" would have primed
+        const unsigned ra = lds_addr(Hobj(3)) + off_row;
+        static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
+    }
+    if (grpY) {                     // Y idles through interval 0 (it is X's M(0)); issues the copy X issues in M(0)
+        dma(2, 2);
+        barrier();
+    }
+    // ---- main loop: 4 tiles per body (nct is a multiple of 4)
+    for (int t4 = 0; t4 < a.nct; t4 += 4) {
+        static_for<0, 4>([&](auto I) {
+            seg_M(I, t4 + decltype(I)::value);
+            seg_E(I, t4 + decltype(I)::value);
+        });
+    }
+    // ---- tail: MFMA-2 of the last tile; X has one interval more than Y
+    seg_M(std::integral_constant<int, 0>{}, a.nct);
+    if (!grpY) barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
+#ifdef KL_STAMPS
+    {
+        unsigned long long tk1; KL_STAMP(tk1);
+        ph[6] = tk1 - tk0;
+        if (a.stamps && lane == 0 && active)
+            for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
+    }
+#endif
+
+    if (!active) return;
+    if (MODE != ROW_INIT) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], a.hsum[16 * s + 8 * h + j], s2);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) a.loss_part[rt] = make_float2(s1, s2);
+    }
+    if (MODE != ROW_LOSS) {
+        const int64_t row = (int64_t)rt * 32 + r;
+#pragma unroll
+        for (int m = 0; m < KT; ++m) {
+            f32x4 w[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int comp = 32 * m + 8 * g + 4 * h;
+                if (MODE == ROW_UPDATE) {
+                    w[g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[g][t] = 1.f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int comp = 32 * m + 8 * g + 4 * h;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[g][t] *= acc[m][4 * g + t];
+                *(f32x4 *)(a.W32_new + row * KP + comp) = w[g];
+                bf16x4 wb;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[g][t];
+                *(bf16x4 *)(a.Wb_new + row * WLD + comp) = wb;
+            }
+        }
+    }
+}
+
+}  // namespace klnmf

@@ -33,18 +33,25 @@ __global__ void k_probe_mfma(const float *A, const float *B, float *D) {
 __global__ void k_probe_tr(short *out, int s, int u) {
     __shared__ __attribute__((aligned(16))) unsigned char img[64 * kHRowB];
     const int l = threadIdx.x;
-    for (int e = l; e < 64 * kHRow; e += 64) {
-        const int row = e / kHRow, col = e % kHRow;
-        ((short *)img)[e] = (short)(row * 128 + col);
+    for (int e = l; e < 64 * 64; e += 64) {                      // logical (row, col) -> permuted image
+        const int row = e / 64, col = e % 64;
+        ((short *)img)[row * kHRow + h_col_perm(col)] = (short)(row * 128 + col);
     }
     __syncthreads();
     const int h = l >> 5, i16 = l & 15, tq = i16 >> 2, tp = i16 & 3, half = (l >> 4) & 1;
-    const int off = (8 * h + tq) * kHRowB + (16 * half + 4 * tp) * 2;
+    const int off = (8 * h + tq) * kHRowB + h_col_perm(16 * half + 4 * tp) * 2;
     const KL_LDS unsigned char *p = (const KL_LDS unsigned char *)img + off + (16 * s) * kHRowB + (32 * u) * 2;
     bf16x8 v = tr_pair(p, p + 4 * kHRowB);
     s16x8 w = __builtin_bit_cast(s16x8, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[l * 8 + j] = w[j];
+    // MFMA-2 row fragment of the same image: lane (r, h), k-step s: element j must be logical
+    // column 32u + 16s + 8(j>>2) + 4h + (j&3) of row r
+    const int r = l & 31;
+    const KL_LDS unsigned char *p2 = (const KL_LDS unsigned char *)img + r * kHRowB + 16 * h + (32 * u) * 2 + 32 * s;
+    s16x8 w2 = __builtin_bit_cast(s16x8, *(const KL_LDS bf16x8 *)p2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[512 + l * 8 + j] = w2[j];
 }
 
 // P3: X = A0.B0 (32x32, K=16) kept in the accumulator, converted to bf16 and fed
@@ -135,8 +142,8 @@ inline int run_probes() {
         if (Y[i] != Yref[i]) { failed |= 4; break; }
 
     short *dT;
-    chk(hipMalloc((void **)&dT, 64 * 8 * 2));
-    std::vector<short> T(64 * 8);
+    chk(hipMalloc((void **)&dT, 2 * 64 * 8 * 2));
+    std::vector<short> T(2 * 64 * 8);
     for (int s = 0; s < 2; ++s)
         for (int u = 0; u < 2; ++u) {
             hipLaunchKernelGGL(k_probe_tr, dim3(1), dim3(64), 0, 0, dT, s, u);
@@ -145,6 +152,8 @@ inline int run_probes() {
                 for (int j = 0; j < 8; ++j) {
                     const int row = 16 * s + 8 * (l >> 5) + j, col = 32 * u + (l & 31);
                     if (T[l * 8 + j] != (short)(row * 128 + col)) failed |= 2;
+                    const int row2 = l & 31, col2 = 32 * u + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+                    if (T[512 + l * 8 + j] != (short)(row2 * 128 + col2)) failed |= 16;
                 }
         }
 
