@@ -606,11 +606,14 @@ int klnmf_destroy(klnmf_ctx *c) {
             double sum[8] = {0};
             for (int i = 0; i < c->nrt; ++i) for (int j = 0; j < 8; ++j) sum[j] += (double)hs[(size_t)i * 8 + j];
             const double tiles = (double)c->nct;
-            if (c->row_gen == 4 && c->prec == KLNMF_PREC_BF16 && c->KT <= 7)
-                std::fprintf(stderr, "[stamps4] per tile per wave (cycles): M segment %.0f | E segment %.0f | copy wait %.0f | barrier after M %.0f | barrier after E %.0f || kernel %.0f cycles, %d tiles\n",
-                             sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles,
-                             sum[4] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
-            else
+            if (c->row_gen == 4 && c->prec == KLNMF_PREC_BF16 && c->KT <= 7) {
+                double pro = 0, epi = 0;
+                for (int i = 0; i < c->nrt; ++i) { pro += (double)(hs[(size_t)i * 8 + 7] >> 32); epi += (double)(hs[(size_t)i * 8 + 7] & 0xffffffffull); }
+                std::fprintf(stderr, "[stamps4] per wave: prologue %.0f cycles, epilogue %.0f cycles\n", pro / c->nrt, epi / c->nrt);
+                std::fprintf(stderr, "[stamps4] per tile per wave (cycles): M segment %.0f | E segment %.0f | V wait %.0f | copy wait %.0f | barrier after M %.0f | barrier after E %.0f || kernel %.0f cycles, %d tiles\n",
+                             sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[5] / c->nrt / tiles,
+                             sum[3] / c->nrt / tiles, sum[4] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
+            } else
             std::fprintf(stderr, "[stamps] per tile per wave (cycles): prime+V %.0f | MFMA1 %.0f | epilogue %.0f | MFMA2 %.0f || per stage: barrier wait %.0f, compute %.0f || kernel %.0f cycles, %d stages\n",
                          sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles,
                          sum[4] / c->nrt / c->nst, sum[5] / c->nrt / c->nst, sum[6] / c->nrt, c->nst);

@@ -32,9 +32,7 @@ namespace klnmf {
 
 constexpr int kRow4 = 32 + 8;                    // image row, elements (80 B = 20 dwords = 4 x odd)
 constexpr int kRow4B = kRow4 * 2;
-constexpr int kObj4 = 3 * kGldsRound;            // LDS bytes of one dictionary image object (3 copy rounds)
-constexpr int kVObj4 = kWavesPerWG * 2048;       // the 8 waves' fp16 V tiles of one stage
-constexpr int kDma4 = 5;                         // VMEM instructions per wave per stage copy (3 image rounds + 2 V pieces)
+constexpr int kObj4 = 3 * kGldsRound;            // upper bound of one dictionary tile image (KP <= 256 -> 20480 B)
 __host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
 // logical column (0..31) of a tile -> physical position (16-column groups stored 0,2,1,3 as in mfma.hip.h)
 __host__ __device__ constexpr int h4_col_perm(int c) { return h_col_perm(c); }
@@ -77,6 +75,29 @@ __device__ __forceinline__ void lds_read_tr_pair(bf16x8 &dst, unsigned addr) {
     s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     dst = __builtin_bit_cast(bf16x8, v);
 }
+// V tile of this lane straight to registers (2 x 16 B), ordinary loads.  Two measured reasons not to hand-issue
+// them: (1) an inline-asm load whose destination overlaps the address pair of the load before it misses the
+// wait state the compiler inserts for its own loads (tiles fetched from a stale address); (2) counted vmcnt
+// waits are only valid among operations of one kind -- global_load_lds copies (L2 hits) overtake older
+// VGPR loads (HBM), so "all but the newest N" does not mean the older V load has landed.  The row pass
+// therefore waits vmcnt(0) once per E segment and lets the compiler place the waits of these loads.
+__device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p) {
+    a = *(const f16x8 *)p;
+    b = *(const f16x8 *)(p + 16);
+}
+// global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
+template <int BYTES>
+__device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LDS unsigned char *ldst, int tid) {
+    constexpr int FULL = BYTES / kGldsRound, REM = BYTES % kGldsRound;
+    const int wave_base = (tid & ~63) * 16;
+#pragma unroll
+    for (int r = 0; r < FULL; ++r)
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kGldsRound + tid * 16),
+                                         (KL_LDS void *)(ldst + r * kGldsRound + wave_base), 16, 0, 0);
+    if (REM > 0 && tid * 16 < REM)
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + FULL * kGldsRound + tid * 16),
+                                         (KL_LDS void *)(ldst + FULL * kGldsRound + wave_base), 16, 0, 0);
+}
 template <int N>
 __device__ __forceinline__ void lds_wait(bf16x8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
@@ -95,15 +116,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     constexpr int D = KL_PF < NF - 1 ? KL_PF : NF - 1;      // reads run D fragments ahead of their MFMA
     constexpr int R = D + 1;
     constexpr int DP = D < N2 ? D : N2;      // fragments of the lead that are MFMA-2 reads (issued one segment early)
-    static_assert(KP * kRow4B <= kObj4, "dictionary tile image exceeds its LDS object");
-    __shared__ __attribute__((aligned(16))) unsigned char h0[kObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char h1[kObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char h2[kObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char h3[kObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char v0[kVObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char v1[kVObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char v2[kVObj4];
-    __shared__ __attribute__((aligned(16))) unsigned char v3[kVObj4];
+    constexpr int IMG = KP * kRow4B;          // bytes of one dictionary tile image
+    static_assert(IMG <= kObj4 && IMG % 16 == 0, "dictionary tile image size");
+    constexpr int OBJ = IMG;
+    __shared__ __attribute__((aligned(16))) unsigned char h0[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char h1[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char h2[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char h3[OBJ];
     if (a.st->stop) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,7 +135,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
     const unsigned off_tr = (8 * h + tq) * kRow4B + h4_col_perm(16 * half + 4 * tp) * 2;   // MFMA-1 transposed reads
     const unsigned off_row = r * kRow4B + 16 * h;                                          // MFMA-2 row reads (b128)
-    const unsigned voff = wave * TB + lane * 16;
 
     bf16x8 wf[KS > 0 ? KS : 1];
     if (MODE != ROW_INIT) {
@@ -138,20 +156,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     auto Hobj = [&](int o) -> KL_LDS unsigned char * {      // o in 0..3 (static after unrolling)
         return (KL_LDS unsigned char *)(o == 0 ? h0 : (o == 1 ? h1 : (o == 2 ? h2 : h3)));
     };
-    auto Vobj = [&](int o) -> KL_LDS unsigned char * {
-        return (KL_LDS unsigned char *)(o == 0 ? v0 : (o == 1 ? v1 : (o == 2 ? v2 : v3)));
-    };
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
-    // copies of tile `tg` (global index, clamped) into the objects of slot o
+    // copy of dictionary tile `tg` (global index, clamped) into object o: this thread's slices
     auto dma = [&](int o, int tg) {
+#ifdef KL_ABL_NOHDMA      // ablation build: dictionary tiles copied once (timing only)
+        if (tg > 4) tg = 4;
+#endif
         tg = min(tg, a.nct - 1);
-        glds_copy(ht + (int64_t)tg * h4_tile_bytes(KP), Hobj(o), 3, tid);
-        stage_v_tile<32>(vt + (int64_t)tg * TB, Vobj(o) + wave * TB, lane);
+        glds_copy_exact<IMG>(ht + (int64_t)tg * IMG, Hobj(o), tid);
     };
-    auto wait_older = [&]() {      // all but this wave's newest stage copy have landed
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma4) : "memory");
+    const unsigned char *vlane = vt + lane * 32;             // this lane's 32 bytes of a V tile
+    f16x8 vreg[4];                                           // V tiles of even / odd column tiles (2 x 16 B each)
+    // segment boundary: nothing may be scheduled across it (the MFMAs of an M segment must not sink into the
+    // following E segment and vice versa -- that is the whole point of the schedule)
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef KL_ABL_NOBARRIER
+        asm volatile("s_barrier" ::: "memory");
+#endif
+        __builtin_amdgcn_sched_barrier(0);
     };
-    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
 
 #ifdef KL_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -167,6 +191,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     // [N2,NF) MFMA-1 of this tile (transposed reads).  ra / ta: per-lane base addresses in the two objects.
     auto issue = [&](auto P, unsigned ra, unsigned ta) {
         constexpr int p = decltype(P)::value;
+#ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
+        return;
+#endif
         if constexpr (p < N2) {
             lds_read_b128<(32 * (p >> 1)) * kRow4B + 32 * (p & 1)>(ring[p % R], ra);
         } else if constexpr (p < NF) {
@@ -180,9 +207,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     auto seg_M = [&](auto TS, int tg) {
         constexpr int ts = decltype(TS)::value;
 #ifdef KL_STAMPS
-        unsigned long long t0, t1, t2, t3; KL_STAMP(t0);
+        unsigned long long t0, t1, t3; KL_STAMP(t0);
 #endif
-        if (!grpY) dma((ts + 2) % 4, tg + 2);
         const unsigned ra = lds_addr(Hobj((ts + 3) % 4)) + off_row;
         const unsigned ta = lds_addr(Hobj(ts % 4)) + off_tr;
         static_for<DP, D>([&](auto P) { issue(P, ra, ta); });      // the part of the lead the E segment could not issue
@@ -193,7 +219,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
             constexpr int last = (p + D < NF - 1) ? p + D : NF - 1;
             constexpr int n_b128 = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
             constexpr int n_tr = (last - p) - n_b128;
+#ifndef KL_ABL_NOLDS
             lds_wait<n_b128 + 2 * n_tr>(ring[p % R]);
+#endif
+#ifdef KL_ABL_NOMFMA      // ablation build: matrix instructions removed (results wrong, timing only)
+            if constexpr (p == 0) { acc[0][0] += (float)ring[p % R][0] + (float)b0[0] + (float)b1[0]; d[0] += (float)ring[p % R][1]; asm volatile("" : "+v"(d)); }
+            if constexpr (false)
+#endif
             if constexpr (p < N2) {
                 acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
             } else {
@@ -207,34 +239,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         KL_STAMP(t1);
 #endif
-        if (grpY) wait_older();
-#ifdef KL_STAMPS
-        KL_STAMP(t2);
-#endif
         barrier();
 #ifdef KL_STAMPS
         KL_STAMP(t3);
-        ph[0] += t1 - t0; ph[2] += t2 - t1; ph[3] += t3 - t2;
+        ph[0] += t1 - t0; ph[3] += t3 - t1;
 #endif
     };
     // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
     auto seg_E = [&](auto TS, int tg) {
         constexpr int ts = decltype(TS)::value;
 #ifdef KL_STAMPS
-        unsigned long long t0, t1, t2, t3; KL_STAMP(t0);
+        unsigned long long t0, t1, t3; KL_STAMP(t0);
 #endif
+        // everything this wave has in flight lands here: V of this tile (issued one E segment ago) and its
+        // slices of the dictionary copy issued one E segment ago (first read two or more intervals from now)
+        f16x8 &va = vreg[2 * (ts & 1)], &vb = vreg[2 * (ts & 1) + 1];
+#ifdef KL_STAMPS
+        unsigned long long tw; KL_STAMP(tw);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+#ifdef KL_STAMPS
+        { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
+#endif
+        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)min(tg + 1, a.nct - 1) * TB);
         if (grpY) dma((ts + 3) % 4, tg + 3);
-        const unsigned va_addr = lds_addr(Vobj(ts % 4)) + voff;
-        f16x8 va, vb;
-        lds_read_b128<0>(va, va_addr);
-        lds_read_b128<1024>(vb, va_addr);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb));
+        else dma((ts + 2) % 4, tg + 2);
         float q[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float x = (float)(e < 8 ? va[e & 7] : vb[e & 7]);
+#ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
+            if (true) {
+                q[e] = x + d[e];
+#else
             if (MODE == ROW_INIT) {
                 q[e] = x;
+#endif
             } else {
                 q[e] = (x + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
@@ -250,37 +290,36 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         KL_STAMP(t1);
 #endif
-        if (!grpY) wait_older();
-#ifdef KL_STAMPS
-        KL_STAMP(t2);
-#endif
         barrier();
 #ifdef KL_STAMPS
         KL_STAMP(t3);
-        ph[1] += t1 - t0; ph[2] += t2 - t1; ph[4] += t3 - t2;
+        ph[1] += t1 - t0; ph[4] += t3 - t1;
 #endif
     };
 
-    // ---- prologue: tiles 0 and 1 in flight; the object of "tile -1" zero-filled; tile 0 (and W) landed
+    // ---- prologue: dictionary tiles 0 and 1 and V tile 0 in flight; the object of "tile -1" zero-filled
     dma(0, 0);
     dma(1, 1);
+    v_tile_load(vreg[0], vreg[1], vlane);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int e = tid; e < kObj4 / 16; e += kThreads) ((KL_LDS u32x4 *)h3)[e] = z;
+        for (int e = tid; e < IMG / 16; e += kThreads) ((KL_LDS u32x4 *)h3)[e] = z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
     }
-    wait_older();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1])::"memory");
     barrier();
     if constexpr (N2 > 0) {         // what the E segment of "tile -1" would have primed
         const unsigned ra = lds_addr(Hobj(3)) + off_row;
         static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
     }
-    if (grpY) {                     // Y idles through interval 0 (it is X's M(0)); issues the copy X issues in M(0)
+    if (grpY) {                     // Y idles through interval 0 (X's M(0)); its "E(-1)": slices of tile 2
         dma(2, 2);
         barrier();
     }
+#ifdef KL_STAMPS
+    unsigned long long tkP; KL_STAMP(tkP);
+#endif
     // ---- main loop: 4 tiles per body (nct is a multiple of 4)
     for (int t4 = 0; t4 < a.nct; t4 += 4) {
         static_for<0, 4>([&](auto I) {
@@ -293,12 +332,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     if (!grpY) barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
 #ifdef KL_STAMPS
-    {
-        unsigned long long tk1; KL_STAMP(tk1);
-        ph[6] = tk1 - tk0;
-        if (a.stamps && lane == 0 && active)
-            for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
-    }
+    unsigned long long tkL; KL_STAMP(tkL);
 #endif
 
     if (!active) return;
@@ -339,6 +373,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
             }
         }
     }
+#ifdef KL_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long tkE; KL_STAMP(tkE);
+        ph[6] = tkE - tk0;
+        ph[7] = ((tkP - tk0) << 32) | ((tkE - tkL) & 0xffffffffull);      // prologue | epilogue
+        if (a.stamps && lane == 0)
+            for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
+    }
+#endif
 }
 
 }  // namespace klnmf

@@ -3,7 +3,7 @@
 import os, subprocess, sys, json
 import numpy as np
 
-CASES = [(64, 64, 32, 2), (256, 256, 32, 2), (256, 512, 200, 2), (4096, 1024, 200, 3), (1024, 128, 17, 2), (512, 4096, 96, 2)]
+CASES = [(2048, 256, 40, 2), (2048, 256, 96, 2), (2048, 256, 128, 2), (2048, 256, 32, 2)]
 
 def child(gen):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

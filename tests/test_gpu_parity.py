@@ -412,3 +412,40 @@ def test_config4_k_and_f_at_reduced_rows_bf16():
     print("config4-shape: true fp64 loss of the bf16 model rel %.3e" % ((true_g - fo) / fo))
     assert abs(true_g - fo) <= 1e-4 * abs(fo)
     assert _rel_to_max(m.components_, Ho) < 3e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k', [(2048, 256, 40), (2048, 512, 96), (4096, 1024, 17), (2048, 256, 128)])
+def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
+    """The ping-pong row pass (mfma4.hip.h) and the generation-1 kernel run the same MFMA
+    sequence per wave: errors, W and H must be bit-identical.  Shapes chosen where the
+    hand-scheduled variant once fetched V tiles from stale addresses (k <= 96, f > 128)."""
+    X = orc.synthetic_V(5, n, f, k)
+    H0 = orc.synthetic_H0(5, f, k)
+    out = {}
+    for gen in ('1', '4'):
+        monkeypatch.setenv('KLNMF_ROWPASS', gen)
+        m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
+        out[gen] = (W, m.components_.copy(), errors)
+    for a, b in zip(out['1'], out['4']):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_rowpass_generations_agree_full_chip(monkeypatch):
+    """Same comparison with enough row tiles to occupy every CU several times over
+    (memory latencies under load are what exposed the ordering bugs of the counted-wait
+    variants: a correct kernel at 8k rows was wrong at 64k+)."""
+    torch = pytest.importorskip('torch')
+    n, f, k = 262144, 512, 200
+    g = torch.Generator(device='cuda').manual_seed(7)
+    X = (torch.rand(n, f, generator=g, device='cuda') * 3).cpu().numpy()
+    H0 = orc.synthetic_H0(7, f, k)
+    out = {}
+    for gen in ('1', '4'):
+        monkeypatch.setenv('KLNMF_ROWPASS', gen)
+        m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
+        out[gen] = (W, m.components_.copy(), errors)
+    assert np.all(np.isfinite(out['4'][2])) and np.all(np.diff(out['4'][2]) < 0)
+    for a, b in zip(out['1'], out['4']):
+        np.testing.assert_array_equal(a, b)
