@@ -427,8 +427,9 @@ def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
         monkeypatch.setenv('KLNMF_ROWPASS', gen)
         m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
         out[gen] = (W, m.components_.copy(), errors)
-    for a, b in zip(out['1'], out['4']):
-        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out['1'][0], out['4'][0])
+    np.testing.assert_array_equal(out['1'][1], out['4'][1])
+    assert_allclose(out['4'][2], out['1'][2], rtol=1e-12)
 
 
 @pytest.mark.gpu
@@ -447,5 +448,6 @@ def test_rowpass_generations_agree_full_chip(monkeypatch):
         m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
         out[gen] = (W, m.components_.copy(), errors)
     assert np.all(np.isfinite(out['4'][2])) and np.all(np.diff(out['4'][2]) < 0)
-    for a, b in zip(out['1'], out['4']):
-        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out['1'][0], out['4'][0])
+    np.testing.assert_array_equal(out['1'][1], out['4'][1])
+    assert_allclose(out['4'][2], out['1'][2], rtol=1e-12)     # fp64 sum of per-row-tile partials
