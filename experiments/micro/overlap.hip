@@ -41,7 +41,7 @@ __device__ __forceinline__ void valu_block(float (&x)[16], float c) {
 }
 
 // mode bit0: MFMA waves active, bit1: VALU waves active; SAMEWAVE: every wave does both, interleaved
-template <int KIND, int SAMEWAVE>
+template <int KIND, int SAMEWAVE, int NACC = 4>
 __global__ __launch_bounds__(512, 2) void k(float *out, int iters, int mode, float seed) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     bf16x8 a, b;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, int mode, flo
         if (mode & 1)
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j & 3], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) acc[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j % NACC], 0, 0, 0);
             }
     } else {
         if (mode & 2)
@@ -80,14 +80,14 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, int mode, flo
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
-template <int KIND, int SAMEWAVE>
+template <int KIND, int SAMEWAVE, int NACC = 4>
 float run(int mode, int iters) {
     float *out; hipMalloc(&out, 256 * 512 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<KIND, SAMEWAVE><<<256, 512>>>(out, 10, mode, 1.5f);
+    k<KIND, SAMEWAVE, NACC><<<256, 512>>>(out, 10, mode, 1.5f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<KIND, SAMEWAVE><<<256, 512>>>(out, iters, mode, 1.5f);
+    k<KIND, SAMEWAVE, NACC><<<256, 512>>>(out, iters, mode, 1.5f);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipFree(out);
@@ -115,6 +115,13 @@ int main() {
     report<K_RCP>("v_rcp");
     report<K_CVTF16>("cvt_f16");
     report<K_MOV>("v_mov");
+    {
+        const int it2 = 20000;
+        const float m1 = run<K_MIX, 0, 1>(1, it2), v1 = run<K_MIX, 0, 1>(2, it2), b1 = run<K_MIX, 0, 1>(3, it2);
+        const float m2 = run<K_MIX, 0, 2>(1, it2), b2 = run<K_MIX, 0, 2>(3, it2);
+        printf("dependent MFMA chain (1 accumulator): MFMA alone %.3f  VALU(mix) alone %.3f  both %.3f\n", m1, v1, b1);
+        printf("2 accumulators alternating:           MFMA alone %.3f  VALU(mix) alone %.3f  both %.3f\n", m2, v1, b2);
+    }
     const int iters = 20000;
     for (int kind = 0; kind < 2; ++kind) {
         const float m = kind ? run<K_TRANS, 1>(1, iters) : run<K_FMA, 1>(1, iters);

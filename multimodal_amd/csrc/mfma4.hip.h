@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     __shared__ __attribute__((aligned(16))) unsigned char h1[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char h2[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char h3[OBJ];
+    __shared__ __attribute__((aligned(16))) float hsum_lds[KP];      // row sums of H, for the sum(W.H) term of the loss
     if (a.st->stop) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,7 +150,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
     float s1 = 0.f, s2 = 0.f;
     const float eps = a.eps;
-
     const unsigned char *ht = (const unsigned char *)aa.Ht4;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
 
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tk0; KL_STAMP(tk0);
 #endif
+    bool tail = false;
     bf16x8 ring[R];
     f32x16 d;                       // W.H of the tile between its M and E segments
     bf16x8 b0, b1;                  // Q operands of the tile between its E segment and the next M segment
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         KL_STAMP(t1);
 #endif
-        barrier();
+        if (grpY && !tail) barrier();
+        else __builtin_amdgcn_sched_barrier(0);
 #ifdef KL_STAMPS
         KL_STAMP(t3);
         ph[0] += t1 - t0; ph[3] += t3 - t1;
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         KL_STAMP(t1);
 #endif
-        barrier();
+        if (!grpY) barrier();
+        else __builtin_amdgcn_sched_barrier(0);
 #ifdef KL_STAMPS
         KL_STAMP(t3);
         ph[1] += t1 - t0; ph[4] += t3 - t1;
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int e = tid; e < IMG / 16; e += kThreads) ((KL_LDS u32x4 *)h3)[e] = z;
+        if (MODE != ROW_INIT && tid < KP) hsum_lds[tid] = a.hsum[tid];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
     }
@@ -313,10 +317,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
         const unsigned ra = lds_addr(Hobj(3)) + off_row;
         static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
     }
-    if (grpY) {                     // Y idles through interval 0 (X's M(0)); its "E(-1)": slices of tile 2
-        dma(2, 2);
-        barrier();
-    }
+    if (grpY) dma(2, 2);            // Y's "E(-1)": its slices of tile 2 (X issues its own in E(0), same interval)
 #ifdef KL_STAMPS
     unsigned long long tkP; KL_STAMP(tkP);
 #endif
@@ -327,9 +328,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
             seg_E(I, t4 + decltype(I)::value);
         });
     }
-    // ---- tail: MFMA-2 of the last tile; X has one interval more than Y
+    // ---- tail: MFMA-2 of the last tile (no copies are in flight into anything it reads; no barrier needed)
+    tail = true;
     seg_M(std::integral_constant<int, 0>{}, a.nct);
-    if (!grpY) barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
 #ifdef KL_STAMPS
     unsigned long long tkL; KL_STAMP(tkL);
@@ -337,41 +338,50 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 
     if (!active) return;
     if (MODE != ROW_INIT) {
+        // sum over this wave's rows of (W.H) = sum_c W[row][c] * hsum[c]; hsum from LDS (staged in the prologue:
+        // read from global memory here it was KS dependent round trips on the kernel's tail)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], a.hsum[16 * s + 8 * h + j], s2);
+            for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (lane == 0) a.loss_part[rt] = make_float2(s1, s2);
     }
     if (MODE != ROW_LOSS) {
+        // W rule.  All loads of the old fp32 master are issued before the first use (the operand fragments,
+        // ring and V registers of the main loop are dead here, so KT*16 registers are free): one memory round
+        // trip per wave instead of one per 32-component block -- with a single workgroup per CU nothing else
+        // hides this tail (it was 15 % of the kernel when the loads were consumed block by block).
         const int64_t row = (int64_t)rt * 32 + r;
+        f32x4 wold[KT][4];
 #pragma unroll
-        for (int m = 0; m < KT; ++m) {
-            f32x4 w[4];
+        for (int m = 0; m < KT; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int comp = 32 * m + 8 * g + 4 * h;
                 if (MODE == ROW_UPDATE) {
-                    w[g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
+                    wold[m][g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) w[g][t] = 1.f;
+                    for (int t = 0; t < 4; ++t) wold[m][g][t] = 1.f;
                 }
             }
+        if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int comp = 32 * m + 8 * g + 4 * h;
+                f32x4 w = wold[m][g];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) w[g][t] *= acc[m][4 * g + t];
-                *(f32x4 *)(a.W32_new + row * KP + comp) = w[g];
+                for (int t = 0; t < 4; ++t) w[t] *= acc[m][4 * g + t];
+                *(f32x4 *)(a.W32_new + row * KP + comp) = w;
                 bf16x4 wb;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[g][t];
+                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[t];
                 *(bf16x4 *)(a.Wb_new + row * WLD + comp) = wb;
             }
-        }
     }
 #ifdef KL_STAMPS
     {
