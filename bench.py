@@ -231,9 +231,12 @@ def main():
             'stopped_early': bool(stopped),
             'loss_first': errors[0] if errors else None,
             'loss_last': errors[-1] if errors else None,
+            'loss_finite_and_decreasing': bool(len(errors) > 1 and all(e == e and abs(e) != float('inf') for e in errors)
+                                               and all(b < a for a, b in zip(errors, errors[1:]))),
             'device': info,
             'roofline': {
-                'kernel': 'k_rowpass (W.H -> ratio/loss -> Q.H^T -> W rule)',
+                'kernel': ('k_rowpass4' if (args.precision == 'bf16' and k <= 224 and os.environ.get('KLNMF_ROWPASS', '4') == '4')
+                           else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule)',
                 'bound': 'mfma',
                 'achieved': flops_row / (row_ms * 1e-3) / 1e12 if row_ms > 0 else None,
                 'peak': PEAK_BF16_TFLOPS,
@@ -244,6 +247,10 @@ def main():
                 'launches': prof['rowpass_launches'],
                 'algorithmic_flops_per_launch': flops_row,
                 'algorithmic_hbm_bytes_per_launch': n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2),
+                # the kernel sits on the ridge (309 flop/B algorithmic vs 2500/8 = 312): the HBM view of the same launch
+                'hbm': {'achieved': (n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2)) / (row_ms * 1e-3) / 1e9 if row_ms > 0 else None,
+                        'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': (n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2)) / (row_ms * 1e-3) / 1e9 / 8000.0 if row_ms > 0 else None},
             },
             'kernels': {
                 'k_colpass': {'avg_launch_ms': col_ms, 'launches': prof['colpass_launches'],

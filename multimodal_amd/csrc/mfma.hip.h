@@ -62,6 +62,10 @@ constexpr int kHRowB = kHRow * 2;                //   16 rows read with ds_read_
 __host__ __device__ constexpr int h_col_perm(int c) {           // logical column (0..63) -> physical
     return (c & ~15) | ((((c >> 2) & 1) << 1 | ((c >> 3) & 1)) << 2) | (c & 3);
 }
+// element offset of (component a, column c) inside a 32-column tile image of the ping-pong row pass (mfma4.hip.h)
+__host__ __device__ constexpr int h4_elem_rt(int a, int c) {
+    return a * 32 + ((((h_col_perm(c) >> 3) ^ ((a >> 2) & 3)) << 3) | (h_col_perm(c) & 7));
+}
 constexpr int kStageRowTiles = 2;                // 32-row tiles per LDS stage (column pass)
 constexpr int kGldsRound = kThreads * 16;        // bytes one global_load_lds round moves (8 KiB)
 
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
         const __bf16 v = (__bf16)row[j];
         Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + h_col_perm((int)(j % kStageCols))] = v;
-        if (Ht4) Ht4[(j / 32) * (int64_t)kp * 40 + (int64_t)a * 40 + h_col_perm((int)(j % 32))] = v;   // mfma4.hip.h tile images
+        if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(a, (int)(j % 32))] = v;   // mfma4.hip.h tile images (swizzled)
         HTb[j * kp + a] = v;
         hs += (double)(float)v;
     }

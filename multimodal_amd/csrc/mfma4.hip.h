@@ -30,8 +30,19 @@
 
 namespace klnmf {
 
-constexpr int kRow4 = 32 + 8;                    // image row, elements (80 B = 20 dwords = 4 x odd)
+// Dictionary tile image [component a][32 columns], 64-byte rows, no padding.  A column c goes to position
+// p = h_col_perm(c) (4-column blocks of each 16-column group in the order 0,2,1,3: the MFMA-2 fragment of
+// a lane half is then 16 contiguous bytes), and the 16-byte chunk p>>3 of row a is stored at chunk
+// (p>>3) ^ ((a>>2)&3).  With that XOR both read patterns are bank-conflict free (64 banks x 4 B):
+//  * ds_read_b64_tr_b16 (MFMA-1): a 32-lane group reads 4 consecutive rows x 64 B = all 64 banks once
+//    (with padded 80-byte rows the 4th row wrapped onto the 1st: 2-way conflict, PMC: a third of all
+//    LDS cycles), the XOR is the same for the 4 rows of a group;
+//  * ds_read_b128 (MFMA-2): the 16 rows of a lane group differ in (a&3, (a>>2)&3), i.e. in (bank/16, chunk).
+constexpr int kRow4 = 32;                        // image row, elements
 constexpr int kRow4B = kRow4 * 2;
+__host__ __device__ constexpr int h4_elem(int a, int c) {       // element offset of (component a, column c) in a tile image
+    return a * kRow4 + ((((h_col_perm(c) >> 3) ^ ((a >> 2) & 3)) << 3) | (h_col_perm(c) & 7));
+}
 constexpr int kObj4 = 3 * kGldsRound;            // upper bound of one dictionary tile image (KP <= 256 -> 20480 B)
 __host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
 // logical column (0..31) of a tile -> physical position (16-column groups stored 0,2,1,3 as in mfma.hip.h)
@@ -67,11 +78,11 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_b128(f16x8 &dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
-template <int OFF0, int OFF1>
-__device__ __forceinline__ void lds_read_tr_pair(bf16x8 &dst, unsigned addr) {
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr_pair(bf16x8 &dst, unsigned addr0, unsigned addr1) {
     s16x4 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF1));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr0), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr1), "n"(OFF));
     s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     dst = __builtin_bit_cast(bf16x8, v);
 }
@@ -134,8 +145,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     const int rt = active ? rt_raw : a.nrt - 1;
 
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
-    const unsigned off_tr = (8 * h + tq) * kRow4B + h4_col_perm(16 * half + 4 * tp) * 2;   // MFMA-1 transposed reads
-    const unsigned off_row = r * kRow4B + 16 * h;                                          // MFMA-2 row reads (b128)
+    // per-lane byte offsets inside a tile image (see h4_elem): MFMA-1 transposed reads (rows 8h+tq and +4 of a
+    // 16-component step), MFMA-2 row reads (row r of a 32-component block, k-step hh = 0 / 1)
+    const unsigned off_tr0 = 2 * h4_elem(8 * h + tq, 16 * half + 4 * tp);
+    const unsigned off_tr1 = 2 * h4_elem(8 * h + tq + 4, 16 * half + 4 * tp);
+    const unsigned off_row0 = 2 * h4_elem(r, 4 * h);             // logical columns 4h.. and 8+4h.. = one permuted chunk
+    const unsigned off_row1 = 2 * h4_elem(r, 16 + 4 * h);
 
     bf16x8 wf[KS > 0 ? KS : 1];
     if (MODE != ROW_INIT) {
@@ -190,16 +205,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 
     // Fragment P of the M segment of tile slot TS: [0,N2) MFMA-2 of the previous tile (row reads of ITS image),
     // [N2,NF) MFMA-1 of this tile (transposed reads).  ra / ta: per-lane base addresses in the two objects.
-    auto issue = [&](auto P, unsigned ra, unsigned ta) {
+    auto issue = [&](auto P, unsigned robj, unsigned tobj) {     // robj / tobj: LDS addresses of the two tile images
         constexpr int p = decltype(P)::value;
 #ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
         return;
 #endif
         if constexpr (p < N2) {
-            lds_read_b128<(32 * (p >> 1)) * kRow4B + 32 * (p & 1)>(ring[p % R], ra);
+            lds_read_b128<(32 * (p >> 1)) * kRow4B>(ring[p % R], robj + ((p & 1) ? off_row1 : off_row0));
         } else if constexpr (p < NF) {
             constexpr int s = p - N2;
-            lds_read_tr_pair<(16 * s) * kRow4B, (16 * s + 4) * kRow4B>(ring[p % R], ta);
+            lds_read_tr_pair<(16 * s) * kRow4B>(ring[p % R], tobj + off_tr0, tobj + off_tr1);
         }
     };
     // M segment of tile slot TS (global tile tg).  Uniform for every tile: before the first tile the "previous"
@@ -210,8 +225,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         unsigned long long t0, t1, t3; KL_STAMP(t0);
 #endif
-        const unsigned ra = lds_addr(Hobj((ts + 3) % 4)) + off_row;
-        const unsigned ta = lds_addr(Hobj(ts % 4)) + off_tr;
+        const unsigned ra = lds_addr(Hobj((ts + 3) % 4));
+        const unsigned ta = lds_addr(Hobj(ts % 4));
         static_for<DP, D>([&](auto P) { issue(P, ra, ta); });      // the part of the lead the E segment could not issue
         static_for<0, NF>([&](auto P) {
             constexpr int p = decltype(P)::value;
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
         b1 = pack8(q + 8);
         asm volatile("" : "+v"(s1));                        // keep the loss terms inside this segment
         if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
-            const unsigned ra = lds_addr(Hobj(ts % 4)) + off_row;
+            const unsigned ra = lds_addr(Hobj(ts % 4));
             static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
         }
 #ifdef KL_STAMPS
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1])::"memory");
     barrier();
     if constexpr (N2 > 0) {         // what the E segment of "tile -1" would have primed
-        const unsigned ra = lds_addr(Hobj(3)) + off_row;
+        const unsigned ra = lds_addr(Hobj(3));
         static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
     }
     if (grpY) dma(2, 2);            // Y's "E(-1)": its slices of tile 2 (X issues its own in E(0), same interval)

@@ -13,10 +13,10 @@ pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_fro
 
 
 def short(name):
-    m = re.search(r'k_[a-zA-Z_]+', name)
+    m = re.search(r'k_[a-zA-Z_]+\d?', name)
     base = m.group(0) if m else name[:40]
     if 'k_rowpass' in name:
-        mm = re.search(r'k_rowpassILi(\d+)ELi(\d+)ELi(\d+)', name) or re.search(r'k_rowpass<(\d+), (\d+), (\d+)', name)
+        mm = re.search(r'k_rowpass4?ILi(\d+)ELi(\d+)ELi(\d+)', name) or re.search(r'k_rowpass4?<(\d+), (\d+), (\d+)', name)
         if mm:
                 base += '<KT=%s,odd=%s,mode=%s>' % mm.groups()
     return base
