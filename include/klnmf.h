@@ -173,6 +173,13 @@ int klnmf_profile_read(klnmf_ctx *ctx, int64_t *rowpass_launches,
                        double *colpass_ms, int reset);
 int klnmf_synchronize(klnmf_ctx *ctx);
 
+/* ---- reconstruction (next-row K7) ---------------------------------------- */
+/* C[m x n] = A[m x kk] . B[kk x n], row-major host arrays of `dtype`, computed on `device` in that
+ * arithmetic.  Replaces `internal.dot(self.get_dico(dest_mod))` / `internal.dot(self.get_stacked_dicos(..))`
+ * of MultimodalLearner.reconstruct_modality / reconstruct_modalities (learner.py:80-84). */
+int klnmf_matmul(int device, int dtype, int64_t m, int64_t n, int64_t kk,
+                 const void *A, const void *B, void *C);
+
 /* ---- hardware probes (tests) -------------------------------------------- */
 /* Runs the MFMA / LDS-transpose layout self-checks the fused kernels rely on;
  * *failed = bitmask of failing probes (0 = all good). */

@@ -72,6 +72,7 @@ SIGNATURES = {
     'klnmf_profile_read': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double),
                                       _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.c_int]),
     'klnmf_synchronize': (_c.c_int, [_ctx_p]),
+    'klnmf_matmul': (_c.c_int, [_c.c_int, _c.c_int, _i64, _i64, _i64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'klnmf_selftest': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_int)]),
 }
 
@@ -138,6 +139,24 @@ def device_info(device=0):
     mem = _c.c_uint64(0)
     _check(lib.klnmf_device_info(device, arch, 64, ctypes.byref(cu), ctypes.byref(mem)))
     return {'arch': arch.value.decode(), 'cu_count': cu.value, 'hbm_bytes': mem.value}
+
+
+def matmul(A, B, device=0):
+    """A.dot(B) on the GPU (klnmf_matmul): float32 if both operands are float32,
+    float64 otherwise -- the reconstruction product of learner.py:80-84."""
+    A = np.asarray(A)
+    B = np.asarray(B)
+    if A.ndim != 2 or B.ndim != 2 or A.shape[1] != B.shape[0]:
+        raise ValueError('shapes %s and %s not aligned' % (A.shape, B.shape))
+    dt = np.float32 if (A.dtype == np.float32 and B.dtype == np.float32) else np.float64
+    A = np.ascontiguousarray(A, dtype=dt)
+    B = np.ascontiguousarray(B, dtype=dt)
+    C = np.empty((A.shape[0], B.shape[1]), dtype=dt)
+    lib = load()
+    _check(lib.klnmf_matmul(device, DT_F32 if dt == np.float32 else DT_F64, A.shape[0], B.shape[1], A.shape[1],
+                            A.ctypes.data_as(_c.c_void_p), B.ctypes.data_as(_c.c_void_p),
+                            C.ctypes.data_as(_c.c_void_p)))
+    return C
 
 
 def selftest(device=0):

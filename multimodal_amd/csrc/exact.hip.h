@@ -106,6 +106,14 @@ struct EpiW {
     __device__ void finish(double *) {}
 };
 
+// Plain store C[r][c] = acc (reconstruction GEMM, learner.py:80-84).
+template <typename T>
+struct EpiStore {
+    T *C; int64_t ldc;
+    __device__ void apply(int r, int c, T v) { C[(int64_t)r * ldc + c] = v; }
+    __device__ void finish(double *) {}
+};
+
 // Partial numerator of the H rule for one row chunk.
 template <typename T>
 struct EpiN {

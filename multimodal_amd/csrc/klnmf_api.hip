@@ -544,6 +544,31 @@ void get_matrix(klnmf_ctx *c, void *dst, int dtype, int64_t rows, int64_t cols, 
 }  // namespace
 
 // =============================================================== exports ===
+template <typename T>
+static void matmul_on_device(int64_t m, int64_t n, int64_t kk, const void *A, const void *B, void *C) {
+    T *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    auto release = [&] { (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); };
+    try {
+        HIPCHK(hipMalloc((void **)&dA, sizeof(T) * (size_t)(m * kk)));
+        HIPCHK(hipMalloc((void **)&dB, sizeof(T) * (size_t)(kk * n)));
+        HIPCHK(hipMalloc((void **)&dC, sizeof(T) * (size_t)(m * n)));
+        HIPCHK(hipMemcpy(dA, A, sizeof(T) * (size_t)(m * kk), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dB, B, sizeof(T) * (size_t)(kk * n), hipMemcpyHostToDevice));
+        EpiStore<T> epi{dC, n};
+        dim3 grid((unsigned)((n + GT - 1) / GT), (unsigned)((m + GT - 1) / GT), 1);
+        hipLaunchKernelGGL((k_gemm<T, EpiStore<T>>), grid, dim3(256), 0, 0, (int)m, (int)n, (int)kk,
+                           (const T *)dA, (int64_t)kk, (int64_t)1, (const T *)dB, (int64_t)n, (int64_t)1,
+                           (int)kk + GK, (const DevState *)nullptr, epi);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(C, dC, sizeof(T) * (size_t)(m * n), hipMemcpyDeviceToHost));
+    } catch (...) {
+        release();
+        throw;
+    }
+    release();
+}
+
+
 extern "C" {
 
 int klnmf_version(void) { return KLNMF_VERSION; }
@@ -1102,6 +1127,20 @@ int klnmf_synchronize(klnmf_ctx *c) {
     return guarded([&] {
         use(c);
         HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_matmul(int device, int dtype, int64_t m, int64_t n, int64_t kk, const void *A, const void *B, void *C) {
+    return guarded([&] {
+        if (m < 0 || n < 0 || kk < 0 || m > (1LL << 30) || n > (1LL << 30) || kk > (1LL << 30))
+            fail(KLNMF_ERR_ARG, "klnmf_matmul: bad shape");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_matmul: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (m == 0 || n == 0) return;
+        if (!A || !B || !C) fail(KLNMF_ERR_ARG, "klnmf_matmul: null pointer");
+        HIPCHK(hipSetDevice(device));
+        if (kk == 0) { std::memset(C, 0, (size_t)(m * n) * (dtype == KLNMF_DT_F64 ? 8 : 4)); return; }
+        if (dtype == KLNMF_DT_F64) matmul_on_device<double>(m, n, kk, A, B, C);
+        else matmul_on_device<float>(m, n, kk, A, B, C);
     });
 }
 

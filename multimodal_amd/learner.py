@@ -13,6 +13,8 @@ from .lib.nmf import KLdivNMF as NMF
 from .lib.nmf import check_non_negative
 from .lib.array_utils import safe_hstack
 from .lib.sklearn_utils import atleast2d_or_csr
+from . import _native
+from .lib.nmf import _default_device
 
 
 def _checked(blocks):
@@ -115,10 +117,13 @@ class MultimodalLearner(object):
                                                iterations)
 
     def reconstruct_modalities(self, dest_mods, internal):
-        return internal.dot(self.get_stacked_dicos(dest_mods))
+        """internal . stacked dictionaries of dest_mods (reference learner.py:83-84),
+        on the device (klnmf_matmul), in the operands' arithmetic."""
+        return _native.matmul(internal, self.get_stacked_dicos(dest_mods), _default_device())
 
     def reconstruct_modality(self, dest_mod, internal):
-        return internal.dot(self.get_dico(dest_mod))
+        """internal . dictionary of dest_mod (reference learner.py:80-81)."""
+        return _native.matmul(internal, self.get_dico(dest_mod), _default_device())
 
     def modalities_to_modalities(self, orig_mods, dest_mods, test_data,
                                  iterations):

@@ -451,3 +451,26 @@ def test_rowpass_generations_agree_full_chip(monkeypatch):
     np.testing.assert_array_equal(out['1'][0], out['4'][0])
     np.testing.assert_array_equal(out['1'][1], out['4'][1])
     assert_allclose(out['4'][2], out['1'][2], rtol=1e-12)     # fp64 sum of per-row-tile partials
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt,rtol', [(np.float64, 1e-12), (np.float32, 2e-5)])
+def test_matmul_reconstruction(dt, rtol):
+    """klnmf_matmul = the `internal.dot(dico)` of reconstruct_modality / reconstruct_modalities
+    (learner.py:80-84): ragged sizes, both arithmetics, empty contraction."""
+    rs = np.random.RandomState(3)
+    for (m, kk, n) in [(1, 1, 1), (7, 3, 5), (130, 50, 257), (64, 200, 64)]:
+        A = rs.random_sample((m, kk)).astype(dt)
+        B = rs.random_sample((kk, n)).astype(dt)
+        C = _native.matmul(A, B)
+        assert C.dtype == dt and C.shape == (m, n)
+        assert_allclose(C, A.astype(np.float64).dot(B.astype(np.float64)), rtol=rtol)
+    assert _native.matmul(np.zeros((3, 0)), np.zeros((0, 4))).tolist() == np.zeros((3, 4)).tolist()
+    with pytest.raises(ValueError):
+        _native.matmul(np.ones((2, 3)), np.ones((4, 2)))
+    lr = learner.MultimodalLearner(['a', 'b'], [3, 5], [2., .5], 4)
+    lr.dico = rs.random_sample((4, 8))
+    internal = rs.random_sample((6, 4))
+    assert_allclose(lr.reconstruct_modality('b', internal), internal.dot(lr.dico[:, 3:8]), rtol=1e-12)
+    assert_allclose(lr.reconstruct_modalities(['b', 'a'], internal),
+                    internal.dot(np.hstack([lr.dico[:, 3:8], lr.dico[:, :3]])), rtol=1e-12)
