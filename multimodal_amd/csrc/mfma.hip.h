@@ -70,8 +70,17 @@ constexpr int kStageRowTiles = 2;                // 32-row tiles per LDS stage (
 constexpr int kGldsRound = kThreads * 16;        // bytes one global_load_lds round moves (8 KiB)
 
 __host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
-// bf16 W image row: KP + 8 elements -> (KP+8)/8 is odd -> ds_read_b128 conflict-free
-__host__ __device__ constexpr int w_ld(int kp) { return kp + 8; }
+// bf16 W image [sample row][component]: row stride KP elements, +32 when KP/32 is even, so that the stride
+// is 16 or 48 dwords (mod 64 banks): the 4 consecutive rows x 64 B of a transposed read (column pass,
+// MFMA-3) then cover all 64 banks once.  The 16 rows of a ds_read_b128 lane group (MFMA-1') would collide
+// 4-way on such a stride, so the 16-byte chunk c of row i is stored at chunk c ^ ((i>>2)&3) -- the same
+// swizzle as the dictionary tile images of mfma4.hip.h.  (Padded 464-byte rows were conflict-free for the
+// row reads only: PMC showed a third of the column pass's LDS cycles as bank conflicts.)
+__host__ __device__ constexpr int w_ld(int kp) { return kp + ((kp / 32) % 2 == 0 ? 32 : 0); }
+// element offset of component `comp` inside row `row` (row stride not included)
+__host__ __device__ constexpr int wb_col(int row, int comp) {
+    return ((((comp >> 3) ^ ((row >> 2) & 3)) << 3) | (comp & 7));
+}
 __host__ __device__ constexpr int h_stage_bytes(int kp) { return kp * kHRowB; }
 __host__ __device__ constexpr int h_stage_lds(int kp) { return round_up(h_stage_bytes(kp), kGldsRound); }
 __host__ __device__ constexpr int w_stage_bytes(int kp) { return kStageRowTiles * 32 * w_ld(kp) * 2; }
@@ -256,9 +265,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 
     bf16x8 wf[KS];
     if (MODE != ROW_INIT) {
-        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD + 8 * h;
+        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + 16 * s);
+        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + wb_col(r, 16 * s + 8 * h));
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 bf16x4 wb;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[g][t];
-                *(bf16x4 *)(a.Wb_new + row * WLD + comp) = wb;
+                *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
             }
         }
     }
@@ -509,10 +518,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     const int send = min(total_stages, sbeg + a.stages_per_chunk);
 
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
-    //  row read (MFMA1' A operand): W_old row r, components 8h..8h+7
-    const int off_row = r * WLDB + (8 * h) * 2;
-    //  tr read (MFMA3 A operand): rows = samples, cols = components
-    const int off_tr = (4 * h + tq) * WLDB + (16 * half + 4 * tp) * 2;
+    //  row read (MFMA1' A operand): W_old row r, components 16*idx + 8h..+7 = chunk 2*idx + h (swizzled, wb_col)
+    const int off_row_e = r * WLDB + 2 * wb_col(r, 8 * h);          // even k-steps (idx & 1 == 0)
+    const int off_row_o = r * WLDB + 2 * wb_col(r, 16 + 8 * h);     // odd k-steps, relative to chunk group idx>>1
+    //  tr read (MFMA3 A operand): rows = samples 4h+tq (+8 for the second read), cols = components
+    const int off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
+    const int off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
 
     bf16x8 hf[KS];
     {
@@ -537,29 +548,34 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
         glds_copy(wo + goff, buf, ROUNDS, tid);
         glds_copy(wn + goff, buf + IMG, ROUNDS, tid);
     };
-    auto compute = [&](const KL_LDS unsigned char *img_old) {
+    auto compute = [&](const KL_LDS unsigned char *img_old, bool more, int sg) {
         const KL_LDS unsigned char *img_new = img_old + IMG;
 #pragma unroll
         for (int u = 0; u < RS; ++u) {
             // fragment sequence: KS row reads of W_old (MFMA1'), then 2*KT transposed
             // reads of W_new (MFMA3); reads run two MFMAs ahead (3-slot ring)
-            const KL_LDS unsigned char *p1 = img_old + off_row + (32 * u) * WLDB;
-            const KL_LDS unsigned char *p3 = img_new + off_tr + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p1e = img_old + off_row_e + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p1o = img_old + off_row_o + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p30 = img_new + off_tr0 + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p31 = img_new + off_tr1 + (32 * u) * WLDB;
             constexpr int N3 = 2 * KT;
             bf16x8 ring[3];
             auto fetch = [&](int idx) {
                 if (idx < KS) {
-                    ring[idx % 3] = *(const KL_LDS bf16x8 *)(p1 + 32 * idx);
+                    ring[idx % 3] = *(const KL_LDS bf16x8 *)(((idx & 1) ? p1o : p1e) + 64 * (idx >> 1));
                 } else if (idx < KS + N3) {
                     const int j = idx - KS, m = j >> 1, hh = j & 1;
-                    ring[idx % 3] = tr_pair(p3 + (16 * hh) * WLDB + (32 * m) * 2,
-                                            p3 + (16 * hh + 8) * WLDB + (32 * m) * 2);
+                    ring[idx % 3] = tr_pair(p30 + (16 * hh) * WLDB + (32 * m) * 2,
+                                            p31 + (16 * hh) * WLDB + (32 * m) * 2);
                 }
             };
             fetch(0);
             fetch(1);
             float x[16], q[16];
             VTr::unpack(vcur[u], x);
+            // this tile's V is in x[] now: its registers take the same tile of the NEXT stage (one stage of
+            // latency to land; a separate set of "next" registers cost 16 VGPRs and pushed the kernel into scratch)
+            if (more) vcur[u] = VTr::load(vt + (int64_t)((sg + 1) * RS + u) * TB, lane);
             f32x16 d;
 #pragma unroll
             for (int e = 0; e < 16; ++e) d[e] = 0.f;
@@ -581,19 +597,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
         }
     };
     auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int sg) {
-        typename VTr::Regs vnext[RS];
         const bool more = sg + 1 < send;
-        if (more) {
-            stage_in(nxt, sg + 1);
-#pragma unroll
-            for (int u = 0; u < RS; ++u)
-                vnext[u] = VTr::load(vt + (int64_t)((sg + 1) * RS + u) * TB, lane);
-        }
-        compute(cur);
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < RS; ++u) vcur[u] = vnext[u];
-        }
+        if (more) stage_in(nxt, sg + 1);
+        compute(cur, more, sg);
         __syncthreads();
     };
 
@@ -668,7 +674,7 @@ __global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wl
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / kp, c = e % kp;
-        Wb[i * wld + c] = (__bf16)W32[e];
+        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (__bf16)W32[e];
     }
 }
 

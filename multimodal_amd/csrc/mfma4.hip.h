@@ -154,9 +154,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 
     bf16x8 wf[KS > 0 ? KS : 1];
     if (MODE != ROW_INIT) {
-        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD + 8 * h;
+        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + 16 * s);
+        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + wb_col(r, 16 * s + 8 * h));
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
                 bf16x4 wb;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[t];
-                *(bf16x4 *)(a.Wb_new + row * WLD + comp) = wb;
+                *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
             }
     }
 #ifdef KL_STAMPS

@@ -468,7 +468,7 @@ def test_matmul_reconstruction(dt, rtol):
     assert _native.matmul(np.zeros((3, 0)), np.zeros((0, 4))).tolist() == np.zeros((3, 4)).tolist()
     with pytest.raises(ValueError):
         _native.matmul(np.ones((2, 3)), np.ones((4, 2)))
-    lr = learner.MultimodalLearner(['a', 'b'], [3, 5], [2., .5], 4)
+    lr = MultimodalLearner(["a", "b"], [3, 5], [2., .5], 4)
     lr.dico = rs.random_sample((4, 8))
     internal = rs.random_sample((6, 4))
     assert_allclose(lr.reconstruct_modality('b', internal), internal.dot(lr.dico[:, 3:8]), rtol=1e-12)
