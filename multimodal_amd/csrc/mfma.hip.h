@@ -356,7 +356,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
                     q[e] = x[e] + d[e];
 #else
-                    const float qq = (x[e] + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
+                    const float rinv = __builtin_amdgcn_rcpf(d[e] + eps);
+                    const float qq = fmaf(x[e], rinv, eps * rinv);          // (x + eps) * r; same form as mfma4.hip.h
                     q[e] = qq;
                     s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
 #endif
@@ -586,7 +587,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                q[e] = (x[e] + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
+            {
+                // (x + eps) * r as x*r + eps*r: with fp16 V the compiler feeds x to v_fma_mix_f32 in its
+                // storage form and drops the conversion (VALU time adds to matrix time on the SIMD)
+                const float rinv = __builtin_amdgcn_rcpf(d[e] + eps);
+                q[e] = fmaf(x[e], rinv, eps * rinv);
+            }
             const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
 #pragma unroll
             for (int j = 0; j < N3; ++j) {

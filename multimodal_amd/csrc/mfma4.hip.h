@@ -225,6 +225,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         unsigned long long t0, t1, t3; KL_STAMP(t0);
 #endif
+#ifdef KL_PRIO_M
+        __builtin_amdgcn_s_setprio(KL_PRIO_M);
+#endif
         const unsigned ra = lds_addr(Hobj((ts + 3) % 4));
         const unsigned ta = lds_addr(Hobj(ts % 4));
         static_for<DP, D>([&](auto P) { issue(P, ra, ta); });      // the part of the lead the E segment could not issue
@@ -268,6 +271,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         unsigned long long t0, t1, t3; KL_STAMP(t0);
 #endif
+#ifdef KL_PRIO_E
+        __builtin_amdgcn_s_setprio(KL_PRIO_E);
+#endif
         // everything this wave has in flight lands here: V of this tile (issued one E segment ago) and its
         // slices of the dictionary copy issued one E segment ago (first read two or more intervals from now)
         f16x8 &va = vreg[2 * (ts & 1)], &vb = vreg[2 * (ts & 1) + 1];
@@ -293,7 +299,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
                 q[e] = x;
 #endif
             } else {
-                q[e] = (x + eps) * __builtin_amdgcn_rcpf(d[e] + eps);
+                // (x + eps) * r as x*r + eps*r: x is consumed in its fp16 storage form by v_fma_mix_f32 (here
+                // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
+                // adds to the matrix time of the SIMD, every instruction counts
+                const float rinv = __builtin_amdgcn_rcpf(d[e] + eps);
+                q[e] = fmaf(x, rinv, eps * rinv);
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
             }
         }
