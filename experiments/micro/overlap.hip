@@ -41,13 +41,15 @@ __device__ __forceinline__ void valu_block(float (&x)[16], float c) {
 }
 
 // mode bit0: MFMA waves active, bit1: VALU waves active; SAMEWAVE: every wave does both, interleaved
-template <int KIND, int SAMEWAVE, int NACC = 4>
+template <int KIND, int SAMEWAVE, int NACC = 4, int VARYOP = 0>
 __global__ __launch_bounds__(512, 2) void k(float *out, int iters, int mode, float seed) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     bf16x8 a, b;
     for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(seed + threadIdx.x * 0.001f + j); b[j] = (__bf16)(seed * 0.5f + j); }
-    f32x16 acc[4];
-    for (int m = 0; m < 4; ++m) for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    f32x16 acc[8];
+    for (int m = 0; m < 8; ++m) for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    bf16x8 av[14], bv[14];
+    for (int i = 0; i < 14; ++i) for (int j = 0; j < 8; ++j) { av[i][j] = (__bf16)(seed + i + j); bv[i][j] = (__bf16)(seed - i + j); }
     float x[16];
     for (int e = 0; e < 16; ++e) x[e] = seed + e + threadIdx.x;
     float r = 0.f;
@@ -69,25 +71,26 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters, int mode, flo
         if (mode & 1)
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j % NACC], 0, 0, 0);
+                for (int j = 0; j < (VARYOP ? 14 : 8); ++j)
+                    acc[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VARYOP ? av[j] : a, VARYOP ? bv[j] : b, acc[j % NACC], 0, 0, 0);
             }
     } else {
         if (mode & 2)
             for (int it = 0; it < iters; ++it) valu_block<KIND>(x, seed);
     }
-    for (int m = 0; m < 4; ++m) for (int e = 0; e < 16; ++e) r += acc[m][e];
+    for (int m = 0; m < 8; ++m) for (int e = 0; e < 16; ++e) r += acc[m][e];
     for (int e = 0; e < 16; ++e) r += x[e];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
-template <int KIND, int SAMEWAVE, int NACC = 4>
+template <int KIND, int SAMEWAVE, int NACC = 4, int VARYOP = 0>
 float run(int mode, int iters) {
     float *out; hipMalloc(&out, 256 * 512 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<KIND, SAMEWAVE, NACC><<<256, 512>>>(out, 10, mode, 1.5f);
+    k<KIND, SAMEWAVE, NACC, VARYOP><<<256, 512>>>(out, 10, mode, 1.5f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<KIND, SAMEWAVE, NACC><<<256, 512>>>(out, iters, mode, 1.5f);
+    k<KIND, SAMEWAVE, NACC, VARYOP><<<256, 512>>>(out, iters, mode, 1.5f);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipFree(out);
@@ -120,6 +123,9 @@ int main() {
         const float m1 = run<K_MIX, 0, 1>(1, it2), v1 = run<K_MIX, 0, 1>(2, it2), b1 = run<K_MIX, 0, 1>(3, it2);
         const float m2 = run<K_MIX, 0, 2>(1, it2), b2 = run<K_MIX, 0, 2>(3, it2);
         printf("dependent MFMA chain (1 accumulator): MFMA alone %.3f  VALU(mix) alone %.3f  both %.3f\n", m1, v1, b1);
+        const float m3 = run<K_MIX, 0, 7, 1>(1, it2), v3 = run<K_MIX, 0, 7, 1>(2, it2 * 14 / 8), b3 = run<K_MIX, 0, 7, 1>(3, it2);
+        printf("14 distinct A/B operand sets, 7 accumulators (14 MFMAs per iteration): MFMA alone %.3f  both %.3f (VALU alone for the same iterations %.3f)\n", m3, b3, run<K_MIX, 0, 7, 1>(2, it2));
+        (void)v3;
         printf("2 accumulators alternating:           MFMA alone %.3f  VALU(mix) alone %.3f  both %.3f\n", m2, v1, b2);
     }
     const int iters = 20000;

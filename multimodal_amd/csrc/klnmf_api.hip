@@ -191,8 +191,8 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
     const int odd = 2 * c->KT - c->ks;
 #define KL_ROW4_CASE(KTV)                                                                                       \
     case KTV:                                                                                                   \
-        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
-        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);       \
+        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE>), dim3(grid), dim3(kThreads4), 0, c->stream, a);  \
+        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
         break;
     switch (c->KT) {
         KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
@@ -247,10 +247,11 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     const bool v16 = c->prec == KLNMF_PREC_BF16;
     if (v16 && c->row_gen == 4 && c->KT <= 7) {        // KT = 8 would spill (scratch traffic breaks the counted vmcnt waits)                       // ping-pong schedule (mfma4.hip.h), fp16 V only
         RowPass4Args a4{a, c->Ht4};
+        const int grid4 = (c->nrt + kWaves4 - 1) / kWaves4;
         switch (mode) {
-            case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid); break;
-            case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid); break;
-            default: launch_rowpass4_kt<ROW_LOSS>(c, a4, grid); break;
+            case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
+            case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
+            default: launch_rowpass4_kt<ROW_LOSS>(c, a4, grid4); break;
         }
         if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
         return;

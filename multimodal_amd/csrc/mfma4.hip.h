@@ -44,6 +44,16 @@ __host__ __device__ constexpr int h4_elem(int a, int c) {       // element offse
     return a * kRow4 + ((((h_col_perm(c) >> 3) ^ ((a >> 2) & 3)) << 3) | (h_col_perm(c) & 7));
 }
 constexpr int kObj4 = 3 * kGldsRound;            // upper bound of one dictionary tile image (KP <= 256 -> 20480 B)
+// Workgroup shape of the ping-pong row pass.  8 waves: the two wave groups share every dictionary copy and one
+// barrier.  4 waves (one per SIMD, two workgroups per CU): each workgroup copies its own dictionary tiles (twice
+// the L2 -> LDS traffic per CU) but only four waves meet at a barrier and the two workgroups of a CU drift
+// freely against each other -- the matrix segment of one overlaps the epilogue of the other statistically.
+#ifndef KL_WG4_WAVES
+#define KL_WG4_WAVES 8
+#endif
+constexpr int kWaves4 = KL_WG4_WAVES;
+constexpr int kThreads4 = 64 * kWaves4;
+constexpr int kRound4 = kThreads4 * 16;          // bytes one global_load_lds round of the workgroup moves
 __host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
 // logical column (0..31) of a tile -> physical position (16-column groups stored 0,2,1,3 as in mfma.hip.h)
 __host__ __device__ constexpr int h4_col_perm(int c) { return h_col_perm(c); }
@@ -99,15 +109,15 @@ __device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned c
 // global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
 template <int BYTES>
 __device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LDS unsigned char *ldst, int tid) {
-    constexpr int FULL = BYTES / kGldsRound, REM = BYTES % kGldsRound;
+    constexpr int FULL = BYTES / kRound4, REM = BYTES % kRound4;
     const int wave_base = (tid & ~63) * 16;
 #pragma unroll
     for (int r = 0; r < FULL; ++r)
-        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kGldsRound + tid * 16),
-                                         (KL_LDS void *)(ldst + r * kGldsRound + wave_base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kRound4 + tid * 16),
+                                         (KL_LDS void *)(ldst + r * kRound4 + wave_base), 16, 0, 0);
     if (REM > 0 && tid * 16 < REM)
-        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + FULL * kGldsRound + tid * 16),
-                                         (KL_LDS void *)(ldst + FULL * kGldsRound + wave_base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + FULL * kRound4 + tid * 16),
+                                         (KL_LDS void *)(ldst + FULL * kRound4 + wave_base), 16, 0, 0);
 }
 template <int N>
 __device__ __forceinline__ void lds_wait(bf16x8 &v) {
@@ -115,7 +125,7 @@ __device__ __forceinline__ void lds_wait(bf16x8 &v) {
 }
 
 template <int KT, int ODD, int MODE>
-__global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
+__global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
     const RowPassArgs &a = aa.base;
     constexpr int KP = 32 * KT;
     constexpr int KS = 2 * KT - ODD;
@@ -139,8 +149,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const bool grpY = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;     // wave-uniform (SGPR)
-    const int rt_raw = blockIdx.x * kWavesPerWG + wave;
+    const bool grpY = kWaves4 == 8 && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;     // wave-uniform (SGPR)
+    const int rt_raw = blockIdx.x * kWaves4 + wave;
     const bool active = rt_raw < a.nrt;
     const int rt = active ? rt_raw : a.nrt - 1;
 
@@ -284,7 +294,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
 #ifdef KL_STAMPS
         { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
 #endif
+#ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
+        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)((tg + 1) & 3) * TB);
+#else
         v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)min(tg + 1, a.nct - 1) * TB);
+#endif
         if (grpY) dma((ts + 3) % 4, tg + 3);
         else dma((ts + 2) % 4, tg + 2);
         float q[16];
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass4(RowPass4Args aa) {
     v_tile_load(vreg[0], vreg[1], vlane);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int e = tid; e < IMG / 16; e += kThreads) ((KL_LDS u32x4 *)h3)[e] = z;
+        for (int e = tid; e < IMG / 16; e += kThreads4) ((KL_LDS u32x4 *)h3)[e] = z;
         if (MODE != ROW_INIT && tid < KP) hsum_lds[tid] = a.hsum[tid];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
