@@ -106,6 +106,7 @@ struct klnmf_ctx {
     float *H32 = nullptr;
     __bf16 *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
     int row_gen = 4;
+    int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
     float *hsum = nullptr;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     float *NpartF = nullptr, *numerF = nullptr;
@@ -189,10 +190,16 @@ void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
 template <int MODE>
 void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
     const int odd = 2 * c->KT - c->ks;
+    const bool ep = c->kc >= 0;
 #define KL_ROW4_CASE(KTV)                                                                                       \
     case KTV:                                                                                                   \
-        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE>), dim3(grid), dim3(kThreads4), 0, c->stream, a);  \
-        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
+        if (ep) {                                                                                               \
+            if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1>), dim3(grid), dim3(kThreads4), 0, c->stream, a);  \
+            else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
+        } else {                                                                                                \
+            if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0>), dim3(grid), dim3(kThreads4), 0, c->stream, a);  \
+            else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
+        }                                                                                                       \
         break;
     switch (c->KT) {
         KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
@@ -205,7 +212,8 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
 
 template <int KT, int ODD, typename VT>
 void launch_colpass_one(klnmf_ctx *c, const ColPassArgs &a, int grid) {
-    hipLaunchKernelGGL((k_colpass<KT, ODD, VT>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+    if (c->kc >= 0) hipLaunchKernelGGL((k_colpass<KT, ODD, VT, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_colpass<KT, ODD, VT, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 
 template <typename VT>
@@ -236,6 +244,7 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     a.loss_part = c->loss_part2;
     a.hsum = c->hsum;
     a.stamps = c->stamps;
+    a.kc = c->kc;
     a.st = c->st;
     a.nrt = c->nrt;
     a.nct = c->nct;
@@ -301,7 +310,8 @@ void fast_colpass(klnmf_ctx *c) {
 void fast_pack_H(klnmf_ctx *c, int do_update) {
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
                        (const float *)c->numerF, c->Ht, c->Ht4, c->HTb, c->hsum, c->f, c->f_pad, c->KP, do_update,
-                       do_update ? (const DevState *)c->st : (const DevState *)nullptr);
+                       do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
+                       (float)(kEpsRatio * c->v_scale));
     HIPCHK(hipGetLastError());
 }
 
@@ -715,6 +725,10 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->Ht4 = (__bf16 *)c->dalloc((size_t)c->nct * h4_tile_bytes(c->KP) + kObj4);
             c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
             if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
+            // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
+            // carrier column at 1) and a spare component inside the MFMA-1 contraction range
+            c->kc = (c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && c->KT <= 7 && (k % 16) != 0 &&
+                     !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
             c->hsum = (float *)c->dalloc((size_t)c->KP * 4);
 #ifdef KL_STAMPS
             c->stamps = (unsigned long long *)c->dalloc((size_t)c->nrt * 8 * 8);
@@ -751,6 +765,7 @@ int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
         int e = 0;
         (void)std::frexp(vmax, &e);             // vmax = m * 2^e, m in [0.5, 1)
         c->v_scale = std::ldexp(1.0, 15 - e);   // c * vmax in [2^14, 2^15)
+        if (c->kc >= 0) fast_pack_H(c, 0);      // the eps row of the dictionary images is in scaled units
     });
 }
 
@@ -813,9 +828,10 @@ int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
         if (!src) fail(KLNMF_ERR_ARG, "null source");
         set_matrix(c, src, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP, c->v_scale);
         if (!c->is_exact()) {
-            hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n * c->KP, 256, 8192)), dim3(256), 0,
-                               c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n, c->KP,
-                               w_ld(c->KP));
+            // all padded rows too: the eps-carrying pad column must be 1 in every row a tile can contain
+            hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n_pad * c->KP, 256, 8192)), dim3(256), 0,
+                               c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n_pad, c->KP,
+                               w_ld(c->KP), c->kc);
             HIPCHK(hipGetLastError());
         }
     });

@@ -217,6 +217,7 @@ struct RowPassArgs {
     float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
     const float *hsum;        // [KP] row sums of the bf16-rounded dictionary (for sum(W.H))
     unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
+    int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
     float eps;                // c * 1e-8 (scaled units)
@@ -485,7 +486,7 @@ struct ColPassArgs {
     float eps;
 };
 
-template <int KT, int ODD, typename VT>
+template <int KT, int ODD, typename VT, int EP = 0>
 __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     constexpr int KP = 32 * KT;
     constexpr int KS = 2 * KT - ODD;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
             {
                 // (x + eps) * r as x*r + eps*r: with fp16 V the compiler feeds x to v_fma_mix_f32 in its
                 // storage form and drops the conversion (VALU time adds to matrix time on the SIMD)
-                const float rinv = __builtin_amdgcn_rcpf(d[e] + eps);
+                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps is already in d (pad component)
                 q[e] = fmaf(x[e], rinv, eps * rinv);
             }
             const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
@@ -639,11 +640,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 // One block per component row.  do_update: H <- H*num then row-normalise
 // (nmf.py:349-350); always (re)writes the bf16 stage images Ht and the transposed
 // copy HTb from the fp32 master.
+//
+// Pad-component eps (kc >= 0): the ratio needs 1/(W.H + eps) for every element.  Instead of one VALU add
+// per element in both passes, the otherwise unused component kc (k <= kc < 16*KS) carries it through the
+// matrix product: row kc of the dictionary images holds eps in every column, column kc of the bf16 W
+// images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
+// loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
 __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
                                                        __bf16 *Ht4, __bf16 *HTb, float *hsum, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
-                                                       const DevState *st) {
+                                                       const DevState *st, int kc, float eps_pad) {
     if (st && st->stop) return;
+    if (kc >= 0 && blockIdx.x == 0) {
+        const __bf16 ev = (__bf16)eps_pad;
+        for (int64_t j = threadIdx.x; j < f_pad; j += blockDim.x) {
+            if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(kc, (int)(j % 32))] = ev;
+            HTb[j * kp + kc] = ev;
+        }
+    }
     __shared__ double red[16];
     __shared__ double total;
     const int a = blockIdx.x;
@@ -675,12 +689,12 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     if (threadIdx.x == 0) hsum[a] = (float)ths;
 }
 
-__global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wld) {
+__global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wld, int kc) {
     const int64_t total = n * kp;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / kp, c = e % kp;
-        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (__bf16)W32[e];
+        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (c == kc) ? (__bf16)1.f : (__bf16)W32[e];
     }
 }
 

@@ -124,7 +124,7 @@ __device__ __forceinline__ void lds_wait(bf16x8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
-template <int KT, int ODD, int MODE>
+template <int KT, int ODD, int MODE, int EP = 0>
 __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
     const RowPassArgs &a = aa.base;
     constexpr int KP = 32 * KT;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
                 // (x + eps) * r as x*r + eps*r: x is consumed in its fp16 storage form by v_fma_mix_f32 (here
                 // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
                 // adds to the matrix time of the SIMD, every instruction counts
-                const float rinv = __builtin_amdgcn_rcpf(d[e] + eps);
+                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps came in through MFMA-1
                 q[e] = fmaf(x, rinv, eps * rinv);
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
             }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
                 *(f32x4 *)(a.W32_new + row * KP + comp) = w;
                 bf16x4 wb;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[t];
+                for (int t = 0; t < 4; ++t) wb[t] = (EP && comp + t == a.kc) ? (__bf16)1.f : (__bf16)w[t];   // eps carrier
                 *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
             }
     }
