@@ -1,0 +1,134 @@
+"""KL-NMF results against the numpy reference within the stated tolerances, one test per
+configuration of BASELINE.json (`configs[0..4]`; the north star names this file).
+
+Tolerances, as stated in BASELINE.json / SURVEY.md section 8c:
+  * f64 mode = the reference's own arithmetic: 1e-9 relative on W, H and every recorded loss;
+  * bf16 MFMA mode: final KL loss within 1e-4 relative of the CPU reference.
+The CPU reference is `oracle/klnmf_oracle.py`, pinned to outputs of the imported reference
+(tests/golden/, tests/test_oracle_golden.py).  Full-size runs of configs 4 and 5 are the
+benchmark's job (bench.py); here their shapes are exercised at reduced row counts.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import klnmf_oracle as orc
+from tests import golden_inputs as gi
+from multimodal_amd import _native
+from multimodal_amd.lib import nmf
+from multimodal_amd.learner import MultimodalLearner
+import multimodal_amd.learner as L
+
+KL_TOL = 1e-4          # north star: final KL within 1e-4 relative of the CPU reference
+
+
+def _fit(X, H0, k, iters, precision):
+    m = nmf.KLdivNMF(n_components=k, max_iter=iters, tol=0, precision=precision)
+    m._init_dictionary = H0
+    with contextlib.redirect_stderr(io.StringIO()):
+        W, errors = m.fit_transform(X, return_errors=True)
+    return m, W, np.asarray(errors)
+
+
+# ---- config 0: 500 x 1000, k = 10, 50 iterations (numpy CPU path; plumbing, no GPU) ----------
+def test_config0_cpu_reference_path():
+    g = gi.load('g1_500x1000_k10')
+    X, H0 = gi.gen_inputs(int(g['seed']), 500, 1000, 10)
+    W, H, errors = orc.fit_transform(X, k=10, H0=H0, max_iter=50, tol=0)
+    assert_allclose(errors, g['errors_50'], rtol=1e-10)         # the imported reference's own losses
+    assert_allclose(orc.kl_error(X, W, H), float(g['final_50']), rtol=1e-10)
+    assert np.all(np.diff(errors) < 0)
+
+
+@pytest.mark.gpu
+def test_config0_gpu_f64_and_bf16():
+    g = gi.load('g1_500x1000_k10')
+    X, H0 = gi.gen_inputs(int(g['seed']), 500, 1000, 10)
+    m, W, errors = _fit(X, H0, 10, 50, 'f64')
+    assert_allclose(errors, g['errors_50'], rtol=1e-9)
+    assert_allclose(W, g['W_50'], rtol=1e-7, atol=1e-12)
+    assert_allclose(m.components_, g['H_50'], rtol=1e-7, atol=1e-14)
+    mb, Wb, eb = _fit(X, H0, 10, 50, 'bf16')
+    final_b = nmf.KLdivNMF(n_components=10, precision='f64').error(X, Wb, H=mb.components_)
+    assert abs(final_b - float(g['final_50'])) <= 5 * KL_TOL * float(g['final_50'])   # 50 iterations of bf16 drift
+    assert abs(mb.error(X, Wb) - final_b) <= KL_TOL * final_b                         # reported = true loss of its model
+
+
+# ---- config 1: single modality 50k x 4096, k = 50 (rows reduced to 4096 for the oracle) -------
+@pytest.mark.gpu
+def test_config1_shape_bf16_final_kl():
+    n, f, k, iters = 4096, 4096, 50, 8
+    X = orc.synthetic_V(21, n, f, k)
+    H0 = orc.synthetic_H0(21, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    m, W, e = _fit(X, H0, k, iters, 'bf16')
+    assert_allclose(e, eo, rtol=1e-3)
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(m.error(X, W) - fo) <= KL_TOL * fo
+
+
+# ---- config 2: two modalities stacked (4096 + 2048 columns), k = 200, per-modality slices ------
+@pytest.mark.gpu
+def test_config2_two_modality_stack_bf16(monkeypatch):
+    n, dims, k, iters = 2048, [4096, 2048], 200, 4
+    coefs = [1.0, 0.5]
+    blocks = [orc.synthetic_V(31 + i, n, d, 24) for i, d in enumerate(dims)]
+    H0 = orc.synthetic_H0(31, sum(dims), k)
+    dico_o, W_o = orc.learner_train(blocks, coefs, k, iters, H0)
+    monkeypatch.setenv('KLNMF_PRECISION', 'bf16')
+    orig = L.NMF
+
+    def factory(**kw):
+        mm = orig(**kw)
+        mm._init_dictionary = H0.copy()
+        return mm
+    monkeypatch.setattr(L, 'NMF', factory)
+    lr = MultimodalLearner(['motion', 'sound'], dims, coefs, k)
+    lr.train(blocks, iters)
+    assert lr.dico.shape == (k, sum(dims))
+    assert lr.get_dico('motion').shape == (k, 4096) and lr.get_dico('sound').shape == (k, 2048)
+    V = orc.stack_modalities(blocks, coefs)
+    fo = orc.kl_error(V, W_o, dico_o)
+    # true fp64 loss of the GPU dictionary with the oracle's transform of it: the dictionary itself is what train() returns
+    Wg = orc.fit_transform(V, k=k, H0=H0, max_iter=iters, tol=0, fit=False, components=lr.dico, warn=False)[0]
+    fg = orc.kl_error(V, Wg, lr.dico)
+    assert abs(fg - fo) <= 50 * KL_TOL * fo          # different W (transform from V.H^T), same dictionary quality
+    assert np.abs(lr.dico - dico_o).max() <= 3e-2 * np.abs(dico_o).max()
+    assert_allclose(lr.dico.sum(axis=1), 1.0, rtol=1e-5)
+
+
+# ---- config 3: 1M x 4096, k = 200 (8192 rows here; the full shape is bench.py's workload) ------
+@pytest.mark.gpu
+def test_config3_shape_bf16_final_kl():
+    n, f, k, iters = 8192, 4096, 200, 3
+    X = orc.synthetic_V(1234, n, f, k)
+    H0 = orc.synthetic_H0(1234, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    m, W, e = _fit(X, H0, k, iters, 'bf16')
+    assert_allclose(e, eo, rtol=1e-3)
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(m.error(X, W) - fo) <= KL_TOL * fo
+    true_g = nmf.KLdivNMF(n_components=k, precision='f64').error(X, W, H=m.components_)
+    assert abs(true_g - fo) <= KL_TOL * fo
+
+
+# ---- config 4: three modalities, k = 500 (fp32 accumulate) ------------------------------------
+@pytest.mark.gpu
+def test_config4_k500_three_modalities():
+    """k = 500 exceeds the 256 components the bf16 MFMA kernels hold in registers: the bf16 mode
+    refuses (no silent change of arithmetic), the fp32 mode runs the same loop on the exact kernels."""
+    n, dims, k, iters = 256, [192, 128, 64], 500, 3
+    blocks = [orc.synthetic_V(41 + i, n, d, 16) for i, d in enumerate(dims)]
+    V = orc.stack_modalities(blocks, [1.0, 1.0, 1.0])
+    H0 = orc.synthetic_H0(41, sum(dims), k)
+    with pytest.raises(_native.NativeError) as ei:
+        _fit(V, H0, k, iters, 'bf16')
+    assert 'k > 256' in str(ei.value)
+    Wo, Ho, eo = orc.fit_transform(V, k=k, H0=H0, max_iter=iters, tol=0)
+    m, W, e = _fit(V.astype(np.float32), H0, k, iters, 'f32')
+    assert_allclose(e, eo, rtol=2e-4)
+    fo = orc.kl_error(V, Wo, Ho)
+    assert abs(m.error(V, W) - fo) <= 5 * KL_TOL * fo
