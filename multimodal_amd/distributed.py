@@ -117,12 +117,19 @@ class ShardedKLNMF(object):
         """Enqueue one iteration (no host synchronisation)."""
         tol_abs = tol * self.n_total * self.f          # nmf.py:207 on the GLOBAL shape
         self.ctx.iter_rowpass(fit)
-        self._all_reduce(self.loss_t)
-        self.ctx.iter_decide(tol_abs)
         if fit:
+            # The column pass does not depend on the stop decision (it needs W_new and the old ratio only), so
+            # it runs before the exchange and both all-reduces go out back to back: the GPUs do not idle
+            # between the two passes waiting for a 16-byte collective.  If the stop rule fires, this
+            # iteration's numerator is simply not applied (iter_update_H is a no-op once stopped).
             self.ctx.iter_colpass()
+            self._all_reduce(self.loss_t)
             self._all_reduce(self.numer_t)
+            self.ctx.iter_decide(tol_abs)
             self.ctx.iter_update_H()
+        else:
+            self._all_reduce(self.loss_t)
+            self.ctx.iter_decide(tol_abs)
         self.ctx.iter_advance()
         self.iterations_enqueued += 1
 
