@@ -38,6 +38,28 @@ __global__ __launch_bounds__(512, 2) void k(float *out, unsigned long long *cyc,
     for (int i = tid; i < 224 * RB / 4; i += 512) ((LDS float *)img)[i] = 0.001f * (i & 255);
     __syncthreads();
     if (wave >= nwaves) {
+        if (FEAT & 32) {
+            float x[16];
+            for (int e = 0; e < 16; ++e) x[e] = seed + e + tid;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int rep = 0; rep < 7; ++rep)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (rep == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[e]) : "v"(seed));
+                        if (rep == 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[e]));
+                        if (rep == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[e]) : "v"(seed));
+                        if (rep == 3) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[e]) : "v"(seed));
+                        if (rep == 4) asm volatile("v_log_f32 %0, %0" : "+v"(x[e]));
+                        if (rep == 5) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[e]) : "v"(seed));
+                        if (rep == 6 && (e & 1)) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[e]) : "v"(seed));
+                    }
+                if (FEAT & 1) asm volatile("s_barrier" ::: "memory");
+            }
+            float rr = 0; for (int e = 0; e < 16; ++e) rr += x[e];
+            out[blockIdx.x * 512 + tid] = rr;
+            return;
+        }
         if (FEAT & 1) for (int it = 0; it < iters; ++it) asm volatile("s_barrier" ::: "memory");
         return;
     }
@@ -156,6 +178,10 @@ int main() {
     run<0, 8, 80, 10>("mix + DMA 3 L2 + 2 HBM", 4);
     run<1, 6, 80, 10>("27 b128 + DMA 3L2+2HBM", 4);
     run<2, 6, 80, 10>("27 tr + DMA 3L2+2HBM", 4);
+    run<3, 3, 80, 32>("regs MFMA + partner VALU epilogue", 4);
+    run<0, 3, 80, 32>("LDS-fed MFMA + partner VALU epilogue", 4);
+    run<0, 3, 80, 33>("LDS-fed MFMA + partner VALU + barrier", 4);
+    run<0, 3, 80, 42>("LDS-fed + partner VALU + DMA(3 L2+2 HBM)", 4);
     run<0, 5, 144>("14 b128 + 13 tr", 4);
     run<1, 6, 144>("27 b128", 4);
     run<2, 6, 144>("27 tr pairs", 4);
