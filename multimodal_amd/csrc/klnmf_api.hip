@@ -737,7 +737,9 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
             c->ncb = (c->nct_used + kWavesPerWG - 1) / kWavesPerWG;
             int nch = 8;
-            while ((int64_t)nch * c->ncb < 2LL * c->cu_count && nch * 2 <= total_stages) nch += 8;
+            int64_t wg_per_cu = 1;       // workgroups per CU the decomposition aims at (one is resident per CU; 2 measured 1-3 % slower)
+            if (const char *g = std::getenv("KLNMF_COL_WG_PER_CU")) wg_per_cu = std::max(1, std::atoi(g));
+            while ((int64_t)nch * c->ncb < wg_per_cu * c->cu_count && nch * 2 <= total_stages) nch += 8;
             while (nch > 8 && ((int64_t)nch * c->ncb) % c->cu_count != 0 &&
                    (int64_t)(nch - 8) * c->ncb >= c->cu_count) nch -= 8;
             if (nch > total_stages) nch = total_stages > 0 ? ((total_stages + 7) / 8) * 8 : 8;

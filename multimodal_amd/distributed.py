@@ -77,6 +77,14 @@ class ShardedKLNMF(object):
                                    device=self.tensor_device)
         self.loss_t = torch.zeros(2, dtype=torch.float64, device=self.tensor_device)
         self.ctx.bind_exchange(self.loss_t.data_ptr(), self.numer_t.data_ptr())
+        # only the k real component rows travel: the MFMA modes lay the numerator out as [KP][f_pad] with
+        # KP = k rounded up to 32, and the rows beyond k are padding (one of them carries eps)
+        valid = count
+        if str(precision).startswith('bf16') and count > 0:
+            kp = 32 * ((k + 31) // 32)
+            if count % kp == 0:
+                valid = k * (count // kp)
+        self.numer_xchg = self.numer_t[:valid]
         self.iterations_enqueued = 0
 
     # ---- data ----
@@ -124,7 +132,7 @@ class ShardedKLNMF(object):
             # iteration's numerator is simply not applied (iter_update_H is a no-op once stopped).
             self.ctx.iter_colpass()
             self._all_reduce(self.loss_t)
-            self._all_reduce(self.numer_t)
+            self._all_reduce(self.numer_xchg)
             self.ctx.iter_decide(tol_abs)
             self.ctx.iter_update_H()
         else:
