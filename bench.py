@@ -58,25 +58,27 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192):
     dev = torch.device('cuda', torch.cuda.current_device())
     g = torch.Generator(device=dev)
     g.manual_seed(seed)                       # Ht identical on every rank
-    Ht = torch._standard_gamma(torch.full((k, f), 0.5, device=dev), generator=g)
+    # Gamma(1/2) = N(0,1)^2 / 2 and Gamma(1) = -log(U): built from randn / rand only, whose streams are reproduced
+    # exactly by restoring the generator state (torch._standard_gamma's rejection sampler is not: a second pass
+    # produced different values, the maximum of the first pass was exceeded and fp16 storage overflowed)
+    Ht = torch.randn((k, f), device=dev, generator=g).square_().mul_(0.5)
     g.manual_seed(seed + 1000 * (rank + 1))
+
+    def block_of(rows):
+        Wt = torch.rand((rows, k), device=dev, generator=g).neg_().add_(1.0).log_().neg_()     # Exp(1)
+        Vb = torch.rand((rows, f), device=dev, generator=g).mul_(0.05)
+        Vb.addmm_(Wt, Ht, alpha=1.0 / k)
+        return Vb
     # the 16-bit storage factor needs the global max before the first upload:
     # generate once for the max, then regenerate the identical stream for the upload
     state = g.get_state()
     vmax = 0.0
     for r0 in range(0, n_local, block):
-        rows = min(block, n_local - r0)
-        Wt = torch._standard_gamma(torch.ones((rows, k), device=dev), generator=g)
-        Vb = torch.rand((rows, f), device=dev, generator=g).mul_(0.05)
-        Vb.addmm_(Wt, Ht, alpha=1.0 / k)
-        vmax = max(vmax, float(Vb.max().item()))
+        vmax = max(vmax, float(block_of(min(block, n_local - r0)).max().item()))
     model.set_v_max(vmax)
     g.set_state(state)
     for r0 in range(0, n_local, block):
-        rows = min(block, n_local - r0)
-        Wt = torch._standard_gamma(torch.ones((rows, k), device=dev), generator=g)
-        Vb = torch.rand((rows, f), device=dev, generator=g).mul_(0.05)
-        Vb.addmm_(Wt, Ht, alpha=1.0 / k)
+        Vb = block_of(min(block, n_local - r0))
         model.upload_V_device(Vb.contiguous(), row0=r0, col0=0, scale=1.0)
     torch.cuda.synchronize()
 

@@ -55,9 +55,12 @@ int         klnmf_device_info(int device, char *arch, int arch_len,
                               int *cu_count, uint64_t *hbm_bytes);
 
 /* ---- context ----------------------------------------------------------- */
-/* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for an
- * own stream.  Replaces constructing KLdivNMF (nmf.py:136-145) + the implicit
+/* stream: a hipStream_t to run on (e.g. torch's current stream), NULL for an own (non-blocking)
+ * stream, or KLNMF_STREAM_DEFAULT for the device's default (null) stream -- whose handle is 0 and
+ * could not be told from "no stream" otherwise; it is what torch reports as its current stream unless
+ * the caller switched streams, and collectives issued through torch are ordered against it.  Replaces constructing KLdivNMF (nmf.py:136-145) + the implicit
  * "everything lives in host numpy arrays" of the reference. */
+#define KLNMF_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int klnmf_create(klnmf_ctx **out, int device, int precision, void *stream);
 int klnmf_destroy(klnmf_ctx *ctx);
 

@@ -17,6 +17,7 @@ PRECISIONS = {'f64': PREC_F64, 'fp64': PREC_F64, 'float64': PREC_F64,
               'f32': PREC_F32, 'fp32': PREC_F32, 'float32': PREC_F32,
               'bf16': PREC_BF16, 'bf16_v32': PREC_BF16_V32}
 DT_F32, DT_F64 = 0, 1
+STREAM_DEFAULT = (1 << 64) - 1        # KLNMF_STREAM_DEFAULT: (void *)(intptr_t)-1
 
 ERR_ARG, ERR_ALLOC, ERR_HIP, ERR_UNSUPP = -1, -2, -3, -4
 
@@ -175,8 +176,16 @@ class Context(object):
         if isinstance(precision, str):
             precision = PRECISIONS[precision]
         self.precision = precision
-        _check(self._lib.klnmf_create(ctypes.byref(self._h), device, precision,
-                                      _c.c_void_p(stream) if stream else None))
+        # stream: None -> the context creates its own stream; an integer hipStream_t handle otherwise, where
+        # 0 is the device's default (null) stream -- torch's current stream unless the caller switched --
+        # and is passed as KLNMF_STREAM_DEFAULT, because the C-ABI reads NULL as "no stream given".
+        if stream is None:
+            handle = None
+        elif int(stream) == 0:
+            handle = _c.c_void_p(STREAM_DEFAULT)
+        else:
+            handle = _c.c_void_p(int(stream))
+        _check(self._lib.klnmf_create(ctypes.byref(self._h), device, precision, handle))
         self.n = self.f = self.k = 0
         self.cap = 0
 

@@ -21,7 +21,8 @@ struct DevState {
     double corr_c;     // storage-rounding correction of the loss (0 when V is stored exactly)
     int stop;          // stop rule fired (the `break` of nmf.py:216)
     int n_done;        // updates executed == len(errors)
-    int pad0, pad1;
+    int v_overflow;    // uploaded values that exceeded the fp16 range announced with klnmf_set_v_max (saturated)
+    int pad1;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -616,7 +616,9 @@ int klnmf_create(klnmf_ctx **out, int device, int precision, void *stream) {
         c->device = device;
         c->prec = precision;
         c->cu_count = p.multiProcessorCount;
-        if (stream) {
+        if (stream == KLNMF_STREAM_DEFAULT) {
+            c->stream = nullptr;                    // the default (null) stream
+        } else if (stream) {
             c->stream = (hipStream_t)stream;
         } else {
             hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -858,9 +860,22 @@ int klnmf_init_W(klnmf_ctx *c) {
     });
 }
 
+// fp16 storage: values above the maximum announced with klnmf_set_v_max were saturated on upload; a fit on such
+// a matrix is not the fit of the caller's data, so the loop entry points refuse it (one 4-byte read per loop).
+static void check_v_overflow(klnmf_ctx *c) {
+    if (c->prec != KLNMF_PREC_BF16 || !c->v_uploaded) return;
+    int ov = 0;
+    HIPCHK(hipMemcpyAsync(&ov, &c->st->v_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ov != 0)
+        fail(KLNMF_ERR_ARG, "uploaded V exceeds the maximum given to klnmf_set_v_max (" + std::to_string(ov) +
+                                " values out of the fp16 storage range)");
+}
+
 int klnmf_loop_begin(klnmf_ctx *c) {
     return guarded([&] {
         need_problem(c);
+        check_v_overflow(c);
         reset_state(c);
         c->loop_start_cur = c->cur;
         c->loop_iters = 0;
@@ -919,6 +934,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         need_problem(c);
         if (max_iter < 0) fail(KLNMF_ERR_ARG, "max_iter < 0");
         if (max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter exceeds the capacity given to klnmf_set_problem");
+        check_v_overflow(c);
         reset_state(c);
         c->loop_start_cur = c->cur;
         for (int64_t it = 0; it < max_iter; ++it) {

@@ -742,7 +742,11 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ii = e / cols, jj = e % cols;
         const double xv = scale * (double)src[ii * ld + jj];   // scale includes the storage factor c
-        const VT xs = (VT)xv;
+        VT xs = (VT)xv;
+        if (sizeof(VT) == 2 && !(xv <= 65504.0)) {             // beyond the maximum given to klnmf_set_v_max: saturate
+            xs = (VT)65504.f;                                  // (never inf in the matrix) and report at the next loop
+            atomicAdd(&st->v_overflow, 1);
+        }
         const double xt = (double)xs;
         const int64_t row = row0 + ii, col = col0 + jj;
         const int64_t rt = row >> 5, ctile = col >> 5;

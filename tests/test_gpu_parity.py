@@ -480,3 +480,32 @@ def test_matmul_reconstruction(dt, rtol):
     assert_allclose(lr.reconstruct_modality('b', internal), internal.dot(lr.dico[:, 3:8]), rtol=1e-12)
     assert_allclose(lr.reconstruct_modalities(['b', 'a'], internal),
                     internal.dot(np.hstack([lr.dico[:, 3:8], lr.dico[:, :3]])), rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_context_on_torch_default_stream_is_ordered_with_torch():
+    """torch's default stream has handle 0.  A context given that handle must run ON it (KLNMF_STREAM_DEFAULT),
+    not on an own stream: otherwise uploads race with the producer of the data and, with several GPUs, the
+    all-reduces torch issues are not ordered against the kernels.  (Found by the benchmark: blocks generated by
+    torch were overwritten before the unordered upload kernel had read them.)"""
+    torch = pytest.importorskip('torch')
+    n, f, k = 8192, 1024, 40
+    X = orc.synthetic_V(3, n, f, k)
+    H0 = orc.synthetic_H0(3, f, k)
+    dev = torch.device('cuda', 0)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0
+    c = _native.Context('bf16', device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    c.set_problem(n, f, k, 3)
+    c.set_v_max(float(X.max()))
+    for r0 in range(0, n, 1024):                       # every block through the SAME device buffer, no host sync
+        if r0 == 0:
+            buf = torch.empty((1024, f), dtype=torch.float32, device=dev)
+        buf.copy_(torch.from_numpy(X[r0:r0 + 1024].astype(np.float32)), non_blocking=False)
+        c.upload_V_device(buf.data_ptr(), 1024, f, f, r0, 0, 1.0)
+        buf.fill_(1.0e9)                               # would poison an upload that is not stream-ordered
+    c.set_H(H0)
+    c.init_W()
+    errs, n_done, stopped = c.run(3, True, 0.0)
+    _, _, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=3, tol=0)
+    assert_allclose(errs, eo, rtol=1e-3)
+    c.close()
