@@ -1,28 +1,26 @@
-// Row pass, ping-pong schedule (generation 4).
+// Row pass, ping-pong schedule (generation 4): loss + ratio + W rule in one stream over V.
 //
-// Measured on generation 1 (mfma.hip.h; profiles/r01_*, in-kernel stamps): per
-// 32x32 tile a wave spends 827 cycles in MFMA-1 (416 of matrix-pipe work), 974 in
-// the ratio/log epilogue and 762 in MFMA-2 (448) -- per SIMD the time is the SUM of
-// the MFMA time and the VALU time of its two waves: nothing overlaps, because both
-// partners run the same barrier-synchronised phases at the same time.
+// A wave owns 32 sample rows (its bf16 W fragments stay in registers) and walks the 32-column tiles of the
+// dictionary, which stream through 4 rotating LDS objects.  Per tile t its work splits into
+//   M(t) = MFMA-2 of tile t-1 (G^T += H_tile . Q_tile^T, 2*KT MFMAs) + MFMA-1 of tile t (W.H, KS MFMAs)
+//   E(t) = the VALU epilogue of tile t: ratio, loss terms, bf16 Q operands for the next M segment.
+// The two wave groups of the workgroup (waves 0-3 = X, 4-7 = Y; wave w and w+4 share a SIMD,
+// experiments/micro/simd_map.hip) run half a tile apart, with ONE s_barrier per tile:
 //
-// Here the two wave groups of the workgroup (waves 0-3 = X, waves 4-7 = Y; wave w
-// and w+4 share a SIMD) alternate ROLES per barrier interval, the scheme the CDNA
-// guide describes for tuned 8-wave kernels:
+//   barrier interval      I_0          I_1          I_2
+//   X                 M(0) E(0)  |  M(1) E(1)  |  M(2) E(2)  | ...
+//   Y                E(-1) M(0)  |  E(0) M(1)  |  E(1) M(2)  | ...        (Y's E(-1) only issues a copy)
 //
-//   interval   0      1      2      3      4
-//   X         M(0)   E(0)   M(1)   E(1)   M(2)  ...      M(t) = MFMA-2(t-1) + MFMA-1(t)   (27 MFMAs)
-//   Y          -     M(0)   E(0)   M(1)   E(1)  ...      E(t) = ratio / log epilogue of tile t (VALU)
-//
-// Every interval ends with one s_barrier for all 8 waves, so on each SIMD exactly
-// one wave owns the matrix pipe while its partner owns the VALU.  Both groups run
-// the same code; Y is shifted by one interval (one extra barrier up front).
-//
-// Stages are single 32-column tiles: dictionary image [KP][32+8] (80-byte rows) and
-// the 8 waves' V tiles, in 4 rotating pairs of DISTINCT LDS objects (static indices:
-// the loop body covers 4 tiles), filled by global_load_lds two tiles ahead; each
-// wave waits for its own copies with a counted vmcnt (the younger stage stays in
-// flight) before the barrier that precedes the first read.
+// so on every SIMD one wave is in its matrix segment while its partner is in its VALU segment.
+//   * dictionary tile t+2 is copied by global_load_lds in exactly its size, each thread its slices, issued
+//     from the E segments (X: tile t+2 in E(t); Y: tile t+3 in its E(t), i.e. the same interval);
+//   * V tiles go straight to registers, one tile ahead (ordinary loads);
+//   * `s_waitcnt vmcnt(0)` at the start of every E segment covers both: the slices issued one E segment ago
+//     have landed before the barrier that precedes their first read (two intervals later for X);
+//   * all LDS operand reads are inline asm with counted lgkmcnt waits (see lds_read_b128 below);
+//   * tile images are unpadded and XOR-swizzled (h4_elem): no bank conflicts for either read pattern.
+// What was measured on the way (two barriers per tile, V through LDS, deeper prefetch, 4-wave workgroups,
+// LDS semaphores instead of the barrier, copies through registers) is in experiments/README.md.
 #pragma once
 #include <type_traits>
 
@@ -55,8 +53,6 @@ constexpr int kWaves4 = KL_WG4_WAVES;
 constexpr int kThreads4 = 64 * kWaves4;
 constexpr int kRound4 = kThreads4 * 16;          // bytes one global_load_lds round of the workgroup moves
 __host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
-// logical column (0..31) of a tile -> physical position (16-column groups stored 0,2,1,3 as in mfma.hip.h)
-__host__ __device__ constexpr int h4_col_perm(int c) { return h_col_perm(c); }
 
 struct RowPass4Args {
     RowPassArgs base;
