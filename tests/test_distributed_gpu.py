@@ -1,0 +1,68 @@
+"""The row-sharded driver with the REAL HIP contexts: two ranks, both on GPU 0, collectives over gloo
+(NCCL refuses two ranks on one device; gloo all-reduces CUDA tensors through the host).  What is checked is
+everything the CPU test cannot see: the kernels' exchange buffers bound to torch tensors, the ordering of
+the collectives against the context's stream, the common fp16 storage factor, and that the sharded fit
+equals the single-process fit of the same kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import klnmf_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, f, k, iters, precision, out_dir):
+    import torch
+    import torch.distributed as dist
+    from multimodal_amd.distributed import ShardedKLNMF, row_partition
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        X = orc.synthetic_V(77, n, f, k)
+        H0 = orc.synthetic_H0(77, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=iters, precision=precision)
+        m.set_v_max(X[r0:r1].max())
+        Xd = torch.from_numpy(X[r0:r1].astype(np.float32)).cuda()
+        m.upload_V_device(Xd)
+        Xd.fill_(7.0e8)                      # the upload must be ordered before this (same stream)
+        m.set_H(H0)
+        m.init_W()
+        errors, n_done, stopped = m.run(iters, fit=True, tol=0.0)
+        W = m.gather_W()
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), W=W, H=m.get_H(), errors=np.array(errors))
+        m.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,rtol', [('bf16', 2e-4), ('f64', 1e-9)])
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, precision, rtol):
+    import torch.multiprocessing as mp
+    from multimodal_amd.lib import nmf
+    n, f, k, iters, world = 4096 + 96, 512, 40, 4, 2         # ragged last shard
+    mp.spawn(_worker, args=(world, _free_port(), n, f, k, iters, precision, str(tmp_path)), nprocs=world, join=True)
+    X = orc.synthetic_V(77, n, f, k)
+    H0 = orc.synthetic_H0(77, f, k)
+    m = nmf.KLdivNMF(n_components=k, max_iter=iters, tol=0, precision=precision)
+    m._init_dictionary = H0
+    W1, e1 = m.fit_transform(X.astype(np.float32).astype(np.float64), return_errors=True)
+    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    np.testing.assert_array_equal(res[0]['H'], res[1]['H'])              # replicas bit-identical
+    np.testing.assert_array_equal(res[0]['errors'], res[1]['errors'])
+    for r in res:
+        np.testing.assert_allclose(r['errors'], e1, rtol=rtol)
+        np.testing.assert_allclose(r['H'], m.components_, rtol=50 * rtol, atol=1e-7)
+        np.testing.assert_allclose(r['W'], W1, rtol=50 * rtol, atol=1e-6 * np.abs(W1).max())
