@@ -87,6 +87,12 @@ int klnmf_upload_V(klnmf_ctx *ctx, const void *src, int dtype,
 int klnmf_upload_V_device(klnmf_ctx *ctx, const float *dsrc,
                           int64_t rows, int64_t cols, int64_t ld,
                           int64_t row0, int64_t col0, double scale);
+/* Same with a row gather: row i of the block is row drow_idx[i] (device array) of the device-resident
+ * matrix dsrc.  Replaces the per-run `x[train, :]` / `x[test, :]` copies of experiment.py:163-164 and the
+ * re-upload that follows them (next-row N2: the stacked data stays on the device across runs). */
+int klnmf_upload_V_device_rows(klnmf_ctx *ctx, const float *dsrc, const int64_t *drow_idx,
+                               int64_t rows, int64_t cols, int64_t ld,
+                               int64_t row0, int64_t col0, double scale);
 /* Dictionary [k,f], C order (nmf.py:149-155 `_init_dictionary`, learner.py:13
  * `components_ = dictionary`). */
 int klnmf_set_H(klnmf_ctx *ctx, const void *src, int dtype);

@@ -37,6 +37,8 @@ SIGNATURES = {
     'klnmf_set_v_max': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_upload_V': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64, _i64, _i64,
                                   _i64, _i64, _c.c_double]),
+    'klnmf_upload_V_device_rows': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_void_p, _i64, _i64, _i64, _i64, _i64,
+                                              _c.c_double]),
     'klnmf_upload_V_device': (_c.c_int, [_ctx_p, _c.c_void_p, _i64, _i64, _i64, _i64,
                                          _i64, _c.c_double]),
     'klnmf_set_H': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
@@ -255,6 +257,11 @@ class Context(object):
     def upload_V_device(self, dev_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
         _check(self._lib.klnmf_upload_V_device(self._h, _c.c_void_p(dev_ptr), rows, cols, ld,
                                                row0, col0, float(scale)))
+
+    def upload_V_device_rows(self, dev_ptr, row_idx_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
+        """Rows row_idx[0..rows) (int64 device array) of a device-resident fp32 matrix."""
+        _check(self._lib.klnmf_upload_V_device_rows(self._h, _c.c_void_p(dev_ptr), _c.c_void_p(row_idx_ptr),
+                                                    rows, cols, ld, row0, col0, float(scale)))
 
     def set_H(self, H):
         H = _as_float_array(H)

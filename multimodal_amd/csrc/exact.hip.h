@@ -170,12 +170,12 @@ __global__ __launch_bounds__(1024) void k_sum_doubles(const double *part, int64_
 // V[row0+i, col0+j] = scale * src[i, j]  (learner.py:53-56 fused into the upload).
 template <typename T, typename S>
 __global__ void k_place_V(T *V, int64_t f, const S *src, int64_t rows, int64_t cols, int64_t ld,
-                          int64_t row0, int64_t col0, double scale) {
+                          int64_t row0, int64_t col0, double scale, const int64_t *row_idx = nullptr) {
     const int64_t total = rows * cols;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / cols, j = e % cols;
-        V[(row0 + i) * f + col0 + j] = (T)(scale * (double)src[i * ld + j]);
+        V[(row0 + i) * f + col0 + j] = (T)(scale * (double)src[(row_idx ? row_idx[i] : i) * ld + j]);
     }
 }
 

@@ -436,27 +436,27 @@ void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopp
 // ---------------------------------------------------------------- uploads ---
 template <typename S>
 void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_t ld, int64_t row0,
-                 int64_t col0, double scale) {
+                 int64_t col0, double scale, const int64_t *row_idx = nullptr) {
     const int64_t total = rows * cols;
     const int grid = grid_for(total, 256, 8192);
     switch (c->prec) {
         case KLNMF_PREC_F64:
             hipLaunchKernelGGL((k_place_V<double, S>), dim3(grid), dim3(256), 0, c->stream,
-                               (double *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale);
+                               (double *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale, row_idx);
             break;
         case KLNMF_PREC_F32:
             hipLaunchKernelGGL((k_place_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
-                               (float *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale);
+                               (float *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale, row_idx);
             break;
         case KLNMF_PREC_BF16:
             hipLaunchKernelGGL((k_tile_V<_Float16, S>), dim3(grid), dim3(256), 0, c->stream,
                                (_Float16 *)c->VtA, (_Float16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
-                               ld, row0, col0, scale * c->v_scale, c->st);
+                               ld, row0, col0, scale * c->v_scale, c->st, row_idx);
             break;
         default:
             hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
                                (float *)c->VtA, (float *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
-                               ld, row0, col0, scale, c->st);
+                               ld, row0, col0, scale, c->st, row_idx);
             break;
     }
     HIPCHK(hipGetLastError());
@@ -813,6 +813,16 @@ int klnmf_upload_V_device(klnmf_ctx *c, const float *dsrc, int64_t rows, int64_t
         if (!dsrc) fail(KLNMF_ERR_ARG, "null source");
         check_block(c, rows, cols, ld, row0, col0);
         place_block<float>(c, dsrc, rows, cols, ld, row0, col0, scale);
+    });
+}
+
+int klnmf_upload_V_device_rows(klnmf_ctx *c, const float *dsrc, const int64_t *drow_idx, int64_t rows,
+                               int64_t cols, int64_t ld, int64_t row0, int64_t col0, double scale) {
+    return guarded([&] {
+        need_problem(c);
+        if (!dsrc || !drow_idx) fail(KLNMF_ERR_ARG, "null source");
+        check_block(c, rows, cols, ld, row0, col0);
+        place_block<float>(c, dsrc, rows, cols, ld, row0, col0, scale, drow_idx);
     });
 }
 

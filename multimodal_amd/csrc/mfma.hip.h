@@ -734,14 +734,15 @@ __global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t r
 template <typename VT, typename S>
 __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int nct, const S *src,
                                                 int64_t rows, int64_t cols, int64_t ld, int64_t row0,
-                                                int64_t col0, double scale, DevState *st) {
+                                                int64_t col0, double scale, DevState *st,
+                                                const int64_t *row_idx = nullptr) {
     __shared__ double red[16];
     const int64_t total = rows * cols;
     double sx = 0, cc = 0;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ii = e / cols, jj = e % cols;
-        const double xv = scale * (double)src[ii * ld + jj];   // scale includes the storage factor c
+        const double xv = scale * (double)src[(row_idx ? row_idx[ii] : ii) * ld + jj];   // scale includes the storage factor c
         VT xs = (VT)xv;
         if (sizeof(VT) == 2 && !(xv <= 65504.0)) {             // beyond the maximum given to klnmf_set_v_max: saturate
             xs = (VT)65504.f;                                  // (never inf in the matrix) and report at the next loop

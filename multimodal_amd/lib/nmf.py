@@ -153,16 +153,23 @@ class KLdivNMF(object):
         blocks = [_dense(b) for b in blocks]
         n_samples = blocks[0].shape[0]
         n_features = sum(b.shape[1] for b in blocks)
+        return self._fit_uploaded(n_samples, n_features, lambda ctx: ctx.upload_blocks(blocks, coefs),
+                                  lambda H_init: _out_dtype(H_init, *blocks), _fit=_fit,
+                                  return_errors=return_errors)
+
+    def _fit_uploaded(self, n_samples, n_features, upload, out_dtype_of, _fit=True, return_errors=False):
+        """The loop of nmf.py:159-230 on a matrix that `upload(ctx)` places in the context: host blocks
+        (`_fit_blocks`) or rows gathered from device-resident data (`device_data.DeviceDataset`)."""
         if not self.n_components:
             self.n_components = n_features
         H_init = self._init_H(n_features)
         k = self.n_components
         max_iter = int(self.max_iter)
-        out_dtype = _out_dtype(H_init, *blocks)
+        out_dtype = out_dtype_of(H_init)
 
         with self._context() as ctx:
             ctx.set_problem(n_samples, n_features, k, max_iter)
-            ctx.upload_blocks(blocks, coefs)
+            upload(ctx)
             ctx.set_H(H_init)
             ctx.init_W()                       # W0 = X . H_init^T (nmf.py:156)
             if _fit:

@@ -509,3 +509,48 @@ def test_context_on_torch_default_stream_is_ordered_with_torch():
     _, _, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=3, tol=0)
     assert_allclose(errs, eo, rtol=1e-3)
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec,rtol', [('f64', 1e-10), ('bf16', 1e-12)])
+def test_device_resident_dataset_equals_host_slices(monkeypatch, prec, rtol):
+    """Next-row N2: modalities stay on the GPU, a run passes row indices (experiment.py:163-164) and the
+    upload kernel gathers them.  Same kernels, same data -> same dictionary and coefficients as slicing on
+    the host and training through MultimodalLearner."""
+    from multimodal_amd.device_data import DeviceDataset
+    import multimodal_amd.learner as L
+    rs = np.random.RandomState(11)
+    n, dims, k = 300, [96, 40, 24], 12
+    data = [rs.random_sample((n, d)).astype(np.float32).astype(np.float64) for d in dims]   # fp32-representable
+    coefs = [1.0, 0.5, 2.0]
+    mods = ['a', 'b', 'c']
+    train = rs.permutation(n)[:200]
+    test = np.setdiff1d(np.arange(n), train)
+    H0 = orc.synthetic_H0(5, sum(dims), k)
+    monkeypatch.setenv('KLNMF_PRECISION', prec)
+    orig = L.NMF
+
+    def factory(**kw):
+        mm = orig(**kw)
+        mm._init_dictionary = H0.copy()
+        return mm
+    monkeypatch.setattr(L, 'NMF', factory)
+    host = MultimodalLearner(mods, dims, coefs, k)
+    host.train([x[train, :] for x in data], 6)
+    import multimodal_amd.device_data as DD
+    monkeypatch.setattr(DD, 'KLdivNMF', factory)
+    ds = DeviceDataset(data)
+    dev = MultimodalLearner(mods, dims, coefs, k)
+    ds.train(dev, train, 6)
+    if prec == 'bf16':      # the host path derives the fp16 storage factor from the slice, the device path from the
+        tol = dict(rtol=2e-3, atol=1e-6)            # whole matrix: same kernels, possibly another power of two
+    else:
+        tol = dict(rtol=rtol, atol=1e-14)
+    assert_allclose(dev.dico, host.dico, **tol)
+    monkeypatch.setattr(L, 'NMF', orig)
+    monkeypatch.setattr(DD, 'KLdivNMF', orig)
+    dev.dico = host.dico
+    for msel in (['a'], ['c', 'a']):
+        hi = host.reconstruct_internal_multi(msel, [data[mods.index(m)][test, :] for m in msel], 5)
+        di = ds.reconstruct_internal_multi(dev, msel, test, 5)
+        assert_allclose(di, hi, rtol=tol['rtol'], atol=1e-8 * np.abs(hi).max())
