@@ -245,3 +245,71 @@ def synthetic_H0(base_seed, f, k):
     return normalize_sum(
         np.random.RandomState(base_seed - 1).random_sample((k, f)) + .01,
         axis=1)
+
+
+# ---- the reference's CSR branch (nmf.py:52-70, 301-308, 331-334) ----------------------------------
+# With sparse X the reference evaluates W.H and the ratio ONLY on the stored entries of X: Q is a sparse
+# matrix with X's structure (structural zeros of X stay zero in Q, unlike the dense branch where they
+# become eps/(WH+eps)), and the loss uses sum(W.H) = sum_a colsum(W)_a * rowsum(H)_a.
+
+def sparse_structure(X):
+    """(ii, jj, data) of the stored non-zeros in CSR order, after eliminate_zeros (nmf.py:66-67)."""
+    import scipy.sparse as sp
+    X = sp.csr_matrix(X, copy=True)
+    X.eliminate_zeros()
+    X.sort_indices()
+    ii, jj = X.nonzero()
+    return X, ii, jj
+
+
+def sparse_wh(X, W, H):
+    """W.H on the stored entries of X.  Reference nmf.py:52-70 (_special_sparse_dot)."""
+    X, ii, jj = sparse_structure(X)
+    return X, ii, jj, np.multiply(W[ii, :], H.T[jj, :]).sum(axis=1)
+
+
+def sparse_ratio_q(X, W, H, eps=EPS_RATIO):
+    """Q values (CSR order of X) = (x + eps) / (wh + eps).  Reference nmf.py:331-334."""
+    Xs, ii, jj, wh = sparse_wh(X, W, H)
+    return Xs, ii, jj, (Xs.data + eps) / (wh + eps)
+
+
+def sparse_kl_error(X, W, H, eps=EPS_RATIO):
+    """Reference nmf.py:301-308."""
+    Xs, ii, jj, wh = sparse_wh(X, W, H)
+    wh_sum = np.sum(np.multiply(np.sum(W, axis=0), np.sum(H, axis=1)))
+    return (np.multiply(Xs.data, np.log(np.divide(Xs.data + eps, wh + eps)))).sum() - Xs.data.sum() + wh_sum
+
+
+def sparse_update_step(X, W, H, fit=True):
+    """One _update with sparse X.  Reference nmf.py:232-257 with the CSR `_Q` (old ratio for both rules)."""
+    import scipy.sparse as sp
+    Xs, ii, jj, q = sparse_ratio_q(X, W, H)
+    Q = sp.csr_matrix((q, (ii, jj)), shape=Xs.shape)
+    W_new = np.multiply(W, np.asarray(Q.dot(H.T)))
+    H_new = H
+    if fit:
+        H_new = normalize_sum(np.multiply(H, np.asarray(Q.T.dot(W_new)).T), axis=1)
+    return W_new, H_new
+
+
+def sparse_fit_transform(X, k, H0, max_iter=200, tol=1e-6, fit=True, components=None):
+    """The loop of nmf.py:159-230 for CSR input.  Returns (W, H, errors)."""
+    import scipy.sparse as sp
+    Xs = sp.csr_matrix(X)
+    n, f = Xs.shape
+    H = np.array(H0, dtype=np.float64)
+    W = np.asarray(Xs.dot(H.T))                               # nmf.py:156
+    if not fit:
+        H = np.array(components, dtype=np.float64)
+    prev = np.inf
+    tol_abs = tol * n * f
+    errors = []
+    for _ in range(max_iter):
+        err = sparse_kl_error(Xs, W, H)
+        if prev - err < tol_abs:
+            break
+        prev = err
+        errors.append(err)
+        W, H = sparse_update_step(Xs, W, H, fit=fit)
+    return W, H, errors

@@ -17,6 +17,7 @@ Fixture families:
   G3 single-step rules         G4 default-tol early stop + warning case
   G5 learner (2 and 3 modalities)   G6 CSR input (error/_Q/one update)
   G7 float32 run               G8 error paths + known-answer helper values
+  G9 CSR input: full fit, transform, default-tol stop (the reference's sparse branch)
 """
 import io
 import os
@@ -197,6 +198,27 @@ def g6():
          Q_dense=np.asarray(Q.todense()), Wn=Wn, Hn=m.components_)
 
 
+def g9():
+    """Full fit and transform through the reference's CSR branch (nmf.py:52-70, 301-308, 331-334):
+    sparse X incl. an empty row and an empty column."""
+    seed, n, f, k = 91, 60, 90, 5
+    rs = np.random.RandomState(seed)
+    dense = np.abs(rs.random_sample((n, f))) * (rs.random_sample((n, f)) < .25)
+    dense[7, :] = 0
+    dense[:, 11] = 0
+    H0 = normalize_sum(np.abs(rs.random_sample((k, f))) + .01, axis=1)
+    X = sp.csr_matrix(dense)
+    m, W, errors, _ = ref_fit(X, H0, k, 12, 0)
+    Wt = m.transform(X[:20])
+    m2 = rnmf.KLdivNMF(n_components=k, max_iter=300, tol=1e-4)
+    m2._init_dictionary = H0.copy()
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        W2, errors2 = m2.fit_transform(X, return_errors=True)
+    save('g9_sparse_fit', seed=seed, n=n, f=f, k=k, W=W, H=m.components_, errors=errors, Wt=Wt,
+         errors_tol=np.array(errors2, dtype=np.float64), W_tol=W2, H_tol=m2.components_)
+
+
 def g7():
     seed, n, f, k = 71, 48, 80, 6
     X, H0 = gen_inputs(seed, n, f, k)
@@ -240,5 +262,5 @@ def g8():
 
 
 if __name__ == '__main__':
-    for g in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for g in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         g()

@@ -62,6 +62,16 @@ def g6_inputs(g):
     return dense, W, H
 
 
+def g9_inputs(g):
+    seed, n, f, k = int(g['seed']), int(g['n']), int(g['f']), int(g['k'])
+    rs = np.random.RandomState(seed)
+    dense = np.abs(rs.random_sample((n, f))) * (rs.random_sample((n, f)) < .25)
+    dense[7, :] = 0
+    dense[:, 11] = 0
+    H0 = _normalize_rows(np.abs(rs.random_sample((k, f))) + .01)
+    return dense, H0
+
+
 def g8_edge_inputs():
     X, H0 = gen_inputs(81, 12, 9, 3)
     X[4, :] = 0

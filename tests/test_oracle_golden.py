@@ -131,6 +131,29 @@ def test_g6_sparse_matches_dense_restatement():
     assert_allclose(Hn, g['Hn'], rtol=1e-5)
 
 
+def test_g9_sparse_branch_fit_transform_and_stop():
+    """The CSR branch of the reference (Q only on the stored entries of X): full fit, transform on the
+    learnt dictionary, and the default-tolerance stop, against outputs of the imported reference."""
+    import scipy.sparse as sp
+    g = gi.load('g9_sparse_fit')
+    dense, H0 = gi.g9_inputs(g)
+    X = sp.csr_matrix(dense)
+    k = int(g['k'])
+    W, H, errors = orc.sparse_fit_transform(X, k, H0, max_iter=12, tol=0)
+    assert_allclose(errors, g['errors'], rtol=1e-11)
+    assert_allclose(W, g['W'], rtol=1e-9, atol=1e-300)
+    assert_allclose(H, g['H'], rtol=1e-9, atol=1e-300)
+    Wt, _, _ = orc.sparse_fit_transform(X[:20], k, H, max_iter=12, tol=0, fit=False, components=H)
+    assert_allclose(Wt, g['Wt'], rtol=1e-9, atol=1e-300)
+    W2, H2, e2 = orc.sparse_fit_transform(X, k, H0, max_iter=300, tol=1e-4)
+    assert len(e2) == len(g['errors_tol'])
+    assert_allclose(e2, g['errors_tol'], rtol=1e-10)
+    assert_allclose(H2, g['H_tol'], rtol=1e-8, atol=1e-300)
+    # and it is NOT the dense rule on the densified matrix (structural zeros stay out of Q)
+    Wd, Hd, ed = orc.fit_transform(dense, k=k, H0=H0, max_iter=12, tol=0)
+    assert abs(ed[-1] - errors[-1]) > 1e-9 * abs(errors[-1])
+
+
 def test_g7_float32_reference_run():
     g = gi.load('g7_float32')
     k = int(g['k'])
