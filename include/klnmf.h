@@ -182,6 +182,19 @@ int klnmf_profile_read(klnmf_ctx *ctx, int64_t *rowpass_launches,
                        double *colpass_ms, int reset);
 int klnmf_synchronize(klnmf_ctx *ctx);
 
+/* ---- CSR input (next-row N3): the reference's sparse branch ----------------------------------- */
+/* With scipy-sparse X the reference evaluates W.H and the ratio only on the stored entries of X
+ * (nmf.py:52-70, 301-308, 331-334).  Exact modes only.  klnmf_set_problem_sparse replaces
+ * klnmf_set_problem; klnmf_upload_csr takes X in CSR (indptr[n+1], indices[nnz], data[nnz]; no explicit
+ * zeros, `eliminate_zeros` of nmf.py:66) and the same entries in CSC order (csc_indptr[f+1], csc_rows[nnz],
+ * csc_perm[nnz] = position of the entry in the CSR arrays).  Every loop / step / error entry point then
+ * works on the stored entries; klnmf_get_Q_values returns the ratio in CSR order (the data of the sparse
+ * matrix `_Q` returns, nmf.py:333-334). */
+int klnmf_set_problem_sparse(klnmf_ctx *ctx, int64_t n, int64_t f, int64_t k, int64_t max_iter_capacity, int64_t nnz);
+int klnmf_upload_csr(klnmf_ctx *ctx, int dtype, const int64_t *indptr, const int64_t *indices, const void *data,
+                     const int64_t *csc_indptr, const int64_t *csc_rows, const int64_t *csc_perm);
+int klnmf_get_Q_values(klnmf_ctx *ctx, void *dst, int dtype);
+
 /* ---- reconstruction (next-row K7) ---------------------------------------- */
 /* C[m x n] = A[m x kk] . B[kk x n], row-major host arrays of `dtype`, computed on `device` in that
  * arithmetic.  Replaces `internal.dot(self.get_dico(dest_mod))` / `internal.dot(self.get_stacked_dicos(..))`

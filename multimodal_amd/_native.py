@@ -75,6 +75,10 @@ SIGNATURES = {
     'klnmf_profile_read': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double),
                                       _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.c_int]),
     'klnmf_synchronize': (_c.c_int, [_ctx_p]),
+    'klnmf_set_problem_sparse': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64, _i64]),
+    'klnmf_upload_csr': (_c.c_int, [_ctx_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                    _c.c_void_p, _c.c_void_p]),
+    'klnmf_get_Q_values': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
     'klnmf_matmul': (_c.c_int, [_c.c_int, _c.c_int, _i64, _i64, _i64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'klnmf_selftest': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_int)]),
 }
@@ -257,6 +261,40 @@ class Context(object):
     def upload_V_device(self, dev_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
         _check(self._lib.klnmf_upload_V_device(self._h, _c.c_void_p(dev_ptr), rows, cols, ld,
                                                row0, col0, float(scale)))
+
+    # ---- CSR input (exact modes) ----
+    def set_problem_sparse(self, X, k, max_iter_capacity):
+        """X: scipy CSR (explicit zeros are dropped, indices sorted -- nmf.py:66 does the same).  Uploads the
+        structure in CSR and CSC order and the values."""
+        import scipy.sparse as sp
+        X = sp.csr_matrix(X, copy=True)
+        X.eliminate_zeros()
+        X.sort_indices()
+        n, f = X.shape
+        nnz = int(X.nnz)
+        dt = np.float32 if X.dtype == np.float32 else np.float64
+        _check(self._lib.klnmf_set_problem_sparse(self._h, n, f, k, int(max_iter_capacity), nnz))
+        self.n, self.f, self.k, self.cap = n, f, k, int(max_iter_capacity)
+        self.nnz = nnz
+        indptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(X.indices, dtype=np.int64)
+        data = np.ascontiguousarray(X.data, dtype=dt)
+        # CSC order of the same entries: a stable sort of the CSR entries by column
+        perm = np.argsort(indices, kind='stable').astype(np.int64)
+        rows_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+        csc_rows = np.ascontiguousarray(rows_of[perm])
+        csc_indptr = np.zeros(f + 1, dtype=np.int64)
+        np.cumsum(np.bincount(indices, minlength=f), out=csc_indptr[1:])
+        p = lambda a: a.ctypes.data_as(_c.c_void_p)
+        _check(self._lib.klnmf_upload_csr(self._h, DT_F32 if dt == np.float32 else DT_F64, p(indptr), p(indices),
+                                          p(data), p(csc_indptr), p(csc_rows), p(perm)))
+        self._csr = (indptr, indices)
+        return X
+
+    def get_Q_values(self, dtype=np.float64):
+        out = np.empty(self.nnz, dtype=dtype)
+        _check(self._lib.klnmf_get_Q_values(self._h, out.ctypes.data, _np_dtype_code(out)))
+        return out
 
     def upload_V_device_rows(self, dev_ptr, row_idx_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
         """Rows row_idx[0..rows) (int64 device array) of a device-resident fp32 matrix."""

@@ -15,6 +15,7 @@
 #include "../../include/klnmf.h"
 #include "common.hip.h"
 #include "exact.hip.h"
+#include "sparse.hip.h"
 #include "mfma.hip.h"
 #include "mfma4.hip.h"
 #include "probe.hip.h"
@@ -95,6 +96,14 @@ struct klnmf_ctx {
     double *loss_part = nullptr;
     int64_t loss_part_count = 0;
     int nsplit = 1, kchunk = 0;
+
+    // CSR input in the exact modes (sparse.hip.h): structure of X in CSR and CSC order, ratio values, H^T
+    bool sparse = false;
+    int64_t nnz = 0;
+    int64_t *sp_indptr = nullptr, *sp_indices = nullptr, *csc_indptr = nullptr, *csc_rows = nullptr, *csc_perm = nullptr;
+    void *sp_data = nullptr, *sp_q = nullptr, *HT = nullptr;
+    double *sp_row_loss = nullptr, *sp_wpart = nullptr, *sp_prod = nullptr;
+    int64_t sp_nblk = 0;
 
     // bf16 modes
     int KT = 0, KP = 0, ks = 0;
@@ -316,8 +325,32 @@ void fast_pack_H(klnmf_ctx *c, int do_update) {
 }
 
 // ------------------------------------------------------------ exact pieces ---
+// CSR input: ratio on the stored entries + loss (nmf.py:301-308, 331-334)
+template <typename T>
+void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
+    const int64_t hk = c->k * c->f;
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_row);
+    hipLaunchKernelGGL((k_sp_transpose_H<T>), dim3(grid_for(hk)), dim3(256), 0, c->stream, (const T *)c->H,
+                       (T *)c->HT, c->k, c->f, (const DevState *)c->st);
+    hipLaunchKernelGGL((k_sp_q<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, (const int64_t *)c->sp_indptr,
+                       (const int64_t *)c->sp_indices, (const T *)c->sp_data, (const T *)c->W[c->cur],
+                       (const T *)c->HT, (T *)c->sp_q, c->sp_row_loss, c->k, (T)eps, write_q,
+                       (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    hipLaunchKernelGGL((k_sp_colsum_part<T>), dim3((unsigned)c->sp_nblk), dim3(256), 0, c->stream,
+                       (const T *)c->W[c->cur], c->sp_wpart, c->n, c->k, (const DevState *)c->st);
+    hipLaunchKernelGGL((k_sp_dots<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (const double *)c->sp_wpart,
+                       c->sp_nblk, (const T *)c->H, c->k, c->f, c->sp_prod, (const DevState *)c->st);
+    hipLaunchKernelGGL(k_sp_loss, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sp_row_loss, c->n,
+                       (const double *)c->sp_prod, c->k, c->loss_xchg, (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
 template <typename T>
 void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
+    if (c->sparse) { sparse_Q<T>(c, write_q, eps); return; }
     EpiQ<T> epi{(const T *)c->V, (T *)c->Q, c->f, c->loss_part, write_q, 0.0, (T)eps};
     dim3 grid((unsigned)((c->f + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), 1);
     EventPair ev{};
@@ -337,6 +370,13 @@ void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
 // W_new = W * (Qsrc . H^T)   (multiply=0: W_new = Qsrc . H^T, i.e. W0 with Qsrc = V)
 template <typename T>
 void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
+    if (c->sparse) {        // Q . H^T over the stored entries (qsrc: the ratio values, or X's values for W0)
+        hipLaunchKernelGGL((k_sp_w<T>), dim3((unsigned)c->n), dim3(256), 0, c->stream, (const int64_t *)c->sp_indptr,
+                           (const int64_t *)c->sp_indices, (const T *)qsrc, (const T *)c->W[c->cur], (const T *)c->HT,
+                           (T *)c->W[c->cur ^ 1], c->k, multiply, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     EpiW<T> epi{(const T *)c->W[c->cur], (T *)c->W[c->cur ^ 1], c->k, multiply};
     dim3 grid((unsigned)((c->k + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), 1);
     hipLaunchKernelGGL((k_gemm<T, EpiW<T>>), grid, dim3(256), 0, c->stream, (int)c->n, (int)c->k,
@@ -348,6 +388,16 @@ void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
 // numer = W[widx]^T . Q
 template <typename T>
 void exact_N(klnmf_ctx *c, int widx) {
+    if (c->sparse) {        // W^T . Q, one block per feature column (CSC order)
+        EventPair evs{};
+        if (c->profiling) evs = begin_event(c, c->ev_col);
+        hipLaunchKernelGGL((k_sp_n<T>), dim3((unsigned)c->f), dim3(256), 0, c->stream, (const int64_t *)c->csc_indptr,
+                           (const int64_t *)c->csc_rows, (const int64_t *)c->csc_perm, (const T *)c->sp_q,
+                           (const T *)c->W[widx], (T *)c->numer, c->k, c->f, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        if (c->profiling) HIPCHK(hipEventRecord(evs.b, c->stream));
+        return;
+    }
     EpiN<T> epi{(T *)c->Npart, c->f, c->k * c->f};
     dim3 grid((unsigned)((c->f + GT - 1) / GT), (unsigned)((c->k + GT - 1) / GT), (unsigned)c->nsplit);
     EventPair ev{};
@@ -388,7 +438,7 @@ void piece_rowpass(klnmf_ctx *c, int fit) {
     (void)fit;   // the W rule is the same for fit and transform (nmf.py:251-253)
     if (c->is_exact()) {
         EXACT_CALL(c, exact_Q, 1);
-        EXACT_CALL(c, exact_W, c->Q, 1);
+        EXACT_CALL(c, exact_W, c->sparse ? c->sp_q : c->Q, 1);
     } else {
         fast_rowpass(c, ROW_UPDATE);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
@@ -673,6 +723,8 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         c->free_all();
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
+        c->sparse = false;
+        c->nnz = 0;
         c->st = (DevState *)c->dalloc(sizeof(DevState));
         c->errors = (double *)c->dalloc(sizeof(double) * (cap > 0 ? cap : 1));
         c->loss_xchg = (double *)c->dalloc(sizeof(double) * 2);
@@ -754,6 +806,78 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         reset_state(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_problem = true;
+    });
+}
+
+int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap, int64_t nnz) {
+    return guarded([&] {
+        use(c);
+        if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "CSR input runs in the exact modes (KLNMF_PREC_F64 / F32); densify for the bf16 kernels");
+        if (n <= 0 || f <= 0 || k <= 0 || cap < 0 || nnz < 0) fail(KLNMF_ERR_ARG, "n, f, k must be positive, nnz >= 0");
+        if (n > (1LL << 30) || f > (1LL << 30) || k > (1LL << 20)) fail(KLNMF_ERR_UNSUPP, "dimension too large");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->free_all();
+        c->n = n; c->f = f; c->k = k; c->cap = cap;
+        c->cur = 0;
+        c->sparse = true;
+        c->nnz = nnz;
+        const size_t es = c->esize();
+        c->st = (DevState *)c->dalloc(sizeof(DevState));
+        c->errors = (double *)c->dalloc(sizeof(double) * (cap > 0 ? cap : 1));
+        c->loss_xchg = (double *)c->dalloc(sizeof(double) * 2);
+        c->V = nullptr; c->Q = nullptr; c->Npart = nullptr; c->loss_part = nullptr;
+        c->W[0] = c->dalloc((size_t)n * k * es);
+        c->W[1] = c->dalloc((size_t)n * k * es);
+        c->H = c->dalloc((size_t)k * f * es);
+        c->HT = c->dalloc((size_t)k * f * es);
+        c->numer = c->dalloc((size_t)k * f * es);
+        c->sp_indptr = (int64_t *)c->dalloc(sizeof(int64_t) * (n + 1));
+        c->sp_indices = (int64_t *)c->dalloc(sizeof(int64_t) * (nnz > 0 ? nnz : 1));
+        c->csc_indptr = (int64_t *)c->dalloc(sizeof(int64_t) * (f + 1));
+        c->csc_rows = (int64_t *)c->dalloc(sizeof(int64_t) * (nnz > 0 ? nnz : 1));
+        c->csc_perm = (int64_t *)c->dalloc(sizeof(int64_t) * (nnz > 0 ? nnz : 1));
+        c->sp_data = c->dalloc((size_t)(nnz > 0 ? nnz : 1) * es);
+        c->sp_q = c->dalloc((size_t)(nnz > 0 ? nnz : 1) * es);
+        c->sp_row_loss = (double *)c->dalloc(sizeof(double) * n);
+        c->sp_nblk = (n + 255) / 256;
+        c->sp_wpart = (double *)c->dalloc(sizeof(double) * c->sp_nblk * k);
+        c->sp_prod = (double *)c->dalloc(sizeof(double) * k);
+        reset_state(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->have_problem = true;
+    });
+}
+
+int klnmf_upload_csr(klnmf_ctx *c, int dtype, const int64_t *indptr, const int64_t *indices, const void *data,
+                     const int64_t *csc_indptr, const int64_t *csc_rows, const int64_t *csc_perm) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->sparse) fail(KLNMF_ERR_ARG, "klnmf_upload_csr needs klnmf_set_problem_sparse");
+        if (!indptr || !csc_indptr || (c->nnz > 0 && (!indices || !data || !csc_rows || !csc_perm)))
+            fail(KLNMF_ERR_ARG, "null pointer");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (indptr[0] != 0 || indptr[c->n] != c->nnz || csc_indptr[0] != 0 || csc_indptr[c->f] != c->nnz)
+            fail(KLNMF_ERR_ARG, "index pointers do not match n, f, nnz");
+        HIPCHK(hipMemcpyAsync(c->sp_indptr, indptr, sizeof(int64_t) * (c->n + 1), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->csc_indptr, csc_indptr, sizeof(int64_t) * (c->f + 1), hipMemcpyHostToDevice, c->stream));
+        if (c->nnz > 0) {
+            HIPCHK(hipMemcpyAsync(c->sp_indices, indices, sizeof(int64_t) * c->nnz, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->csc_rows, csc_rows, sizeof(int64_t) * c->nnz, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->csc_perm, csc_perm, sizeof(int64_t) * c->nnz, hipMemcpyHostToDevice, c->stream));
+            // values: through the dense setter (dtype conversion) as a 1 x nnz matrix
+            set_matrix(c, data, dtype, 1, c->nnz, c->sp_data, nullptr, 0);
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->v_uploaded = true;
+    });
+}
+
+int klnmf_get_Q_values(klnmf_ctx *c, void *dst, int dtype) {
+    return guarded([&] {
+        need_problem(c);
+        if (!c->sparse) fail(KLNMF_ERR_ARG, "klnmf_get_Q_values needs a CSR problem");
+        if (!dst && c->nnz > 0) fail(KLNMF_ERR_ARG, "null destination");
+        if (c->nnz > 0) get_matrix(c, dst, dtype, 1, c->nnz, c->sp_q, nullptr, 0);
     });
 }
 
@@ -856,6 +980,7 @@ int klnmf_set_Q(klnmf_ctx *c, const void *src, int dtype) {
         need_problem(c);
         if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "the ratio Q is never materialised in the bf16 modes");
         if (!src) fail(KLNMF_ERR_ARG, "null source");
+        if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_set_Q: the ratio of a CSR problem lives on X's structure");
         set_matrix(c, src, dtype, c->n, c->f, c->Q, nullptr, 0);
     });
 }
@@ -864,7 +989,15 @@ int klnmf_init_W(klnmf_ctx *c) {
     return guarded([&] {
         need_problem(c);
         reset_state(c);
-        if (c->is_exact()) EXACT_CALL(c, exact_W, c->V, 0);
+        if (c->sparse) {     // W0 = X . H0^T over the stored entries (nmf.py:156 with CSR X); needs H^T first
+            if (c->prec == KLNMF_PREC_F64)
+                hipLaunchKernelGGL((k_sp_transpose_H<double>), dim3(grid_for(c->k * c->f)), dim3(256), 0, c->stream,
+                                   (const double *)c->H, (double *)c->HT, c->k, c->f, (const DevState *)nullptr);
+            else
+                hipLaunchKernelGGL((k_sp_transpose_H<float>), dim3(grid_for(c->k * c->f)), dim3(256), 0, c->stream,
+                                   (const float *)c->H, (float *)c->HT, c->k, c->f, (const DevState *)nullptr);
+            EXACT_CALL(c, exact_W, c->sp_data, 0);
+        } else if (c->is_exact()) EXACT_CALL(c, exact_W, c->V, 0);
         else fast_rowpass(c, ROW_INIT);
         c->cur ^= 1;
     });
@@ -1046,7 +1179,7 @@ int klnmf_step_W(klnmf_ctx *c) {
         need_problem(c);
         if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "step API needs KLNMF_PREC_F64/F32");
         reset_state(c);
-        EXACT_CALL(c, exact_W, c->Q, 1);
+        EXACT_CALL(c, exact_W, c->sparse ? c->sp_q : c->Q, 1);
         c->cur ^= 1;
         HIPCHK(hipStreamSynchronize(c->stream));
     });
@@ -1133,6 +1266,7 @@ int klnmf_get_Q(klnmf_ctx *c, void *dst, int dtype) {
         need_problem(c);
         if (!c->is_exact()) fail(KLNMF_ERR_UNSUPP, "the ratio Q is never materialised in the bf16 modes");
         if (!dst) fail(KLNMF_ERR_ARG, "null destination");
+        if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_get_Q: use klnmf_get_Q_values for a CSR problem");
         get_matrix(c, dst, dtype, c->n, c->f, c->Q, nullptr, 0);
     });
 }

@@ -86,6 +86,14 @@ def _dense(X):
     return np.asarray(X)
 
 
+def _csr_of(blocks, coefs):
+    """CSR of hstack([c * b ...]) (safe_hstack keeps the stack sparse if any block is, array_utils.py:5-9)."""
+    mats = [sp.csr_matrix(b) * float(c) if sp.issparse(b) else sp.csr_matrix(np.asarray(b) * float(c))
+            for b, c in zip(blocks, coefs)]
+    X = mats[0] if len(mats) == 1 else sp.hstack(mats, format='csr')
+    return sp.csr_matrix(X)
+
+
 def _out_dtype(*arrays):
     """The reference computes in float32 only if every operand is float32."""
     if all(np.asarray(a).dtype == np.float32 for a in arrays):
@@ -116,6 +124,12 @@ class KLdivNMF(object):
         self.device = device if device is not None else _default_device()
 
     # ------------------------------------------------------------ helpers ---
+    def _sparse_route(self, *blocks):
+        """CSR input runs the reference's sparse branch (ratio on the stored entries only, nmf.py:52-70,
+        301-308, 331-334) in the exact modes; the bf16 modes densify (Q off the non-zeros ~1e-8/WH)."""
+        return (any(sp.issparse(b) for b in blocks) and
+                _native.PRECISIONS[self.precision] in (_native.PREC_F64, _native.PREC_F32))
+
     def _context(self, exact=False):
         prec = self.precision
         if exact and _native.PRECISIONS[prec] not in (_native.PREC_F64, _native.PREC_F32):
@@ -150,6 +164,11 @@ class KLdivNMF(object):
         """fit_transform of hstack([c * b for b, c in zip(blocks, coefs)])
         without building the stacked matrix on the host: each modality block is
         scaled, cast and placed by the upload kernel (learner.py:53-56 fused)."""
+        if self._sparse_route(*blocks):
+            X = _csr_of(blocks, coefs)
+            return self._fit_uploaded(X.shape[0], X.shape[1], None,
+                                      lambda H_init: np.float32 if (X.dtype == np.float32 and H_init.dtype == np.float32)
+                                      else np.float64, _fit=_fit, return_errors=return_errors, sparse_X=X)
         blocks = [_dense(b) for b in blocks]
         n_samples = blocks[0].shape[0]
         n_features = sum(b.shape[1] for b in blocks)
@@ -157,7 +176,8 @@ class KLdivNMF(object):
                                   lambda H_init: _out_dtype(H_init, *blocks), _fit=_fit,
                                   return_errors=return_errors)
 
-    def _fit_uploaded(self, n_samples, n_features, upload, out_dtype_of, _fit=True, return_errors=False):
+    def _fit_uploaded(self, n_samples, n_features, upload, out_dtype_of, _fit=True, return_errors=False,
+                      sparse_X=None):
         """The loop of nmf.py:159-230 on a matrix that `upload(ctx)` places in the context: host blocks
         (`_fit_blocks`) or rows gathered from device-resident data (`device_data.DeviceDataset`)."""
         if not self.n_components:
@@ -168,8 +188,11 @@ class KLdivNMF(object):
         out_dtype = out_dtype_of(H_init)
 
         with self._context() as ctx:
-            ctx.set_problem(n_samples, n_features, k, max_iter)
-            upload(ctx)
+            if sparse_X is not None:
+                ctx.set_problem_sparse(sparse_X, k, max_iter)
+            else:
+                ctx.set_problem(n_samples, n_features, k, max_iter)
+                upload(ctx)
             ctx.set_H(H_init)
             ctx.init_W()                       # W0 = X . H_init^T (nmf.py:156)
             if _fit:
@@ -216,8 +239,11 @@ class KLdivNMF(object):
             raise ValueError("the bf16 kernels use the reference's fixed eps = 1e-8")
         H = self.components_
         with self._context() as ctx:
-            ctx.set_problem(Xd.shape[0], Xd.shape[1], H.shape[0], 1)
-            ctx.upload_blocks([Xd])
+            if self._sparse_route(X):
+                ctx.set_problem_sparse(X, H.shape[0], 1)
+            else:
+                ctx.set_problem(Xd.shape[0], Xd.shape[1], H.shape[0], 1)
+                ctx.upload_blocks([Xd])
             ctx.set_H(H)
             ctx.set_W(W)
             if eps != 1.e-8:
@@ -239,10 +265,13 @@ class KLdivNMF(object):
         X = atleast2d_or_csr(X)
         if H is None:
             H = self.components_
-        Xd = _dense(X)
         with self._context() as ctx:
-            ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
-            ctx.upload_blocks([Xd])
+            if self._sparse_route(X):
+                ctx.set_problem_sparse(X, np.shape(H)[0], 1)      # nmf.py:301-308
+            else:
+                Xd = _dense(X)
+                ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
+                ctx.upload_blocks([Xd])
             ctx.set_H(H)
             ctx.set_W(W)
             return ctx.error()
@@ -258,6 +287,15 @@ class KLdivNMF(object):
     def _Q(cls, X, W, H, eps=1.e-8):
         """(X + eps) / (W.H + eps), element-wise (reference nmf.py:325-336).
         CSR input gives a CSR result on X's structure, as in the reference."""
+        if sp.issparse(X):
+            with cls._exact_context() as ctx:
+                Xc = ctx.set_problem_sparse(X, np.shape(H)[0], 1)
+                ctx.set_H(H)
+                ctx.set_W(W)
+                ctx.set_ratio_eps(eps)
+                ctx.step_Q()
+                q = ctx.get_Q_values(dtype=_out_dtype(Xc.data, W, H))
+            return sp.csr_matrix((q, Xc.indices, Xc.indptr), shape=Xc.shape)
         Xd = _dense(X)
         with cls._exact_context() as ctx:
             ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)
@@ -266,16 +304,23 @@ class KLdivNMF(object):
             ctx.set_W(W)
             ctx.set_ratio_eps(eps)
             ctx.step_Q()
-            Q = ctx.get_Q(dtype=_out_dtype(Xd, W, H))
-        if sp.issparse(X):
-            Xc = X.tocsr(copy=True)
-            Xc.eliminate_zeros()
-            ii, jj = Xc.nonzero()
-            return sp.coo_matrix((Q[ii, jj], (ii, jj)), shape=Xc.shape).tocsr()
-        return Q
+            return ctx.get_Q(dtype=_out_dtype(Xd, W, H))
 
     @classmethod
     def _step(cls, X, W, H, Q, eps, which):
+        if sp.issparse(X) and Q is None:          # the sparse branch end to end (nmf.py:331-351)
+            with cls._exact_context() as ctx:
+                Xc = ctx.set_problem_sparse(X, np.shape(H)[0], 1)
+                ctx.set_H(H)
+                ctx.set_W(W)
+                ctx.set_ratio_eps(eps)
+                ctx.step_Q()
+                dt = _out_dtype(Xc.data, W, H)
+                if which == 'W':
+                    ctx.step_W()
+                    return ctx.get_W(dtype=dt)
+                ctx.step_H()
+                return ctx.get_H(dtype=dt)
         Xd = _dense(X)
         with cls._exact_context() as ctx:
             ctx.set_problem(Xd.shape[0], Xd.shape[1], np.shape(H)[0], 1)

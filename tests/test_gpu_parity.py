@@ -176,19 +176,63 @@ def test_f64_learner_matches_reference_golden(name):
                     g['m2m_0_to_1'], rtol=1e-8)
 
 
-def test_f64_sparse_input_is_densified():
+def test_f64_sparse_branch_single_steps_match_reference_golden():
+    """CSR input takes the reference's sparse branch on the device (ratio on the stored entries only):
+    error, _Q, one _update against outputs of the imported reference, to summation order."""
     g = gi.load('g6_sparse')
     dense, W, H = gi.g6_inputs(g)
     X = sp.csr_matrix(dense)
     m = nmf.KLdivNMF(n_components=int(g['k']))
     m.components_ = H.copy()
-    assert_allclose(m.error(X, W, H=H), g['err'], rtol=1e-7)
+    assert_allclose(m.error(X, W, H=H), g['err'], rtol=1e-12)
     Q = m._Q(X, W, H)
     assert sp.isspmatrix_csr(Q)
-    assert_allclose(np.asarray(Q.todense())[dense != 0], g['Q_dense'][dense != 0], rtol=1e-12)
+    assert_allclose(np.asarray(Q.todense()), g['Q_dense'], rtol=1e-12)          # structural zeros stay zero
+    assert_allclose(nmf.KLdivNMF._updated_W(X, W, H), W * np.asarray(Q.dot(H.T)), rtol=1e-12)
     Wn = m._update(X, W, _fit=True)
-    assert_allclose(Wn, g['Wn'], rtol=1e-5)
-    assert_allclose(m.components_, g['Hn'], rtol=1e-5)
+    assert_allclose(Wn, g['Wn'], rtol=1e-11)
+    assert_allclose(m.components_, g['Hn'], rtol=1e-11)
+
+
+def test_f64_sparse_branch_fit_transform_and_stop_match_reference_golden():
+    """Full fit (12 iterations, tol 0), transform on the learnt dictionary and the default-tolerance stop of
+    the reference's CSR branch (fixture g9: X with an empty row and an empty column)."""
+    g = gi.load('g9_sparse_fit')
+    dense, H0 = gi.g9_inputs(g)
+    X = sp.csr_matrix(dense)
+    k = int(g['k'])
+    m, W, errors, _ = fit_gpu(X, H0, k, 12, 0)
+    assert_allclose(errors, g['errors'], rtol=1e-11)
+    assert_allclose(W, g['W'], rtol=1e-9, atol=1e-300)
+    assert_allclose(m.components_, g['H'], rtol=1e-9, atol=1e-300)
+    assert_allclose(m.transform(X[:20]), g['Wt'], rtol=1e-9, atol=1e-300)
+    m2, W2, e2, _ = fit_gpu(X, H0, k, 300, 1e-4)
+    assert len(e2) == len(g['errors_tol'])
+    assert_allclose(e2, g['errors_tol'], rtol=1e-10)
+    assert_allclose(m2.components_, g['H_tol'], rtol=1e-8, atol=1e-300)
+    # float32 mode runs the same branch; the bf16 modes densify (close, not identical)
+    m3, W3, e3, _ = fit_gpu(X.astype(np.float32), H0.astype(np.float32), k, 12, 0, precision='f32')
+    assert W3.dtype == np.float32
+    assert_allclose(e3, g['errors'], rtol=2e-4)
+    m4, W4, e4, _ = fit_gpu(X, H0, k, 12, 0, precision='bf16')
+    assert_allclose(e4, g['errors'], rtol=5e-3)
+    # learner with one sparse modality: the stacked matrix stays sparse (array_utils.py:5-9)
+    lr = MultimodalLearner(['s', 'd'], [60, 30], [1.0, 0.5], k)
+    import multimodal_amd.learner as L
+    orig = L.NMF
+
+    def factory(**kw):
+        mm = orig(**kw)
+        mm._init_dictionary = H0.copy()
+        return mm
+    L.NMF = factory
+    try:
+        lr.train([sp.csr_matrix(dense[:, :60]), dense[:, 60:]], 5)
+    finally:
+        L.NMF = orig
+    Xs = sp.hstack([sp.csr_matrix(dense[:, :60]), sp.csr_matrix(0.5 * dense[:, 60:])], format='csr')
+    _, Ho, _ = orc.sparse_fit_transform(Xs, k, H0, max_iter=5, tol=0)
+    assert_allclose(lr.dico, Ho, rtol=1e-9, atol=1e-300)
 
 
 def test_f64_known_answers_and_edges():
