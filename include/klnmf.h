@@ -202,6 +202,19 @@ int klnmf_get_Q_values(klnmf_ctx *ctx, void *dst, int dtype);
 int klnmf_matmul(int device, int dtype, int64_t m, int64_t n, int64_t kk,
                  const void *A, const void *B, void *C);
 
+/* ---- nearest-neighbour evaluation (next-row N4) ------------------------------------------------- */
+/* out[na x nb] (row-major) = measure(A[i, :], B[j, :]) for all pairs; A [na x d], B [nb x d] row-major host
+ * arrays of `dtype`.  Replaces `all_distances(reco_data, ex_data, measure)` (evaluation.py:103-106: a
+ * [na,1,d] x [1,nb,d] broadcast of one of the measures of metrics.py:58-86).  metric: 0 kl_div(a, b),
+ * 1 rev_kl_div, 2 sym_kl_div, 3 frobenius, 4 cosine_diff; eps = 1e-8 (metrics.py:15). */
+#define KLNMF_DIST_KL 0
+#define KLNMF_DIST_REV_KL 1
+#define KLNMF_DIST_SYM_KL 2
+#define KLNMF_DIST_FROBENIUS 3
+#define KLNMF_DIST_COSINE_DIFF 4
+int klnmf_all_distances(int device, int dtype, int metric, int64_t na, int64_t nb, int64_t d,
+                        const void *A, const void *B, void *out);
+
 /* ---- hardware probes (tests) -------------------------------------------- */
 /* Runs the MFMA / LDS-transpose layout self-checks the fused kernels rely on;
  * *failed = bitmask of failing probes (0 = all good). */

@@ -80,6 +80,8 @@ SIGNATURES = {
                                     _c.c_void_p, _c.c_void_p]),
     'klnmf_get_Q_values': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int]),
     'klnmf_matmul': (_c.c_int, [_c.c_int, _c.c_int, _i64, _i64, _i64, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'klnmf_all_distances': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _i64, _i64, _i64, _c.c_void_p, _c.c_void_p,
+                                       _c.c_void_p]),
     'klnmf_selftest': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_int)]),
 }
 
@@ -164,6 +166,26 @@ def matmul(A, B, device=0):
                             A.ctypes.data_as(_c.c_void_p), B.ctypes.data_as(_c.c_void_p),
                             C.ctypes.data_as(_c.c_void_p)))
     return C
+
+
+DIST_KL, DIST_REV_KL, DIST_SYM_KL, DIST_FROBENIUS, DIST_COSINE_DIFF = 0, 1, 2, 3, 4
+
+
+def all_distances(A, B, metric, device=0):
+    """[len(A), len(B)] matrix of metric(A[i], B[j]) on the GPU (klnmf_all_distances)."""
+    A = np.asarray(A)
+    B = np.asarray(B)
+    if A.ndim != 2 or B.ndim != 2 or A.shape[1] != B.shape[1]:
+        raise ValueError('shapes %s and %s do not hold vectors of one length' % (A.shape, B.shape))
+    dt = np.float32 if (A.dtype == np.float32 and B.dtype == np.float32) else np.float64
+    A = np.ascontiguousarray(A, dtype=dt)
+    B = np.ascontiguousarray(B, dtype=dt)
+    out = np.empty((A.shape[0], B.shape[0]), dtype=dt)
+    lib = load()
+    _check(lib.klnmf_all_distances(device, DT_F32 if dt == np.float32 else DT_F64, int(metric), A.shape[0],
+                                   B.shape[0], A.shape[1], A.ctypes.data_as(_c.c_void_p),
+                                   B.ctypes.data_as(_c.c_void_p), out.ctypes.data_as(_c.c_void_p)))
+    return out
 
 
 def selftest(device=0):

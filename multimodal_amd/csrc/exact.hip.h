@@ -201,4 +201,43 @@ __global__ __launch_bounds__(256) void k_gkl(const T *x, const T *y, int64_t cou
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// ---- pairwise distances for the nearest-neighbour evaluation (next-row N4) --------------------------
+// out[i][j] = measure(A[i, :], B[j, :]) for the measures of metrics.py:58-86 (as used by
+// evaluation.py:103-116 `all_distances`, which broadcasts [n_a,1,d] x [1,n_b,d]).  One wave per pair.
+enum DistMetric { DIST_KL = 0, DIST_REV_KL = 1, DIST_SYM_KL = 2, DIST_FROBENIUS = 3, DIST_COSINE_DIFF = 4 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_all_distances(const T *A, const T *B, T *out, int64_t na, int64_t nb,
+                                                        int64_t d, int metric, double eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= na * nb) return;
+    const int64_t i = pair / nb, j = pair % nb;
+    const T *a = A + i * d, *b = B + j * d;
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int64_t e = lane; e < d; e += 64) {
+        const double x = (double)a[e], y = (double)b[e];
+        if (metric <= DIST_SYM_KL) {
+            const double l = log((x + eps) / (y + eps));
+            s0 += x * l - x + y;                    // generalized_KL(a, b)
+            s1 += -y * l - y + x;                   // generalized_KL(b, a): log((y+eps)/(x+eps)) = -l
+        } else if (metric == DIST_FROBENIUS) {
+            s0 += (x - y) * (x - y);
+        } else {
+            s0 += x * y; s1 += x * x; s2 += y * y;
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane != 0) return;
+    double r;
+    switch (metric) {
+        case DIST_KL: r = s0; break;
+        case DIST_REV_KL: r = s1; break;
+        case DIST_SYM_KL: r = 0.5 * (s0 + s1); break;
+        case DIST_FROBENIUS: r = sqrt(s0); break;
+        default: r = -(s0 / (sqrt(s1 * s2) + (s0 == 0.0 ? 1.0 : 0.0))); break;     // metrics.py:71-77
+    }
+    out[pair] = (T)r;
+}
+
 }  // namespace klnmf

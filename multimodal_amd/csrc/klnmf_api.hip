@@ -606,6 +606,30 @@ void get_matrix(klnmf_ctx *c, void *dst, int dtype, int64_t rows, int64_t cols, 
 
 // =============================================================== exports ===
 template <typename T>
+static void distances_on_device(int metric, int64_t na, int64_t nb, int64_t d, const void *A, const void *B, void *out) {
+    T *dA = nullptr, *dB = nullptr, *dO = nullptr;
+    auto release = [&] { (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO); };
+    try {
+        HIPCHK(hipMalloc((void **)&dA, sizeof(T) * (size_t)std::max<int64_t>(1, na * d)));
+        HIPCHK(hipMalloc((void **)&dB, sizeof(T) * (size_t)std::max<int64_t>(1, nb * d)));
+        HIPCHK(hipMalloc((void **)&dO, sizeof(T) * (size_t)(na * nb)));
+        if (d > 0) {
+            HIPCHK(hipMemcpy(dA, A, sizeof(T) * (size_t)(na * d), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(dB, B, sizeof(T) * (size_t)(nb * d), hipMemcpyHostToDevice));
+        }
+        const int64_t pairs = na * nb;
+        hipLaunchKernelGGL((k_all_distances<T>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, 0, (const T *)dA,
+                           (const T *)dB, dO, na, nb, d, metric, kEpsRatio);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(out, dO, sizeof(T) * (size_t)pairs, hipMemcpyDeviceToHost));
+    } catch (...) {
+        release();
+        throw;
+    }
+    release();
+}
+
+template <typename T>
 static void matmul_on_device(int64_t m, int64_t n, int64_t kk, const void *A, const void *B, void *C) {
     T *dA = nullptr, *dB = nullptr, *dC = nullptr;
     auto release = [&] { (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); };
@@ -1320,6 +1344,21 @@ int klnmf_matmul(int device, int dtype, int64_t m, int64_t n, int64_t kk, const 
         if (kk == 0) { std::memset(C, 0, (size_t)(m * n) * (dtype == KLNMF_DT_F64 ? 8 : 4)); return; }
         if (dtype == KLNMF_DT_F64) matmul_on_device<double>(m, n, kk, A, B, C);
         else matmul_on_device<float>(m, n, kk, A, B, C);
+    });
+}
+
+int klnmf_all_distances(int device, int dtype, int metric, int64_t na, int64_t nb, int64_t d, const void *A,
+                        const void *B, void *out) {
+    return guarded([&] {
+        if (na < 0 || nb < 0 || d < 0 || na > (1LL << 24) || nb > (1LL << 24) || d > (1LL << 30))
+            fail(KLNMF_ERR_ARG, "klnmf_all_distances: bad shape");
+        if (metric < DIST_KL || metric > DIST_COSINE_DIFF) fail(KLNMF_ERR_ARG, "klnmf_all_distances: unknown metric");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_all_distances: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (na == 0 || nb == 0) return;
+        if (!out || (d > 0 && (!A || !B))) fail(KLNMF_ERR_ARG, "klnmf_all_distances: null pointer");
+        HIPCHK(hipSetDevice(device));
+        if (dtype == KLNMF_DT_F64) distances_on_device<double>(metric, na, nb, d, A, B, out);
+        else distances_on_device<float>(metric, na, nb, d, A, B, out);
     });
 }
 

@@ -313,3 +313,23 @@ def sparse_fit_transform(X, k, H0, max_iter=200, tol=1e-6, fit=True, components=
         errors.append(err)
         W, H = sparse_update_step(Xs, W, H, fit=fit)
     return W, H, errors
+
+
+# ---- measures of the nearest-neighbour evaluation (metrics.py:58-86, evaluation.py:103-106) ---------
+def pairwise_distances(A, B, name, eps=EPS_RATIO):
+    """[len(A), len(B)] matrix of the reference's measure `name` through its own broadcast pattern."""
+    a = np.asarray(A, dtype=np.float64)[:, np.newaxis, :]
+    b = np.asarray(B, dtype=np.float64)[np.newaxis, :, :]
+    gkl = lambda x, y: (np.multiply(x, np.log(np.divide(x + eps, y + eps))) - x + y).sum(axis=-1)
+    if name == 'kl_div':
+        return gkl(a, b)
+    if name == 'rev_kl_div':
+        return gkl(b, a)
+    if name == 'sym_kl_div':
+        return .5 * (gkl(a, b) + gkl(b, a))
+    if name == 'frobenius':
+        return np.sqrt(np.square(a - b).sum(axis=-1))
+    if name == 'cosine_diff':
+        ab = np.multiply(a, b).sum(axis=-1)
+        return -(ab / (np.sqrt(np.square(a).sum(axis=-1) * np.square(b).sum(axis=-1)) + (ab == 0)))
+    raise ValueError(name)

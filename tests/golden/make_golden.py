@@ -18,6 +18,7 @@ Fixture families:
   G5 learner (2 and 3 modalities)   G6 CSR input (error/_Q/one update)
   G7 float32 run               G8 error paths + known-answer helper values
   G9 CSR input: full fit, transform, default-tol stop (the reference's sparse branch)
+  G10 nearest-neighbour evaluation: pairwise distances for 5 measures, classify_NN labels
 """
 import io
 import os
@@ -219,6 +220,25 @@ def g9():
          errors_tol=np.array(errors2, dtype=np.float64), W_tol=W2, H_tol=m2.components_)
 
 
+def g10():
+    """Nearest-neighbour evaluation: all_distances for the four measures experiment.py uses, and the labels
+    classify_NN finds (evaluation.py:70-116, metrics.py:58-86)."""
+    from multimodal import evaluation as rev
+    from multimodal.lib import metrics as rm
+    seed, na, nb, d = 101, 23, 7, 50
+    rs = np.random.RandomState(seed)
+    A = np.abs(rs.random_sample((na, d))) * (rs.random_sample((na, d)) < .8)
+    B = np.abs(rs.random_sample((nb, d)))
+    A[3, :] = 0                                  # a zero vector (the cosine measure's special case)
+    out = dict(seed=seed, na=na, nb=nb, d=d)
+    for name in ('kl_div', 'rev_kl_div', 'sym_kl_div', 'frobenius', 'cosine_diff'):
+        out[name] = rev.all_distances(A, B, getattr(rm, name))
+    labels = list(range(nb))
+    out['found_frobenius'] = np.array(rev.classify_NN(A, B, labels, rm.frobenius))
+    out['found_cosine'] = np.array(rev.classify_NN(A, B, labels, rm.cosine_diff))
+    save('g10_distances', **out)
+
+
 def g7():
     seed, n, f, k = 71, 48, 80, 6
     X, H0 = gen_inputs(seed, n, f, k)
@@ -262,5 +282,5 @@ def g8():
 
 
 if __name__ == '__main__':
-    for g in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for g in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         g()

@@ -72,6 +72,15 @@ def g9_inputs(g):
     return dense, H0
 
 
+def g10_inputs(g):
+    seed, na, nb, d = int(g['seed']), int(g['na']), int(g['nb']), int(g['d'])
+    rs = np.random.RandomState(seed)
+    A = np.abs(rs.random_sample((na, d))) * (rs.random_sample((na, d)) < .8)
+    B = np.abs(rs.random_sample((nb, d)))
+    A[3, :] = 0
+    return A, B
+
+
 def g8_edge_inputs():
     X, H0 = gen_inputs(81, 12, 9, 3)
     X[4, :] = 0

@@ -598,3 +598,32 @@ def test_device_resident_dataset_equals_host_slices(monkeypatch, prec, rtol):
         hi = host.reconstruct_internal_multi(msel, [data[mods.index(m)][test, :] for m in msel], 5)
         di = ds.reconstruct_internal_multi(dev, msel, test, 5)
         assert_allclose(di, hi, rtol=tol['rtol'], atol=1e-8 * np.abs(hi).max())
+
+
+@pytest.mark.gpu
+def test_nearest_neighbour_measures_match_reference_golden():
+    """Next-row N4: all_distances for the five measures and the labels classify_NN finds, against outputs of
+    the imported reference (fixture G10: includes a zero vector, the cosine measure's special case)."""
+    from multimodal_amd import evaluation as ev
+    from multimodal_amd.lib import metrics as M
+    g = gi.load('g10_distances')
+    A, B = gi.g10_inputs(g)
+    for name in ('kl_div', 'rev_kl_div', 'sym_kl_div', 'frobenius', 'cosine_diff'):
+        D = ev.all_distances(A, B, getattr(M, name))
+        assert D.shape == (A.shape[0], B.shape[0])
+        assert_allclose(D, g[name], rtol=1e-11, atol=1e-13)
+    labels = list(range(B.shape[0]))
+    assert ev.classify_NN(A, B, labels, M.frobenius) == list(g['found_frobenius'])
+    assert ev.classify_NN(sp.csr_matrix(A), B, labels, M.cosine_diff) == list(g['found_cosine'])
+    # row-paired and vector forms, float32
+    assert_allclose(M.frobenius(A[:7], B), np.sqrt(((A[:7] - B) ** 2).sum(axis=1)), rtol=1e-12)
+    assert_allclose(M.kl_div(A[5], B[2]), g['kl_div'][5, 2], rtol=1e-11)
+    D32 = ev.all_distances(A.astype(np.float32), B.astype(np.float32), M.sym_kl_div)
+    assert D32.dtype == np.float32
+    assert_allclose(D32, g['sym_kl_div'], rtol=2e-5, atol=1e-5)
+
+    def unknown(a, b, axis=-1):
+        return 0
+    with pytest.raises(ValueError):
+        ev.all_distances(A, B, unknown)
+    assert ev.found_labels_to_score([1, 2, 3, 4], [1, 2, 0, 4]) == 0.75

@@ -154,6 +154,13 @@ def test_g9_sparse_branch_fit_transform_and_stop():
     assert abs(ed[-1] - errors[-1]) > 1e-9 * abs(errors[-1])
 
 
+def test_g10_pairwise_measures():
+    g = gi.load('g10_distances')
+    A, B = gi.g10_inputs(g)
+    for name in ('kl_div', 'rev_kl_div', 'sym_kl_div', 'frobenius', 'cosine_diff'):
+        assert_allclose(orc.pairwise_distances(A, B, name), g[name], rtol=1e-12, atol=1e-300)
+
+
 def test_g7_float32_reference_run():
     g = gi.load('g7_float32')
     k = int(g['k'])
