@@ -333,10 +333,17 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
     if (c->profiling) ev = begin_event(c, c->ev_row);
     hipLaunchKernelGGL((k_sp_transpose_H<T>), dim3(grid_for(hk)), dim3(256), 0, c->stream, (const T *)c->H,
                        (T *)c->HT, c->k, c->f, (const DevState *)c->st);
-    hipLaunchKernelGGL((k_sp_q<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, (const int64_t *)c->sp_indptr,
-                       (const int64_t *)c->sp_indices, (const T *)c->sp_data, (const T *)c->W[c->cur],
-                       (const T *)c->HT, (T *)c->sp_q, c->sp_row_loss, c->k, (T)eps, write_q,
-                       (const DevState *)c->st);
+#define KL_SPQ_ARGS (const int64_t *)c->sp_indptr, (const int64_t *)c->sp_indices, (const T *)c->sp_data, \
+        (const T *)c->W[c->cur], (const T *)c->HT, (T *)c->sp_q, c->sp_row_loss, c->k, (T)eps, write_q, (const DevState *)c->st
+    switch ((int)((c->k + 63) / 64)) {
+        case 1: hipLaunchKernelGGL((k_sp_q<T, 1>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
+        case 2: hipLaunchKernelGGL((k_sp_q<T, 2>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
+        case 3: case 4: hipLaunchKernelGGL((k_sp_q<T, 4>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
+        case 5: case 6: case 7: case 8:
+            hipLaunchKernelGGL((k_sp_q<T, 8>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
+        default: hipLaunchKernelGGL((k_sp_q_anyk<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
+    }
+#undef KL_SPQ_ARGS
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     hipLaunchKernelGGL((k_sp_colsum_part<T>), dim3((unsigned)c->sp_nblk), dim3(256), 0, c->stream,
@@ -371,7 +378,8 @@ void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
 template <typename T>
 void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
     if (c->sparse) {        // Q . H^T over the stored entries (qsrc: the ratio values, or X's values for W0)
-        hipLaunchKernelGGL((k_sp_w<T>), dim3((unsigned)c->n), dim3(256), 0, c->stream, (const int64_t *)c->sp_indptr,
+        const int spw_threads = (int)std::min<int64_t>(256, (c->k + 63) / 64 * 64);
+        hipLaunchKernelGGL((k_sp_w<T>), dim3((unsigned)c->n), dim3(spw_threads), 0, c->stream, (const int64_t *)c->sp_indptr,
                            (const int64_t *)c->sp_indices, (const T *)qsrc, (const T *)c->W[c->cur], (const T *)c->HT,
                            (T *)c->W[c->cur ^ 1], c->k, multiply, (const DevState *)c->st);
         HIPCHK(hipGetLastError());
@@ -391,7 +399,8 @@ void exact_N(klnmf_ctx *c, int widx) {
     if (c->sparse) {        // W^T . Q, one block per feature column (CSC order)
         EventPair evs{};
         if (c->profiling) evs = begin_event(c, c->ev_col);
-        hipLaunchKernelGGL((k_sp_n<T>), dim3((unsigned)c->f), dim3(256), 0, c->stream, (const int64_t *)c->csc_indptr,
+        const int spn_threads = (int)std::min<int64_t>(256, (c->k + 63) / 64 * 64);
+        hipLaunchKernelGGL((k_sp_n<T>), dim3((unsigned)c->f), dim3(spn_threads), 0, c->stream, (const int64_t *)c->csc_indptr,
                            (const int64_t *)c->csc_rows, (const int64_t *)c->csc_perm, (const T *)c->sp_q,
                            (const T *)c->W[widx], (T *)c->numer, c->k, c->f, (const DevState *)c->st);
         HIPCHK(hipGetLastError());

@@ -26,11 +26,93 @@ __global__ void k_sp_transpose_H(const T *H, T *HT, int64_t k, int64_t f, const 
     }
 }
 
-// One wave per row: q_p = (x_p + eps) / (W_i . H_:,j_p + eps), loss partial of the row (fp64).
+// Lane u of the wave receives the value lane u holds in `v`, as a wave-uniform (scalar) number.
+__device__ __forceinline__ int64_t lane_value(int64_t v, int u) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, u);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), u);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float lane_value(float v, int u) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), u));
+}
+__device__ __forceinline__ double lane_value(double v, int u) {
+    return __longlong_as_double(lane_value((int64_t)__double_as_longlong(v), u));
+}
+
+// N vectors of 64 lanes -> their N sums, sum u ending in the lanes whose low bits equal u: at each level the
+// vectors are paired (u, u + N/2), a lane keeps the half its bit selects and receives the other lane's
+// contribution to it, so the number of live vectors halves per exchange: N - 1 exchanges for N sums
+// instead of N * log2(64), and a fixed summation order.
+template <typename T, int N>
+struct LaneTransposeSum {
+    static __device__ __forceinline__ T run(const T (&v)[N], int lane) {
+        constexpr int H = N / 2;
+        T r[H];
+        const bool hi = (lane & H) != 0;
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const T keep = hi ? v[u + H] : v[u];
+            const T send = hi ? v[u] : v[u + H];
+            r[u] = keep + __shfl_xor(send, H);
+        }
+        return LaneTransposeSum<T, H>::run(r, lane);
+    }
+};
 template <typename T>
+struct LaneTransposeSum<T, 1> {
+    static __device__ __forceinline__ T run(const T (&v)[1], int) { return v[0]; }
+};
+
+// One wave per row: q_p = (x_p + eps) / (W_i . H_:,j_p + eps), loss partial of the row (fp64).
+// The wave takes 64 stored entries at a time.  Lane l holds components l, l+64, ... of the row of W in
+// registers; for entry u every lane reads the same components of H^T's row j_u (one coalesced k-vector at a
+// wave-uniform address), which leaves 64 vectors of per-lane partial products; LaneTransposeSum turns them
+// into the 64 dot products, one per lane, and the division and the logarithm run with all lanes active.
+// (Measured on the 11 M-entry test matrix, fp64: lane-per-entry with a sequential k-loop 3.0 ms -- every
+// lane walks a different row of H^T; one entry at a time with a wave reduction and lane 0 taking the
+// logarithm 2.7 ms -- the fp64 log of one lane costs the wave as much as 64 of them; this version: see
+// DESIGN 4.5.)
+template <typename T, int KC>      // KC = ceil(k / 64) <= 8
 __global__ __launch_bounds__(64) void k_sp_q(const int64_t *indptr, const int64_t *indices, const T *data, const T *W,
                                               const T *HT, T *q, double *row_loss, int64_t k, T eps, int write_q,
                                               const DevState *st) {
+    if (st && st->stop) return;
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    T w[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) w[c] = (64 * c + lane < k) ? W[i * k + 64 * c + lane] : T(0);
+    double local = 0;
+    const int64_t p0 = indptr[i], p1 = indptr[i + 1];
+    for (int64_t p = p0; p < p1; p += 64) {
+        const bool mine = p + lane < p1;
+        const int64_t my_j = mine ? indices[p + lane] : 0;      // past the end: row 0 of H^T, result unused
+        T part[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+            const T *h = HT + lane_value(my_j, u) * k;
+            part[u] = T(0);
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                if (64 * c + lane < k) part[u] += w[c] * h[64 * c + lane];
+        }
+        const T wh = LaneTransposeSum<T, 64>::run(part, lane);
+        if (mine) {
+            const T x = data[p + lane];
+            const T qq = (x + eps) / (wh + eps);
+            if (write_q) q[p + lane] = qq;
+            local += (double)(x * log(qq)) - (double)x;
+        }
+    }
+    local = wave_sum(local);
+    if (lane == 0) row_loss[i] = local;
+}
+
+// General k (> 512): every lane takes its own entries and loops over the components.
+template <typename T>
+__global__ __launch_bounds__(64) void k_sp_q_anyk(const int64_t *indptr, const int64_t *indices, const T *data, const T *W,
+                                                   const T *HT, T *q, double *row_loss, int64_t k, T eps, int write_q,
+                                                   const DevState *st) {
     if (st && st->stop) return;
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
@@ -50,28 +132,81 @@ __global__ __launch_bounds__(64) void k_sp_q(const int64_t *indptr, const int64_
 }
 
 // W_new[i][a] = (multiply ? W[i][a] : 1) * sum_{p in row i} v_p * H[a][j_p]      (v = q, or x for W0 = X.H0^T)
+// Thread a of the block owns component a.  Each wave fetches the row's (j_p, v_p) 64 at a time with one
+// coalesced load and hands them round as wave-uniform values, so the gathers of H^T's rows are independent
+// loads at scalar addresses that the hardware can keep in flight together.
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_w(const int64_t *indptr, const int64_t *indices, const T *v, const T *Wold,
                                                const T *HT, T *Wnew, int64_t k, int multiply, const DevState *st) {
     if (st && st->stop) return;
     const int64_t i = blockIdx.x;
-    for (int64_t a = threadIdx.x; a < k; a += blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = indptr[i], p1 = indptr[i + 1];
+    for (int64_t a0 = 0; a0 < k; a0 += blockDim.x) {
+        const int64_t a = a0 + threadIdx.x;
+        const bool live = a < k;
         T s = T(0);
-        for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) s += v[p] * HT[indices[p] * k + a];
-        Wnew[i * k + a] = multiply ? Wold[i * k + a] * s : s;
+        for (int64_t p = p0; p < p1; p += 64) {
+            const bool mine = p + lane < p1;
+            const int64_t my_j = mine ? indices[p + lane] : 0;
+            const T my_v = mine ? v[p + lane] : T(0);               // past the end: adds 0 * H^T[0][a]
+            const int cnt = (int)min((int64_t)64, p1 - p);
+            if (cnt == 64) {
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+                    const int64_t ju = lane_value(my_j, u);
+                    const T vu = lane_value(my_v, u);
+                    const T hv = live ? HT[ju * k + a] : T(0);
+                    s += vu * hv;
+                }
+            } else {
+                for (int u = 0; u < cnt; ++u) {                     // (exchange outside the `live` select: a
+                    const int64_t ju = __shfl(my_j, u);             //  lane-exchange only sees active lanes)
+                    const T vu = __shfl(my_v, u);
+                    const T hv = live ? HT[ju * k + a] : T(0);
+                    s += vu * hv;
+                }
+            }
+        }
+        if (live) Wnew[i * k + a] = multiply ? Wold[i * k + a] * s : s;
     }
 }
 
-// numer[a][j] = sum_{p in column j} W[row_p][a] * q[perm_p]
+// numer[a][j] = sum_{p in column j} W[row_p][a] * q[perm_p]          (same scheme over the CSC arrays)
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_n(const int64_t *csc_indptr, const int64_t *csc_rows, const int64_t *csc_perm,
                                                const T *q, const T *W, T *numer, int64_t k, int64_t f, const DevState *st) {
     if (st && st->stop) return;
     const int64_t j = blockIdx.x;
-    for (int64_t a = threadIdx.x; a < k; a += blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = csc_indptr[j], p1 = csc_indptr[j + 1];
+    for (int64_t a0 = 0; a0 < k; a0 += blockDim.x) {
+        const int64_t a = a0 + threadIdx.x;
+        const bool live = a < k;
         T s = T(0);
-        for (int64_t p = csc_indptr[j]; p < csc_indptr[j + 1]; ++p) s += W[csc_rows[p] * k + a] * q[csc_perm[p]];
-        numer[a * f + j] = s;
+        for (int64_t p = p0; p < p1; p += 64) {
+            const bool mine = p + lane < p1;
+            const int64_t my_i = mine ? csc_rows[p + lane] : 0;
+            const T my_q = mine ? q[csc_perm[p + lane]] : T(0);
+            const int cnt = (int)min((int64_t)64, p1 - p);
+            if (cnt == 64) {
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+                    const int64_t iu = lane_value(my_i, u);
+                    const T qu = lane_value(my_q, u);
+                    const T wv = live ? W[iu * k + a] : T(0);
+                    s += wv * qu;
+                }
+            } else {
+                for (int u = 0; u < cnt; ++u) {
+                    const int64_t iu = __shfl(my_i, u);
+                    const T qu = __shfl(my_q, u);
+                    const T wv = live ? W[iu * k + a] : T(0);
+                    s += wv * qu;
+                }
+            }
+        }
+        if (live) numer[a * f + j] = s;
     }
 }
 
