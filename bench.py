@@ -209,8 +209,23 @@ def main():
         row_ms = prof['rowpass_ms'] / max(1, prof['rowpass_launches'])
         col_ms = prof['colpass_ms'] / max(1, prof['colpass_launches'])
         flops_row = 4.0 * n_local * f * k          # W.H and Q.H^T, unpadded k
-        flops_col = 2.0 * n_local * f * k          # W_new^T.Q (the recomputed W.H is not counted)
+        flops_col = 2.0 * n_local * f * k          # W_new^T.Q
         vbytes = 2 if args.precision == 'bf16' else 4
+        pingpong = args.precision == 'bf16' and k <= 224 and os.environ.get('KLNMF_ROWPASS', '4') == '4'
+        # the H rule runs on the ratios the row pass stores (2 B per element of V) unless the recomputing kernel is forced
+        stored_q = pingpong and os.environ.get('KLNMF_COLPASS', '2') in ('2', '3')
+        # bytes the row-pass launch must move by its contract: V once, W fp32 in and out, W bf16 in and out,
+        # and -- stored-ratio schedule -- the ratio tiles out
+        bytes_row = n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2) + (n_local * f * 2 if stored_q else 0)
+        bytes_col = (n_local * f * 2 + n_local * k * 2) if stored_q else (n_local * f * vbytes + 2 * n_local * k * 2)
+        row_tflops = flops_row / (row_ms * 1e-3) / 1e12 if row_ms > 0 else None
+        row_gbs = bytes_row / (row_ms * 1e-3) / 1e9 if row_ms > 0 else None
+        mfma_view = {'achieved': row_tflops, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': row_tflops / PEAK_BF16_TFLOPS if row_tflops else None}
+        hbm_view = {'achieved': row_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': row_gbs / 8000.0 if row_gbs else None}
+        # binding roofline of the launch = the larger of the two lower bounds (t_min = max(flops/P, bytes/BW))
+        hbm_bound = bytes_row / 8000e9 > flops_row / (PEAK_BF16_TFLOPS * 1e12)
+        head, other = (hbm_view, mfma_view) if hbm_bound else (mfma_view, hbm_view)
         out = {
             'metric': 'nmf_update_iterations_per_sec',
             'value': its,
@@ -236,28 +251,24 @@ def main():
             'loss_finite_and_decreasing': bool(len(errors) > 1 and all(e == e and abs(e) != float('inf') for e in errors)
                                                and all(b < a for a, b in zip(errors, errors[1:]))),
             'device': info,
-            'roofline': {
-                'kernel': ('k_rowpass4' if (args.precision == 'bf16' and k <= 224 and os.environ.get('KLNMF_ROWPASS', '4') == '4')
-                           else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule)',
-                'bound': 'mfma',
-                'achieved': flops_row / (row_ms * 1e-3) / 1e12 if row_ms > 0 else None,
-                'peak': PEAK_BF16_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': (flops_row / (row_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if row_ms > 0 else None,
-                'traffic': measured_traffic(args, n_local),
-                'avg_launch_ms': row_ms,
-                'launches': prof['rowpass_launches'],
-                'algorithmic_flops_per_launch': flops_row,
-                'algorithmic_hbm_bytes_per_launch': n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2),
-                # the kernel sits on the ridge (309 flop/B algorithmic vs 2500/8 = 312): the HBM view of the same launch
-                'hbm': {'achieved': (n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2)) / (row_ms * 1e-3) / 1e9 if row_ms > 0 else None,
-                        'peak': 8000.0, 'unit': 'GB/s',
-                        'frac': (n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2)) / (row_ms * 1e-3) / 1e9 / 8000.0 if row_ms > 0 else None},
-            },
+            'roofline': dict(
+                kernel=('k_rowpass4' if pingpong else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule'
+                       + (', ratio tiles stored for the H rule)' if stored_q else ')'),
+                bound='hbm' if hbm_bound else 'mfma', achieved=head['achieved'], peak=head['peak'], unit=head['unit'],
+                frac=head['frac'], traffic=measured_traffic(args, n_local),
+                avg_launch_ms=row_ms, launches=prof['rowpass_launches'],
+                algorithmic_flops_per_launch=flops_row, algorithmic_hbm_bytes_per_launch=bytes_row,
+                t_min_ms={'mfma': flops_row / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 'hbm': bytes_row / 8000e9 * 1e3},
+                **{('mfma' if hbm_bound else 'hbm'): other}),
             'kernels': {
-                'k_colpass': {'avg_launch_ms': col_ms, 'launches': prof['colpass_launches'],
-                              'algorithmic_tflops': flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
-                              'executed_tflops': 2 * flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None},
+                ('k_colpass_q2' if stored_q else 'k_colpass'): {
+                    'avg_launch_ms': col_ms, 'launches': prof['colpass_launches'],
+                    'algorithmic_tflops': flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
+                    'executed_tflops': (1 if stored_q else 2) * flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
+                    'algorithmic_hbm_bytes_per_launch': bytes_col,
+                    'hbm_gbs': bytes_col / (col_ms * 1e-3) / 1e9 if col_ms > 0 else None,
+                    'hbm_frac': bytes_col / (col_ms * 1e-3) / 1e9 / 8000.0 if col_ms > 0 else None},
+                'iteration_hbm_bytes_by_contract': bytes_row + bytes_col,
                 'iteration_algorithmic_tflops': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12,
                 'iteration_frac_of_bf16_peak': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
             },

@@ -1,0 +1,171 @@
+// Column pass on stored ratios, pipelined (the product kernel of the H rule in the bf16 mode).
+//
+//   numer[a][j] = sum_i W_new[i][a] * Q[i][j]          (nmf.py:347-349, Q = ratio of the OLD W and H)
+//
+// Q comes from the ping-pong row pass (mfma4.hip.h), which stores its packed bf16 MFMA operands as it applies
+// the W rule; see k_colpass_q in mfma.hip.h for the tile layout (Qt) and for how the transposition
+// "row-pass lane = one row, several columns" -> "this kernel's lane = one column, several rows" happens on
+// the way through LDS (regrouping global_load_lds copy + ds_read_b64_tr_b16).  That first kernel is kept as
+// the readable reference of the data path (KLNMF_COLPASS=3); it runs one 64-row stage ahead and drains all
+// copies at every stage barrier, so each stage pays the full HBM latency (2.1 us per stage measured,
+// against 0.9 us of matrix work).  This one keeps NB-1 stages of 32 rows in flight:
+//
+//   * NB distinct LDS objects, each [W_new rows of the stage | the 8 waves' ratio tiles]; a workgroup is 8 waves,
+//     wave w owns column tile 8*cb + w and all KP components (KT accumulator blocks);
+//   * stage s computes on object s % NB while the copies of stages s+1 .. s+NB-1 are in flight; its copy of
+//     stage s+NB-1 goes into the object stage s-1 used, which every wave has left (barrier at the end of s-1);
+//   * every wave issues the same number of copy instructions per stage (the W_new copy is rounded up to whole
+//     8 KiB rounds, reading into the next stage's rows), so "my copies of stage s+1 have landed" is the counted
+//     wait vmcnt((NB-2) * OPS); the barrier after it makes that true for all waves.  Only LDS copies are in
+//     flight in the loop (no VGPR loads, no stores): counted waits are valid among operations of one kind
+//     (DESIGN.md section 8, h3);
+//   * operand fragments are read with inline-asm LDS reads and counted lgkmcnt waits (helpers of mfma4.hip.h):
+//     the compiler cannot track which object a copy is still in flight into and would drain all of them
+//     before the first read.
+#pragma once
+#include "mfma4.hip.h"
+
+namespace klnmf {
+
+__host__ __device__ constexpr int colq_w_area(int kp) { return round_up(32 * w_ld(kp) * 2, kGldsRound); }
+__host__ __device__ constexpr int colq_obj_bytes(int kp) { return colq_w_area(kp) + kWavesPerWG * kQTile; }
+#ifndef KL_COLQ_NB
+#define KL_COLQ_NB 4
+#endif
+
+__device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+template <int KT, int NB>
+__global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
+    static_assert(kWaves4 == kWavesPerWG, "uses the 8-wave copy helpers of mfma4.hip.h");
+    constexpr int KP = 32 * KT;
+    constexpr int WLD = w_ld(KP);
+    constexpr int WLDB = WLD * 2;
+    constexpr int WST = 32 * WLDB;                 // bytes of W_new per 32-row stage in global memory
+    constexpr int WA = colq_w_area(KP);            // copied per stage (whole rounds)
+    constexpr int OBJ = colq_obj_bytes(KP);
+    constexpr int OPS = WA / kGldsRound + kQTile / 1024;     // copy instructions per wave and stage
+    constexpr int N3 = 2 * KT;
+    static_assert(NB >= 3 && NB <= 5 && NB * OBJ <= 160 * 1024, "LDS budget");
+    static_assert((NB - 2) * OPS <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) unsigned char o0[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char o1[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char o2[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char o3[NB > 3 ? OBJ : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char o4[NB > 4 ? OBJ : 16];
+    if (a.st->stop) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;                       // XCD-aware block -> (row chunk, column block)
+    int lin = blockIdx.x;
+    if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = lin / a.ncb, cb = lin % a.ncb;
+    const int ct_raw = cb * kWavesPerWG + wave;
+    const bool active = ct_raw < a.nct;            // wave-uniform
+    const int ct = active ? ct_raw : a.nct - 1;
+    // stages of 32 rows; the chunk decomposition of the host counts 64-row stages
+    const int sbeg = 2 * chunk * a.stages_per_chunk;
+    const int send = min(a.nrt, sbeg + 2 * a.stages_per_chunk);
+    if (sbeg >= send) {                            // empty chunk: its slab of partials must still be defined
+        if (active) {
+            float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+            for (int c = h; c < KP; c += 2) np[(int64_t)c * a.f_pad] = 0.f;
+        }
+        return;
+    }
+
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    //  W_new (A operand): rows = samples 4h+tq (+8 for the second read), cols = components
+    const unsigned off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
+    const unsigned off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
+    //  ratios (B operand): row 4h+tq (+8j), columns 16*half + 4*tp.. = slot 2*row + (tp&1), group 2*half + (tp>>1)
+    const unsigned off_q = WA + wave * kQTile + (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8;
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    const unsigned char *wn = (const unsigned char *)a.Wb_new;
+    // copy piece P = 64p + lane of a tile (16 bytes at LDS offset 16P): slot P>>1, operand P&1
+    const unsigned char *qt = a.Qt + (int64_t)ct * a.nrt * kQTile + (lane & 1) * 1024 +
+                              ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+
+    auto obj = [&](int o) -> KL_LDS unsigned char * {      // o static after unrolling
+        return (KL_LDS unsigned char *)(o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o == 3 ? o3 : o4);
+    };
+    auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
+    auto stage_in = [&](int o, int sg) {
+        sg = min(sg, send - 1);                    // past the end: re-copy the last stage (uniform instruction count)
+        glds_copy_exact<WA>(wn + (int64_t)sg * WST, obj(o), tid);
+        const unsigned char *qs = qt + (int64_t)sg * kQTile;
+#pragma unroll
+        for (int p = 0; p < kQTile / 1024; ++p)
+            __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + p * 256),
+                                             (KL_LDS void *)(obj(o) + WA + wave * kQTile + 1024 * p), 16, 0, 0);
+    };
+    auto compute = [&](unsigned base) {
+        bf16x8 ring[3];
+        s16x4 q0, q1, q2, q3;
+        lds_read_tr(q0, base + off_q);
+        lds_read_tr(q1, base + off_q + 8 * 64);
+        lds_read_tr(q2, base + off_q + 16 * 64);
+        lds_read_tr(q3, base + off_q + 24 * 64);
+        const unsigned t0 = base + off_tr0, t1 = base + off_tr1;
+        auto fetch = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j < N3) lds_read_tr_pair<(16 * (j & 1)) * WLDB + 64 * (j >> 1)>(ring[j % 3], t0, t1);
+        };
+        fetch(std::integral_constant<int, 0>{});
+        fetch(std::integral_constant<int, 1>{});
+        // the ratio reads are older than every W_new read: they have landed when fragment 0 has
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(ring[0]));
+        // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7));
+        static_for<0, N3>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            fetch(std::integral_constant<int, j + 2>{});
+            constexpr int younger = (j + 2 < N3 ? 2 : N3 - 1 - j);      // fragments issued after fragment j
+            lds_wait<2 * younger>(ring[j % 3]);
+            acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+        });
+    };
+    auto fence = [&]() {          // my copies of the next stage have landed; then everybody's
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * OPS) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: stages sbeg .. sbeg+NB-2 in flight, the first one awaited
+    static_for<0, NB - 1>([&](auto I) { stage_in(decltype(I)::value, sbeg + decltype(I)::value); });
+    fence();
+    for (int s0 = sbeg; s0 < send; s0 += NB) {
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (s0 + i < send) {                                   // uniform
+                stage_in((i + NB - 1) % NB, s0 + i + NB - 1);
+                compute(lds_addr(obj(i)));
+                fence();
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS copy may outlive the workgroup
+
+    if (!active) return;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            np[(int64_t)comp * a.f_pad] = acc[m][e];
+        }
+}
+
+}  // namespace klnmf

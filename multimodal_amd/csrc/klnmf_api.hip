@@ -18,6 +18,7 @@
 #include "sparse.hip.h"
 #include "mfma.hip.h"
 #include "mfma4.hip.h"
+#include "colq.hip.h"
 #include "probe.hip.h"
 
 using namespace klnmf;
@@ -110,6 +111,8 @@ struct klnmf_ctx {
     int64_t n_pad = 0, f_pad = 0, w_rows = 0;
     int nrt = 0, nct = 0, nct_used = 0, nst = 0, ncb = 0, nchunks = 0, stages_per_chunk = 0;
     void *VtA = nullptr, *VtB = nullptr;
+    unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
+    int col_gen = 2;
     float *W32[2] = {nullptr, nullptr};
     __bf16 *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
@@ -242,9 +245,10 @@ void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
     HIPCHK(hipGetLastError());
 }
 
-void fast_rowpass(klnmf_ctx *c, int mode) {
+void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     RowPassArgs a{};
     a.VtA = c->VtA;
+    a.Qt = (store_q && mode == ROW_UPDATE) ? c->Qt : nullptr;
     a.Ht = c->Ht;
     a.Wb_old = c->Wb[c->cur];
     a.W32_old = c->W32[c->cur];
@@ -288,7 +292,42 @@ void fast_rowpass(klnmf_ctx *c, int mode) {
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
 }
 
+void fast_colpass_q(klnmf_ctx *c) {
+    ColPassQArgs a{};
+    a.Qt = c->Qt;
+    a.Wb_new = c->Wb[c->cur ^ 1];
+    a.Npart = c->NpartF;
+    a.st = c->st;
+    a.nrt = c->nrt;
+    a.nct = c->nct_used;
+    a.ncb = c->ncb;
+    a.nchunks = c->nchunks;
+    a.stages_per_chunk = c->stages_per_chunk;
+    a.f_pad = c->f_pad;
+    const int grid = c->ncb * c->nchunks;
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_col);
+#define KL_COLQ_CASE(KTV)                                                                                          \
+    case KTV:                                                                                                      \
+        if (c->col_gen == 3) hipLaunchKernelGGL((k_colpass_q<KTV>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
+        break;
+    switch (c->KT) {
+        KL_COLQ_CASE(1) KL_COLQ_CASE(2) KL_COLQ_CASE(3) KL_COLQ_CASE(4) KL_COLQ_CASE(5) KL_COLQ_CASE(6) KL_COLQ_CASE(7)
+        default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: k > 224 runs on the recomputing kernel");
+    }
+#undef KL_COLQ_CASE
+    HIPCHK(hipGetLastError());
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    const int64_t count = (int64_t)c->KP * c->f_pad;
+    hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4)), dim3(256), 0, c->stream,
+                       (const float *)c->NpartF, c->numerF, count / 4, c->nchunks,
+                       (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
 void fast_colpass(klnmf_ctx *c) {
+    if (c->Qt) { fast_colpass_q(c); return; }
     ColPassArgs a{};
     a.VtB = c->VtB;
     a.HTb = c->HTb;
@@ -444,12 +483,12 @@ void reset_state(klnmf_ctx *c) {
 }
 
 void piece_rowpass(klnmf_ctx *c, int fit) {
-    (void)fit;   // the W rule is the same for fit and transform (nmf.py:251-253)
+    // the W rule is the same for fit and transform (nmf.py:251-253); a fit also keeps the ratios for the H rule
     if (c->is_exact()) {
         EXACT_CALL(c, exact_Q, 1);
         EXACT_CALL(c, exact_W, c->sparse ? c->sp_q : c->Q, 1);
     } else {
-        fast_rowpass(c, ROW_UPDATE);
+        fast_rowpass(c, ROW_UPDATE, fit);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const float2 *)c->loss_part2, (int64_t)c->nrt, (const DevState *)c->st,
                            1.0 / c->v_scale, c->loss_xchg);
@@ -801,8 +840,14 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + 64;
             const size_t vs = c->vsize();
             const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * vs;
+            if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
+            if (const char *g = std::getenv("KLNMF_COLPASS")) c->col_gen = std::atoi(g);
+            // column pass on the ratios the ping-pong row pass stores (k_colpass_q) where that row pass runs;
+            // otherwise the recomputing one, which needs the second, column-tiled copy of V
+            const bool stored_q = c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && c->KT <= 7 && c->col_gen >= 2;
             c->VtA = c->dalloc(vbytes);
-            c->VtB = c->dalloc(vbytes);
+            c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
+            c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;
             for (int i = 0; i < 2; ++i) {
                 c->W32[i] = (float *)c->dalloc((size_t)c->n_pad * c->KP * 4);
                 c->Wb[i] = (__bf16 *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
@@ -811,7 +856,6 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->Ht = (__bf16 *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
             c->Ht4 = (__bf16 *)c->dalloc((size_t)c->nct * h4_tile_bytes(c->KP) + kObj4);
             c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
-            if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
             // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
             // carrier column at 1) and a spare component inside the MFMA-1 contraction range
             c->kc = (c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && c->KT <= 7 && (k % 16) != 0 &&

@@ -217,6 +217,7 @@ struct RowPassArgs {
     float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
     const float *hsum;        // [KP] row sums of the bf16-rounded dictionary (for sum(W.H))
     unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
+    unsigned char *Qt;            // ratio tiles for k_colpass_q ([nct][nrt][2 KiB], see there), or null (ping-pong pass only)
     int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
@@ -636,6 +637,138 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
         }
 }
 
+// ---- column pass on stored ratios ----------------------------------------------------------------
+// The H rule needs W_new^T . Q with the ratio Q of the OLD W and H (nmf.py:347-349) -- exactly what the row
+// pass has in registers, as packed bf16 MFMA operands, when it applies the W rule.  The ping-pong row pass
+// (mfma4.hip.h) stores them (Qt, 2 B per element of V) and this kernel is then a plain streaming product:
+// no second W.H, no division, no V -- half the matrix work of k_colpass and none of its VALU work, for the
+// same bytes read (Q instead of the second copy of V, which is no longer kept) plus the row pass's writes.
+//
+// Qt layout: [column tile][row tile][2 KiB]; a tile is the row pass's two packed operands as its lanes hold
+// them: bytes [16*lane, +16) = b0 and [1024 + 16*lane, +16) = b1 of lane (row i = lane & 31, h' = lane >> 5),
+// element 4g + t of the 16 = column 8g + 4h' + t -- two fully contiguous 1 KiB stores per wave and tile.
+// The row pass needs "one row, several columns" per lane (its contraction runs over columns), this kernel
+// "one column, several rows" (contraction over rows): the transposition happens here, on the way through
+// LDS.  The global -> LDS copy (global_load_lds takes a per-lane source address) regroups the 16-byte pieces
+// so that the 32 bytes of slot 2i + h' are adjacent, and ds_read_b64_tr_b16 -- whose unit is the 8-byte
+// group of 4 consecutive columns of one row, which the layout keeps together -- delivers the transposed
+// fragments; the 32 lanes of a read's first pass touch 256 consecutive bytes (conflict-free).
+struct ColPassQArgs {
+    const unsigned char *Qt;
+    const __bf16 *Wb_new;     // [n_pad(+pad)][w_ld(KP)]
+    float *Npart;             // [nchunks][KP][f_pad]
+    const DevState *st;
+    int nrt, nct, ncb, nchunks, stages_per_chunk;
+    int64_t f_pad;
+};
+constexpr int kQTile = 2048;                                         // bytes of one 32x32 bf16 ratio tile
+__host__ __device__ constexpr int colq_lds_stage(int kp) { return w_stage_lds(kp) + kWavesPerWG * kStageRowTiles * kQTile; }
+
+template <int KT>
+__global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
+    constexpr int KP = 32 * KT;
+    constexpr int WLD = w_ld(KP);
+    constexpr int WLDB = WLD * 2;
+    constexpr int IMG = w_stage_lds(KP);           // W_new image of one stage
+    constexpr int ROUNDS = IMG / kGldsRound;
+    constexpr int RS = kStageRowTiles;
+    constexpr int QW = RS * kQTile;                // one wave's ratio tiles of one stage
+    // two distinct LDS objects (the compiler then knows reads of one do not wait for copies into the other)
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[IMG + kWavesPerWG * QW];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[IMG + kWavesPerWG * QW];
+    if (a.st->stop) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;                       // XCD-aware block -> (row chunk, column block), as k_colpass
+    int lin = blockIdx.x;
+    if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = lin / a.ncb, cb = lin % a.ncb;
+    const int ct_raw = cb * kWavesPerWG + wave;
+    const bool active = ct_raw < a.nct;              // wave-uniform
+    const int ct = active ? ct_raw : a.nct - 1;
+    const int total_stages = a.nrt / RS;
+    const int sbeg = chunk * a.stages_per_chunk;
+    const int send = min(total_stages, sbeg + a.stages_per_chunk);
+
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    //  W_new (A operand): rows = samples 4h+tq (+8 for the second read), cols = components
+    const int off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
+    const int off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
+    //  ratios (B operand): row 4h+tq (+8j), columns 16*half + 4*tp.. = slot 2*row + (tp&1), group 2*half + (tp>>1)
+    const int off_q = (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8 + wave * QW;
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    const unsigned char *wn = (const unsigned char *)a.Wb_new;
+    // copy piece P = 64p + lane of a tile (16 bytes at LDS offset 16P): slot P>>1, operand P&1
+    const unsigned char *qt = a.Qt + (int64_t)ct * a.nrt * kQTile + (lane & 1) * 1024 +
+                              ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+
+    auto stage_in = [&](KL_LDS unsigned char *buf, int sg) {
+        glds_copy(wn + (int64_t)sg * w_stage_bytes(KP), buf, ROUNDS, tid);
+        const unsigned char *qs = qt + (int64_t)sg * QW;           // this wave's RS tiles are consecutive
+#pragma unroll
+        for (int p = 0; p < QW / 1024; ++p)          // tile p>>1, its piece group p&1 (rows 16(p&1) .. +15)
+            __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + (p >> 1) * kQTile + (p & 1) * 256),
+                                             (KL_LDS void *)(buf + IMG + wave * QW + 1024 * p), 16, 0, 0);
+    };
+    auto compute = [&](const KL_LDS unsigned char *img) {
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+            const KL_LDS unsigned char *p30 = img + off_tr0 + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p31 = img + off_tr1 + (32 * u) * WLDB;
+            const KL_LDS unsigned char *pq = img + IMG + off_q + u * kQTile;
+            constexpr int N3 = 2 * KT;
+            bf16x8 ring[3];
+            auto fetch = [&](int j) {
+                if (j < N3) {
+                    const int m = j >> 1, hh = j & 1;
+                    ring[j % 3] = tr_pair(p30 + (16 * hh) * WLDB + (32 * m) * 2, p31 + (16 * hh) * WLDB + (32 * m) * 2);
+                }
+            };
+            fetch(0);
+            fetch(1);
+            // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
+            const bf16x8 b0 = tr_pair(pq, pq + 8 * 64), b1 = tr_pair(pq + 16 * 64, pq + 24 * 64);
+#pragma unroll
+            for (int j = 0; j < N3; ++j) {
+                fetch(j + 2);
+                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+            }
+        }
+    };
+    auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int sg) {
+        if (sg + 1 < send) stage_in(nxt, sg + 1);
+        compute(cur);
+        __syncthreads();
+    };
+
+    KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
+    KL_LDS unsigned char *B = (KL_LDS unsigned char *)bufB;
+    if (sbeg < send) stage_in(A, sbeg);
+    __syncthreads();
+    for (int sg = sbeg; sg < send; sg += 2) {
+        stage(A, B, sg);
+        if (sg + 1 < send) stage(B, A, sg + 1);
+    }
+
+    if (!active) return;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            np[(int64_t)comp * a.f_pad] = acc[m][e];
+        }
+}
+
 // ---- dictionary / coefficient packing ----------------------------------------
 // One block per component row.  do_update: H <- H*num then row-normalise
 // (nmf.py:349-350); always (re)writes the bf16 stage images Ht and the transposed
@@ -755,7 +888,7 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
         const int laneA = i + 32 * ((c >> 2) & 1), eA = 4 * (c >> 3) + (c & 3);
         const int laneB = c + 32 * ((i >> 2) & 1), eB = 4 * (i >> 3) + (i & 3);
         VtA[((rt * nct + ctile) * 64 + laneA) * 16 + eA] = xs;
-        VtB[((ctile * nrt + rt) * 64 + laneB) * 16 + eB] = xs;
+        if (VtB) VtB[((ctile * nrt + rt) * 64 + laneB) * 16 + eB] = xs;      // only the recomputing column pass reads it
         sx += xt;
         cc += (xt > 0 && xv > 0) ? xt * log(xt / xv) - (xt - xv) : (xv - xt);
     }

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         glds_copy_exact<IMG>(ht + (int64_t)tg * IMG, Hobj(o), tid);
     };
     const unsigned char *vlane = vt + lane * 32;             // this lane's 32 bytes of a V tile
+    // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
+    unsigned char *qlane = (a.Qt && active) ? a.Qt + (int64_t)rt * 2048 + lane * 16 : nullptr;
+    const int64_t qstride = (int64_t)a.nrt * 2048;
     f16x8 vreg[4];                                           // V tiles of even / odd column tiles (2 x 16 B each)
     // segment boundary: nothing may be scheduled across it (the MFMAs of an M segment must not sink into the
     // following E segment and vice versa -- that is the whole point of the schedule)
@@ -319,6 +322,15 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         }
         b0 = pack8(q);
         b1 = pack8(q + 8);
+        if (MODE == ROW_UPDATE && qlane) {                  // the ratios, as packed, for the column pass (k_colpass_q)
+#ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
+            unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
+#else
+            unsigned char *qp = qlane + (int64_t)tg * qstride;
+#endif
+            __builtin_nontemporal_store(b0, (bf16x8 *)qp);            // written once, read once by another kernel
+            __builtin_nontemporal_store(b1, (bf16x8 *)(qp + 1024));
+        }
         asm volatile("" : "+v"(s1));                        // keep the loss terms inside this segment
         if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
             const unsigned ra = lds_addr(Hobj(ts % 4));

@@ -504,6 +504,32 @@ def test_rowpass_generations_agree_full_chip(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k', [(2048, 256, 40), (1000, 300, 17), (4096, 1024, 96), (2048, 256, 128),
+                                   (3000, 520, 200), (262144, 512, 200)])
+def test_colpass_generations_agree(monkeypatch, n, f, k):
+    """H rule three ways: on the ratios the row pass stored, pipelined (colq.hip.h, the product kernel) and
+    stage by stage (k_colpass_q) -- same MFMA sequence and summation order per wave: bit-identical -- and
+    by recomputing W.H and the ratio from the second copy of V (k_colpass): the same numbers up to the
+    rounding of one more bf16 product.  Ragged n and f, every accumulator count, several row chunks."""
+    torch = pytest.importorskip('torch')
+    g = torch.Generator(device='cuda').manual_seed(11)
+    X = (torch.rand(n, f, generator=g, device='cuda') * 3).cpu().numpy()
+    H0 = orc.synthetic_H0(11, f, k)
+    out = {}
+    for gen in ('1', '2', '3'):
+        monkeypatch.setenv('KLNMF_COLPASS', gen)
+        m, W, errors, _ = fit_gpu(X, H0, k, 4, 0, precision='bf16')
+        out[gen] = (W, m.components_.copy(), errors)
+    assert np.all(np.isfinite(out['2'][2])) and np.all(np.diff(out['2'][2]) < 0)
+    np.testing.assert_array_equal(out['2'][0], out['3'][0])
+    np.testing.assert_array_equal(out['2'][1], out['3'][1])
+    assert_allclose(out['2'][2], out['3'][2], rtol=1e-12)      # sum(x) of the upload is an atomic sum: last-bit noise between runs
+    assert_allclose(out['2'][0], out['1'][0], rtol=2e-4, atol=1e-5 * np.abs(out['1'][0]).max())
+    assert_allclose(out['2'][1], out['1'][1], rtol=2e-4, atol=1e-5 * np.abs(out['1'][1]).max())
+    assert_allclose(out['2'][2], out['1'][2], rtol=1e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dt,rtol', [(np.float64, 1e-12), (np.float32, 2e-5)])
 def test_matmul_reconstruction(dt, rtol):
     """klnmf_matmul = the `internal.dot(dico)` of reconstruct_modality / reconstruct_modalities
