@@ -1,6 +1,9 @@
 // bf16-MFMA kernels of the KL-NMF update for gfx950 (CDNA4).
 //
-// One fit iteration = two streaming passes over V:
+// One fit iteration = a row pass over V and a column pass for the H rule.  This file
+// holds the generation-1 row pass, the recomputing column pass and the first column pass on stored ratios;
+// the product kernels of the bf16 mode are the ping-pong row pass (mfma4.hip.h), which also stores the
+// ratio tiles, and the pipelined column pass that streams them (colq.hip.h).
 //
 //   k_rowpass  a wave owns 32 sample rows (its W block stays in registers as the
 //              MFMA B operand) and streams the dictionary through LDS, 64 feature
@@ -22,7 +25,7 @@
 // (W' = cW, eps' = c*eps; H and Q are scale-free) and W / the loss are divided
 // by c on the way out -- exact, c is a power of two.
 //
-// Neither W.H nor Q ever goes to HBM.  V is stored twice, pre-tiled so that each
+// With these two kernels neither W.H nor Q goes to HBM and V is stored twice, pre-tiled so that each
 // lane's 16 elements of a 32x32 tile are contiguous in exactly the MFMA
 // accumulator order of the pass that reads it (layout A: sample on the lane,
 // layout B: feature on the lane) -> every V access is a fully coalesced
