@@ -274,6 +274,19 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         ph[0] += t1 - t0; ph[3] += t3 - t1;
 #endif
     };
+    // the ratios of tile tg as packed in b0 / b1, for the column pass (k_colpass_q2): written once, read once by
+    // another kernel -> non-temporal
+    auto store_q = [&](int tg) {
+        if (MODE == ROW_UPDATE && qlane) {
+#ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
+            unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
+#else
+            unsigned char *qp = qlane + (int64_t)tg * qstride;
+#endif
+            __builtin_nontemporal_store(b0, (bf16x8 *)qp);
+            __builtin_nontemporal_store(b1, (bf16x8 *)(qp + 1024));
+        }
+    };
     // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
     auto seg_E = [&](auto TS, int tg) {
         constexpr int ts = decltype(TS)::value;
@@ -292,6 +305,9 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
 #ifdef KL_STAMPS
         { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
+#endif
+#ifndef KL_QSTORE_EARLY   // the previous tile's ratios (still in b0 / b1) leave here, a whole tile interval before the next wait
+        if (tg > 0) store_q(tg - 1);
 #endif
 #ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
         v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)((tg + 1) & 3) * TB);
@@ -322,15 +338,9 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         }
         b0 = pack8(q);
         b1 = pack8(q + 8);
-        if (MODE == ROW_UPDATE && qlane) {                  // the ratios, as packed, for the column pass (k_colpass_q)
-#ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
-            unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
-#else
-            unsigned char *qp = qlane + (int64_t)tg * qstride;
+#ifdef KL_QSTORE_EARLY    // variant: store as soon as packed (the wait at the start of the next E segment then
+        store_q(tg);          // includes stores issued half a tile interval ago: row pass 4.16 instead of 4.10 ms at C4)
 #endif
-            __builtin_nontemporal_store(b0, (bf16x8 *)qp);            // written once, read once by another kernel
-            __builtin_nontemporal_store(b1, (bf16x8 *)(qp + 1024));
-        }
         asm volatile("" : "+v"(s1));                        // keep the loss terms inside this segment
         if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
             const unsigned ra = lds_addr(Hobj(ts % 4));
@@ -378,6 +388,9 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
     // ---- tail: MFMA-2 of the last tile (no copies are in flight into anything it reads; no barrier needed)
     tail = true;
     seg_M(std::integral_constant<int, 0>{}, a.nct);
+#ifndef KL_QSTORE_EARLY
+    store_q(a.nct - 1);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
 #ifdef KL_STAMPS
     unsigned long long tkL; KL_STAMP(tkL);
