@@ -211,9 +211,10 @@ def main():
         flops_row = 4.0 * n_local * f * k          # W.H and Q.H^T, unpadded k
         flops_col = 2.0 * n_local * f * k          # W_new^T.Q
         vbytes = 2 if args.precision == 'bf16' else 4
-        pingpong = args.precision == 'bf16' and k <= 224 and os.environ.get('KLNMF_ROWPASS', '4') == '4'
+        pingpong = (args.precision == 'bf16' and (k <= 224 or 256 < k <= 512)
+                    and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         # the H rule runs on the ratios the row pass stores (2 B per element of V) unless the recomputing kernel is forced
-        stored_q = pingpong and os.environ.get('KLNMF_COLPASS', '2') in ('2', '3')
+        stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         # bytes the row-pass launch must move by its contract: V once, W fp32 in and out, W bf16 in and out,
         # and -- stored-ratio schedule -- the ratio tiles out
         bytes_row = n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2) + (n_local * f * 2 if stored_q else 0)

@@ -22,13 +22,16 @@
 //   * operand fragments are read with inline-asm LDS reads and counted lgkmcnt waits (helpers of mfma4.hip.h):
 //     the compiler cannot track which object a copy is still in flight into and would drain all of them
 //     before the first read.
+//   * KSPLIT = 2 (KT > 8, k <= 512): the 8 waves are 4 column tiles x 2 halves of the component range, so that a
+//     wave's accumulators (KT/2 blocks) fit 2 waves per SIMD; the two waves of a column tile read the same ratio
+//     tile.  The W_new stage is 40 KiB at KP = 512 and only NB = 3 objects fit: two stages in flight.
 #pragma once
 #include "mfma4.hip.h"
 
 namespace klnmf {
 
 __host__ __device__ constexpr int colq_w_area(int kp) { return round_up(32 * w_ld(kp) * 2, kGldsRound); }
-__host__ __device__ constexpr int colq_obj_bytes(int kp) { return colq_w_area(kp) + kWavesPerWG * kQTile; }
+__host__ __device__ constexpr int colq_obj_bytes(int kp, int ksplit) { return colq_w_area(kp) + kWavesPerWG / ksplit * kQTile; }
 #ifndef KL_COLQ_NB
 #define KL_COLQ_NB 4
 #endif
@@ -37,17 +40,20 @@ __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
 }
 
-template <int KT, int NB>
+template <int KT, int NB, int KSPLIT = 1>
 __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
-    static_assert(kWaves4 == kWavesPerWG, "uses the 8-wave copy helpers of mfma4.hip.h");
+    static_assert(kWavesPerWG == 8 && (KSPLIT == 1 || KSPLIT == 2) && KT % KSPLIT == 0, "wave decomposition");
+    constexpr int CTW = kWavesPerWG / KSPLIT;      // column tiles per workgroup
+    constexpr int KTW = KT / KSPLIT;               // accumulator blocks per wave
     constexpr int KP = 32 * KT;
     constexpr int WLD = w_ld(KP);
     constexpr int WLDB = WLD * 2;
     constexpr int WST = 32 * WLDB;                 // bytes of W_new per 32-row stage in global memory
     constexpr int WA = colq_w_area(KP);            // copied per stage (whole rounds)
-    constexpr int OBJ = colq_obj_bytes(KP);
-    constexpr int OPS = WA / kGldsRound + kQTile / 1024;     // copy instructions per wave and stage
-    constexpr int N3 = 2 * KT;
+    constexpr int OBJ = colq_obj_bytes(KP, KSPLIT);
+    constexpr int QP = 2 / KSPLIT;                 // 1 KiB pieces of its column tile's ratio tile a wave copies
+    constexpr int OPS = WA / kGldsRound + QP;      // copy instructions per wave and stage
+    constexpr int N3 = 2 * KTW;
     static_assert(NB >= 3 && NB <= 5 && NB * OBJ <= 160 * 1024, "LDS budget");
     static_assert((NB - 2) * OPS <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char o0[OBJ];
@@ -63,7 +69,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     int lin = blockIdx.x;
     if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int chunk = lin / a.ncb, cb = lin % a.ncb;
-    const int ct_raw = cb * kWavesPerWG + wave;
+    const int ctl = wave % CTW, kh = wave / CTW;   // column tile inside the workgroup, half of the component range
+    const int ct_raw = cb * CTW + ctl;
     const bool active = ct_raw < a.nct;            // wave-uniform
     const int ct = active ? ct_raw : a.nct - 1;
     // stages of 32 rows; the chunk decomposition of the host counts 64-row stages
@@ -72,21 +79,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     if (sbeg >= send) {                            // empty chunk: its slab of partials must still be defined
         if (active) {
             float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
-            for (int c = h; c < KP; c += 2) np[(int64_t)c * a.f_pad] = 0.f;
+            for (int c = 32 * KTW * kh + h; c < 32 * KTW * (kh + 1); c += 2) np[(int64_t)c * a.f_pad] = 0.f;
         }
         return;
     }
 
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
     //  W_new (A operand): rows = samples 4h+tq (+8 for the second read), cols = components
-    const unsigned off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
-    const unsigned off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
+    const unsigned off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp) + 64 * KTW * kh;
+    const unsigned off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp) + 64 * KTW * kh;
     //  ratios (B operand): row 4h+tq (+8j), columns 16*half + 4*tp.. = slot 2*row + (tp&1), group 2*half + (tp>>1)
-    const unsigned off_q = WA + wave * kQTile + (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8;
+    const unsigned off_q = WA + ctl * kQTile + (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8;
 
-    f32x16 acc[KT];
+    f32x16 acc[KTW];
 #pragma unroll
-    for (int m = 0; m < KT; ++m)
+    for (int m = 0; m < KTW; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
@@ -101,12 +108,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
     auto stage_in = [&](int o, int sg) {
         sg = min(sg, send - 1);                    // past the end: re-copy the last stage (uniform instruction count)
-        glds_copy_exact<WA>(wn + (int64_t)sg * WST, obj(o), tid);
+        glds_copy_exact<WA, kWavesPerWG>(wn + (int64_t)sg * WST, obj(o), tid);
         const unsigned char *qs = qt + (int64_t)sg * kQTile;
 #pragma unroll
-        for (int p = 0; p < kQTile / 1024; ++p)
+        for (int pp = 0; pp < QP; ++pp) {
+            const int p = kh * QP + pp;            // KSPLIT = 2: the two waves of a column tile copy one piece each
             __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + p * 256),
-                                             (KL_LDS void *)(obj(o) + WA + wave * kQTile + 1024 * p), 16, 0, 0);
+                                             (KL_LDS void *)(obj(o) + WA + ctl * kQTile + 1024 * p), 16, 0, 0);
+        }
     };
     auto compute = [&](unsigned base) {
         bf16x8 ring[3];
@@ -160,10 +169,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
     float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
 #pragma unroll
-    for (int m = 0; m < KT; ++m)
+    for (int m = 0; m < KTW; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            const int comp = 32 * (KTW * kh + m) + 8 * (e >> 2) + 4 * h + (e & 3);
             np[(int64_t)comp * a.f_pad] = acc[m][e];
         }
 }

@@ -133,6 +133,8 @@ struct klnmf_ctx {
     std::vector<EventPair> ev_row, ev_col;
 
     bool is_exact() const { return prec == KLNMF_PREC_F64 || prec == KLNMF_PREC_F32; }
+    // ping-pong row pass (mfma4.hip.h): fp16-stored V; 8-wave workgroups for KT <= 7, 4-wave ones for 10 <= KT <= 16 (even)
+    bool pingpong() const { return prec == KLNMF_PREC_BF16 && row_gen == 4 && (KT <= 7 || KT > 8); }
     size_t esize() const { return prec == KLNMF_PREC_F64 ? 8 : 4; }
     size_t vsize() const { return prec == KLNMF_PREC_BF16 ? 2 : 4; }
 
@@ -213,11 +215,18 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
             else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
         }                                                                                                       \
         break;
+#define KL_ROW4_BIG(KTV)                                                                                        \
+    case KTV:                                                                                                   \
+        if (ep) hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 4>), dim3(grid), dim3(256), 0, c->stream, a);   \
+        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4>), dim3(grid), dim3(256), 0, c->stream, a);      \
+        break;
     switch (c->KT) {
         KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
         KL_ROW4_CASE(5) KL_ROW4_CASE(6) KL_ROW4_CASE(7)
-        default: fail(KLNMF_ERR_UNSUPP, "ping-pong row pass: k > 224 runs on the generation-1 kernel");
+        KL_ROW4_BIG(10) KL_ROW4_BIG(12) KL_ROW4_BIG(14) KL_ROW4_BIG(16)
+        default: fail(KLNMF_ERR_UNSUPP, "ping-pong row pass: 224 < k <= 256 runs on the generation-1 kernel");
     }
+#undef KL_ROW4_BIG
 #undef KL_ROW4_CASE
     HIPCHK(hipGetLastError());
 }
@@ -267,9 +276,10 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
     const bool v16 = c->prec == KLNMF_PREC_BF16;
-    if (v16 && c->row_gen == 4 && c->KT <= 7) {        // KT = 8 would spill (scratch traffic breaks the counted vmcnt waits)                       // ping-pong schedule (mfma4.hip.h), fp16 V only
+    if (c->pingpong()) {                               // ping-pong schedule (mfma4.hip.h), fp16 V only
         RowPass4Args a4{a, c->Ht4};
-        const int grid4 = (c->nrt + kWaves4 - 1) / kWaves4;
+        const int nw = c->KT > 8 ? 4 : kWaves4;
+        const int grid4 = (c->nrt + nw - 1) / nw;
         switch (mode) {
             case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
             case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
@@ -314,7 +324,10 @@ void fast_colpass_q(klnmf_ctx *c) {
         break;
     switch (c->KT) {
         KL_COLQ_CASE(1) KL_COLQ_CASE(2) KL_COLQ_CASE(3) KL_COLQ_CASE(4) KL_COLQ_CASE(5) KL_COLQ_CASE(6) KL_COLQ_CASE(7)
-        default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: k > 224 runs on the recomputing kernel");
+#define KL_COLQ_BIG(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a); break;
+        KL_COLQ_BIG(10) KL_COLQ_BIG(12) KL_COLQ_BIG(14) KL_COLQ_BIG(16)
+#undef KL_COLQ_BIG
+        default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: 224 < k <= 256 runs on the recomputing kernel");
     }
 #undef KL_COLQ_CASE
     HIPCHK(hipGetLastError());
@@ -822,10 +835,19 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->loss_part_count = ((f + GT - 1) / GT) * ((n + GT - 1) / GT);
             c->loss_part = (double *)c->dalloc(sizeof(double) * c->loss_part_count);
         } else {
+            if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
+            if (const char *g = std::getenv("KLNMF_COLPASS")) c->col_gen = std::atoi(g);
             c->KT = (int)((k + 31) / 32);
-            if (c->KT > 8) fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels; use KLNMF_PREC_F32/F64");
-            c->KP = 32 * c->KT;
             c->ks = (int)((k + 15) / 16);
+            if (c->KT > 8) {
+                // 256 < k <= 512: 4-wave workgroups of the ping-pong row pass (whole register file per wave) and the
+                // component-split column pass; component tiles in pairs, the W.H contraction over all of them
+                if (!(c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && k <= 512))
+                    fail(KLNMF_ERR_UNSUPP, "k > 256 runs in KLNMF_PREC_BF16 (k <= 512, ping-pong row pass) or KLNMF_PREC_F32/F64");
+                c->KT = 2 * (int)((k + 63) / 64);
+                c->ks = 2 * c->KT;
+            }
+            c->KP = 32 * c->KT;
             // both passes work on 64-row / 64-column stages: pad to 64 (zero padding is inert)
             c->n_pad = (n + 63) / 64 * 64;
             c->f_pad = (f + 127) / 128 * 128;            // the ping-pong row pass walks 4 column tiles per loop body
@@ -840,11 +862,9 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + 64;
             const size_t vs = c->vsize();
             const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * vs;
-            if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
-            if (const char *g = std::getenv("KLNMF_COLPASS")) c->col_gen = std::atoi(g);
             // column pass on the ratios the ping-pong row pass stores (k_colpass_q) where that row pass runs;
             // otherwise the recomputing one, which needs the second, column-tiled copy of V
-            const bool stored_q = c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && c->KT <= 7 && c->col_gen >= 2;
+            const bool stored_q = c->pingpong() && (c->col_gen >= 2 || c->KT > 8);
             c->VtA = c->dalloc(vbytes);
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;
@@ -858,15 +878,15 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
             // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
             // carrier column at 1) and a spare component inside the MFMA-1 contraction range
-            c->kc = (c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && c->KT <= 7 && (k % 16) != 0 &&
-                     !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
+            c->kc = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
             c->hsum = (float *)c->dalloc((size_t)c->KP * 4);
 #ifdef KL_STAMPS
             c->stamps = (unsigned long long *)c->dalloc((size_t)c->nrt * 8 * 8);
 #endif
             // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
-            c->ncb = (c->nct_used + kWavesPerWG - 1) / kWavesPerWG;
+            const int ctw = c->KT > 8 ? kWavesPerWG / 2 : kWavesPerWG;      // column tiles per workgroup (colq.hip.h, KSPLIT)
+            c->ncb = (c->nct_used + ctw - 1) / ctw;
             int nch = 8;
             int64_t wg_per_cu = 1;       // workgroups per CU the decomposition aims at (one is resident per CU; 2 measured 1-3 % slower)
             if (const char *g = std::getenv("KLNMF_COL_WG_PER_CU")) wg_per_cu = std::max(1, std::atoi(g));

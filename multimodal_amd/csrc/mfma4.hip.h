@@ -41,7 +41,7 @@ constexpr int kRow4B = kRow4 * 2;
 __host__ __device__ constexpr int h4_elem(int a, int c) {       // element offset of (component a, column c) in a tile image
     return a * kRow4 + ((((h_col_perm(c) >> 3) ^ ((a >> 2) & 3)) << 3) | (h_col_perm(c) & 7));
 }
-constexpr int kObj4 = 3 * kGldsRound;            // upper bound of one dictionary tile image (KP <= 256 -> 20480 B)
+constexpr int kObj4 = 4 * kGldsRound;            // upper bound of one dictionary tile image (KP <= 512 -> 32768 B)
 // Workgroup shape of the ping-pong row pass.  8 waves: the two wave groups share every dictionary copy and one
 // barrier.  4 waves (one per SIMD, two workgroups per CU): each workgroup copies its own dictionary tiles (twice
 // the L2 -> LDS traffic per CU) but only four waves meet at a barrier and the two workgroups of a CU drift
@@ -103,8 +103,9 @@ __device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned c
     b = *(const f16x8 *)(p + 16);
 }
 // global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
-template <int BYTES>
+template <int BYTES, int NW = kWaves4>
 __device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LDS unsigned char *ldst, int tid) {
+    constexpr int kRound4 = NW * 1024;       // bytes one round of the NW-wave workgroup moves
     constexpr int FULL = BYTES / kRound4, REM = BYTES % kRound4;
     const int wave_base = (tid & ~63) * 16;
 #pragma unroll
@@ -120,8 +121,13 @@ __device__ __forceinline__ void lds_wait(bf16x8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
-template <int KT, int ODD, int MODE, int EP = 0>
-__global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
+// NW = waves per workgroup: 8 (two per SIMD, the X / Y groups of the schedule above; KT <= 7) or 4 (one per SIMD with
+// the whole 512-register file -- accumulators in AGPRs -- for 8 <= KT <= 16, i.e. k <= 512: every wave then runs the X
+// order alone on its SIMD, matrix and epilogue segments in sequence; with 2*KT + KS >= 48 matrix instructions per tile
+// the epilogue is the smaller part).
+template <int KT, int ODD, int MODE, int EP = 0, int NW = kWaves4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4Args aa) {
+    constexpr int kWaves4 = NW, kThreads4 = 64 * NW;
     const RowPassArgs &a = aa.base;
     constexpr int KP = 32 * KT;
     constexpr int KS = 2 * KT - ODD;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         if (tg > 4) tg = 4;
 #endif
         tg = min(tg, a.nct - 1);
-        glds_copy_exact<IMG>(ht + (int64_t)tg * IMG, Hobj(o), tid);
+        glds_copy_exact<IMG, NW>(ht + (int64_t)tg * IMG, Hobj(o), tid);
     };
     const unsigned char *vlane = vt + lane * 32;             // this lane's 32 bytes of a V tile
     // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
@@ -364,7 +370,8 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int e = tid; e < IMG / 16; e += kThreads4) ((KL_LDS u32x4 *)h3)[e] = z;
-        if (MODE != ROW_INIT && tid < KP) hsum_lds[tid] = a.hsum[tid];
+        if (MODE != ROW_INIT)
+            for (int e = tid; e < KP; e += kThreads4) hsum_lds[e] = a.hsum[e];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
     }
@@ -413,35 +420,43 @@ __global__ __launch_bounds__(kThreads4, 2) void k_rowpass4(RowPass4Args aa) {
         // ring and V registers of the main loop are dead here, so KT*16 registers are free): one memory round
         // trip per wave instead of one per 32-component block -- with a single workgroup per CU nothing else
         // hides this tail (it was 15 % of the kernel when the loads were consumed block by block).
+        // (For KT > 8 in blocks of 8 component tiles: the accumulators alone fill half the register file.)
         const int64_t row = (int64_t)rt * 32 + r;
-        f32x4 wold[KT][4];
+        constexpr int MB = KT <= 8 ? KT : 8;
 #pragma unroll
-        for (int m = 0; m < KT; ++m)
+        for (int m0 = 0; m0 < KT; m0 += MB) {
+            f32x4 wold[MB][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int comp = 32 * m + 8 * g + 4 * h;
-                if (MODE == ROW_UPDATE) {
-                    wold[m][g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
-                } else {
+            for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) wold[m][g][t] = 1.f;
+                for (int g = 0; g < 4; ++g) {
+                    const int comp = 32 * (m0 + mm) + 8 * g + 4 * h;
+                    if (MODE == ROW_UPDATE && m0 + mm < KT) {
+                        wold[mm][g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) wold[mm][g][t] = 1.f;
+                    }
                 }
-            }
-        if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
+            if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
 #pragma unroll
-        for (int m = 0; m < KT; ++m)
+            for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int comp = 32 * m + 8 * g + 4 * h;
-                f32x4 w = wold[m][g];
+                for (int g = 0; g < 4; ++g) {
+                    if (m0 + mm >= KT) continue;
+                    const int m = m0 + mm;
+                    const int comp = 32 * m + 8 * g + 4 * h;
+                    f32x4 w = wold[mm][g];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) w[t] *= acc[m][4 * g + t];
-                *(f32x4 *)(a.W32_new + row * KP + comp) = w;
-                bf16x4 wb;
+                    for (int t = 0; t < 4; ++t) w[t] *= acc[m][4 * g + t];
+                    *(f32x4 *)(a.W32_new + row * KP + comp) = w;
+                    bf16x4 wb;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) wb[t] = (EP && comp + t == a.kc) ? (__bf16)1.f : (__bf16)w[t];   // eps carrier
-                *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
-            }
+                    for (int t = 0; t < 4; ++t) wb[t] = (EP && comp + t == a.kc) ? (__bf16)1.f : (__bf16)w[t];   // eps carrier
+                    *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
+                }
+            if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #ifdef KL_STAMPS
     {

@@ -411,8 +411,10 @@ def test_bf16_edge_cases():
     assert np.all(W[4] == 0)
     Wo, Ho, eo = orc.fit_transform(X, k=3, H0=H0, max_iter=10, tol=0)
     assert_allclose(errors, eo, rtol=2e-3)
-    with pytest.raises(RuntimeError):    # k > 256 is refused loudly, not emulated
-        fit_gpu(np.ones((8, 300)), orc.synthetic_H0(1, 300, 257), 257, 1, 0, precision='bf16')
+    with pytest.raises(RuntimeError):    # k > 512 is refused loudly, not emulated (k <= 512: test_nmf_kl.py, config 4)
+        fit_gpu(np.ones((8, 300)), orc.synthetic_H0(1, 300, 513), 513, 1, 0, precision='bf16')
+    with pytest.raises(RuntimeError):    # fp32-stored V runs the generation-1 kernels: k <= 256
+        fit_gpu(np.ones((8, 300)), orc.synthetic_H0(1, 300, 257), 257, 1, 0, precision='bf16_v32')
 
 
 # ==================================================== full-size properties ===

@@ -118,17 +118,54 @@ def test_config3_shape_bf16_final_kl():
 # ---- config 4: three modalities, k = 500 (fp32 accumulate) ------------------------------------
 @pytest.mark.gpu
 def test_config4_k500_three_modalities():
-    """k = 500 exceeds the 256 components the bf16 MFMA kernels hold in registers: the bf16 mode
-    refuses (no silent change of arithmetic), the fp32 mode runs the same loop on the exact kernels."""
+    """k = 500 (KT = 16 component tiles): the bf16 mode runs the 4-wave workgroups of the ping-pong row pass
+    (the whole register file per wave) and the component-split column pass; bf16_v32 (fp32-stored V, generation-1
+    kernels) refuses beyond 256 components instead of silently changing arithmetic; the fp32 mode runs the same
+    loop on the exact kernels."""
     n, dims, k, iters = 256, [192, 128, 64], 500, 3
     blocks = [orc.synthetic_V(41 + i, n, d, 16) for i, d in enumerate(dims)]
     V = orc.stack_modalities(blocks, [1.0, 1.0, 1.0])
     H0 = orc.synthetic_H0(41, sum(dims), k)
     with pytest.raises(_native.NativeError) as ei:
-        _fit(V, H0, k, iters, 'bf16')
+        _fit(V, H0, k, iters, 'bf16_v32')
     assert 'k > 256' in str(ei.value)
+    with pytest.raises(_native.NativeError):
+        _fit(V, orc.synthetic_H0(41, sum(dims), 513), 513, iters, 'bf16')
     Wo, Ho, eo = orc.fit_transform(V, k=k, H0=H0, max_iter=iters, tol=0)
+    fo = orc.kl_error(V, Wo, Ho)
     m, W, e = _fit(V.astype(np.float32), H0, k, iters, 'f32')
     assert_allclose(e, eo, rtol=2e-4)
-    fo = orc.kl_error(V, Wo, Ho)
     assert abs(m.error(V, W) - fo) <= 5 * KL_TOL * fo
+    m, W, e = _fit(V, H0, k, iters, 'bf16')
+    assert_allclose(e, eo, rtol=1e-3)
+    assert abs(m.error(V, W) - fo) <= KL_TOL * fo
+    true_g = nmf.KLdivNMF(n_components=k, precision='f64').error(V, W, H=m.components_)
+    assert abs(true_g - fo) <= KL_TOL * fo
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k', [(4096, 1536, 500), (3000, 700, 300), (2048, 512, 384), (2048, 384, 430), (1024, 256, 512)])
+def test_config4_k_up_to_512_bf16_final_kl(n, f, k):
+    """256 < k <= 512 in the bf16 mode against the fp64 reference: every accumulator count of the 4-wave row pass
+    (KT = 10, 12, 14, 16), k a multiple of 64 (no spare component for the eps carrier) and not, ragged n and f,
+    several row chunks of the column pass; plus transform on the fitted dictionary."""
+    iters = 3
+    X = orc.synthetic_V(77, n, f, 24)
+    H0 = orc.synthetic_H0(77, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    m, W, e = _fit(X, H0, k, iters, 'bf16')
+    assert_allclose(e, eo, rtol=1e-3)
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(m.error(X, W) - fo) <= KL_TOL * fo
+    true_g = nmf.KLdivNMF(n_components=k, precision='f64').error(X, W, H=m.components_)
+    assert abs(true_g - fo) <= KL_TOL * fo
+    assert_allclose(W, Wo, rtol=2e-2, atol=2e-3 * np.abs(Wo).max())
+    assert_allclose(m.components_, Ho, rtol=2e-2, atol=2e-3 * np.abs(Ho).max())
+    # transform (W rule only) on the fitted dictionary
+    Wt_o, et_o = orc.transform(X[:512], m.components_.astype(np.float64), max_iter=2, tol=0)
+    mt = nmf.KLdivNMF(n_components=k, max_iter=2, tol=0, precision='bf16')
+    mt.components_ = m.components_
+    with contextlib.redirect_stderr(io.StringIO()):
+        Wt, et = mt.transform(X[:512], return_errors=True)
+    assert_allclose(np.asarray(et), et_o, rtol=1e-3)
+    assert_allclose(Wt, Wt_o, rtol=2e-2, atol=2e-3 * np.abs(Wt_o).max())
