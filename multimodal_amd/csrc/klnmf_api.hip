@@ -193,8 +193,12 @@ void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
         else launch_rowpass_one<KTV, 0, MODE, VT>(c, a, grid);                  \
         break;
     switch (c->KT) {
+#ifdef KL_DEV_BUILD          // experiment builds (scripts/ab.sh): only the two headline shapes, a quarter of the compile time
+        KL_ROW_CASE(7)
+#else
         KL_ROW_CASE(1) KL_ROW_CASE(2) KL_ROW_CASE(3) KL_ROW_CASE(4)
         KL_ROW_CASE(5) KL_ROW_CASE(6) KL_ROW_CASE(7) KL_ROW_CASE(8)
+#endif
         default: fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels");
     }
 #undef KL_ROW_CASE
@@ -221,9 +225,13 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
         else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4>), dim3(grid), dim3(256), 0, c->stream, a);      \
         break;
     switch (c->KT) {
+#ifdef KL_DEV_BUILD
+        KL_ROW4_CASE(7) KL_ROW4_BIG(16)
+#else
         KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
         KL_ROW4_CASE(5) KL_ROW4_CASE(6) KL_ROW4_CASE(7)
         KL_ROW4_BIG(10) KL_ROW4_BIG(12) KL_ROW4_BIG(14) KL_ROW4_BIG(16)
+#endif
         default: fail(KLNMF_ERR_UNSUPP, "ping-pong row pass: 224 < k <= 256 runs on the generation-1 kernel");
     }
 #undef KL_ROW4_BIG
@@ -246,8 +254,12 @@ void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
         else launch_colpass_one<KTV, 0, VT>(c, a, grid);                        \
         break;
     switch (c->KT) {
+#ifdef KL_DEV_BUILD
+        KL_COL_CASE(7)
+#else
         KL_COL_CASE(1) KL_COL_CASE(2) KL_COL_CASE(3) KL_COL_CASE(4)
         KL_COL_CASE(5) KL_COL_CASE(6) KL_COL_CASE(7) KL_COL_CASE(8)
+#endif
         default: fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels");
     }
 #undef KL_COL_CASE
@@ -323,9 +335,13 @@ void fast_colpass_q(klnmf_ctx *c) {
         else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
         break;
     switch (c->KT) {
-        KL_COLQ_CASE(1) KL_COLQ_CASE(2) KL_COLQ_CASE(3) KL_COLQ_CASE(4) KL_COLQ_CASE(5) KL_COLQ_CASE(6) KL_COLQ_CASE(7)
 #define KL_COLQ_BIG(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a); break;
+#ifdef KL_DEV_BUILD
+        KL_COLQ_CASE(7) KL_COLQ_BIG(16)
+#else
+        KL_COLQ_CASE(1) KL_COLQ_CASE(2) KL_COLQ_CASE(3) KL_COLQ_CASE(4) KL_COLQ_CASE(5) KL_COLQ_CASE(6) KL_COLQ_CASE(7)
         KL_COLQ_BIG(10) KL_COLQ_BIG(12) KL_COLQ_BIG(14) KL_COLQ_BIG(16)
+#endif
 #undef KL_COLQ_BIG
         default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: 224 < k <= 256 runs on the recomputing kernel");
     }
@@ -779,7 +795,11 @@ int klnmf_destroy(klnmf_ctx *c) {
             double sum[8] = {0};
             for (int i = 0; i < c->nrt; ++i) for (int j = 0; j < 8; ++j) sum[j] += (double)hs[(size_t)i * 8 + j];
             const double tiles = (double)c->nct;
-            if (c->row_gen == 4 && c->prec == KLNMF_PREC_BF16 && c->KT <= 7) {
+            if (c->pingpong() && c->KT > 8)
+                std::fprintf(stderr, "[stampsF] per tile per wave (cycles): vmcnt wait %.0f | barrier %.0f | stores+loads+copies issue %.0f | MFMA-2 + epilogue %.0f | MFMA-1 %.0f || kernel %.0f cycles, %d tiles\n",
+                             sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles, sum[4] / c->nrt / tiles, sum[0] / c->nrt / tiles,
+                             sum[1] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
+            else if (c->row_gen == 4 && c->prec == KLNMF_PREC_BF16 && c->KT <= 7) {
                 double pro = 0, epi = 0;
                 for (int i = 0; i < c->nrt; ++i) { pro += (double)(hs[(size_t)i * 8 + 7] >> 32); epi += (double)(hs[(size_t)i * 8 + 7] & 0xffffffffull); }
                 std::fprintf(stderr, "[stamps4] per wave: prologue %.0f cycles, epilogue %.0f cycles\n", pro / c->nrt, epi / c->nrt);

@@ -54,6 +54,12 @@ constexpr int kThreads4 = 64 * kWaves4;
 constexpr int kRound4 = kThreads4 * 16;          // bytes one global_load_lds round of the workgroup moves
 __host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
 
+// MFMA-2 fragment p of a tile -> (32-component block, k-step).  Paired order (p>>1, p&1): the two k-steps of a block back to
+// back on one accumulator; split order (p % KT, p / KT): all blocks with the first k-step, then all with the second, so
+// that consecutive MFMAs never share an accumulator.
+__host__ __device__ constexpr int m2_block(int p, int kt, bool split) { return split ? p % kt : p >> 1; }
+__host__ __device__ constexpr int m2_kstep(int p, int kt, bool split) { return split ? p / kt : p & 1; }
+
 struct RowPass4Args {
     RowPassArgs base;
     const __bf16 *Ht4;        // [nct][KP][kRow4] per-tile dictionary images
@@ -116,6 +122,33 @@ __device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LD
         __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + FULL * kRound4 + tid * 16),
                                          (KL_LDS void *)(ldst + FULL * kRound4 + wave_base), 16, 0, 0);
 }
+
+// MFMA-1 of the FUSED order with its accumulator pinned to VGPRs.  A kernel that may use more than 256 registers has
+// every compiler-generated MFMA accumulate in AGPRs; at KT = 16 the G accumulators alone are all 256 of them, and
+// hipcc then shuttles one block between the two files around every tile (32 moves and a 12-cycle hazard stall).
+// The epilogue reads W.H with VALU instructions anyway, so this product lives in VGPRs: written as inline asm (the
+// compiler does not know these are matrix instructions -- the wait states between the last one and the first VALU
+// read of d are provided by hand, see seg_F).
+//
+// FUSED order: the counted wait and the matrix instruction as ONE asm statement.  Behind a separate wait statement with
+// the fragment as an in/out operand hipcc adds an `s_nop 0` before every MFMA (it must assume a VALU write), and a lone
+// wave's issue slots are the scarce resource of that schedule.  G accumulates in AGPRs ("a"), W.H in VGPRs ("v").
+template <int N>
+__device__ __forceinline__ void mfma2_w(f32x16 &acc, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void mfma2_wv(f32x16 &acc, const bf16x8 &a, const bf16x8 &b) {      // accumulator in VGPRs
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void mfma1_first_w(f32x16 &d, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void mfma1_acc_w(f32x16 &d, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
+}
 template <int N>
 __device__ __forceinline__ void lds_wait(bf16x8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
@@ -139,6 +172,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     constexpr int D = KL_PF < NF - 1 ? KL_PF : NF - 1;      // reads run D fragments ahead of their MFMA
     constexpr int R = D + 1;
     constexpr int DP = D < N2 ? D : N2;      // fragments of the lead that are MFMA-2 reads (issued one segment early)
+    // One wave per SIMD (NW = 4) has no partner whose matrix segment could cover its epilogue: the update pass then runs
+    // the FUSED order below, in which the wave itself issues the epilogue of tile t between the MFMA-2 of tile t-1.
+#ifdef KL_NO_FUSED
+    constexpr bool FUSED = false;
+#else
+    constexpr bool FUSED = NW == 4 && MODE == ROW_UPDATE && N2 >= 16;
+#endif
+#ifdef KL_M2_PAIRED
+    constexpr bool FUSED_ORDER = false;
+#else
+    constexpr bool FUSED_ORDER = FUSED;      // MFMA-2 fragments of the FUSED order: split k-steps (m2_block)
+#endif
     constexpr int IMG = KP * kRow4B;          // bytes of one dictionary tile image
     static_assert(IMG <= kObj4 && IMG % 16 == 0, "dictionary tile image size");
     constexpr int OBJ = IMG;
@@ -192,6 +237,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         tg = min(tg, a.nct - 1);
         glds_copy_exact<IMG, NW>(ht + (int64_t)tg * IMG, Hobj(o), tid);
     };
+    // one round (this thread's 16 bytes of every NW KiB) of the copy of dictionary tile tg into object o: the FUSED
+    // order issues the rounds one per MFMA instead of back to back (a lone wave's VMEM issue is not covered by a partner)
+    constexpr int kRounds = IMG / (NW * 1024);
+    constexpr int kDmaEvery = (N2 - 3) / (kRounds > 0 ? kRounds : 1) > 0 ? (N2 - 3) / (kRounds > 0 ? kRounds : 1) : 1;
+    unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave index as a scalar
+    auto dma_round = [&](int o, int tg, auto Rr) {
+        constexpr int rr = decltype(Rr)::value;
+        tg = min(tg, a.nct - 1);
+        // scalar base + 32-bit lane offset, LDS destination (M0) from scalars: 3 instructions per round instead of the
+        // 5 (v_or, v_readfirstlane, s_mov, 64-bit VALU add, load) hipcc produces for the builtin with a per-lane pointer
+        const unsigned char *gbase = ht + (int64_t)tg * IMG + rr * (NW * 1024);
+        unsigned m0v = lds_addr(Hobj(o)) + rr * (NW * 1024) + wave_u * 1024;
+        unsigned t16 = tid * 16;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(t16), "s"(gbase) : "memory");
+    };
     const unsigned char *vlane = vt + lane * 32;             // this lane's 32 bytes of a V tile
     // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
     unsigned char *qlane = (a.Qt && active) ? a.Qt + (int64_t)rt * 2048 + lane * 16 : nullptr;
@@ -212,6 +272,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     unsigned long long tk0; KL_STAMP(tk0);
 #endif
     bool tail = false;
+    bf16x8 bq[2][2];                // FUSED: Q operands of the even / odd tile slot (one consumed while the other is produced)
+    float qv[2] = {0.f, 0.f};       // FUSED: the ratio pair being built
     bf16x8 ring[R];
     f32x16 d;                       // W.H of the tile between its M and E segments
     bf16x8 b0, b1;                  // Q operands of the tile between its E segment and the next M segment
@@ -222,11 +284,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // [N2,NF) MFMA-1 of this tile (transposed reads).  ra / ta: per-lane base addresses in the two objects.
     auto issue = [&](auto P, unsigned robj, unsigned tobj) {     // robj / tobj: LDS addresses of the two tile images
         constexpr int p = decltype(P)::value;
+        constexpr int pm = m2_block(p, KT, FUSED_ORDER), ph2 = m2_kstep(p, KT, FUSED_ORDER);
 #ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
         return;
 #endif
         if constexpr (p < N2) {
-            lds_read_b128<(32 * (p >> 1)) * kRow4B>(ring[p % R], robj + ((p & 1) ? off_row1 : off_row0));
+            lds_read_b128<(32 * pm) * kRow4B>(ring[p % R], robj + (ph2 ? off_row1 : off_row0));
         } else if constexpr (p < NF) {
             constexpr int s = p - N2;
             lds_read_tr_pair<(16 * s) * kRow4B>(ring[p % R], tobj + off_tr0, tobj + off_tr1);
@@ -253,6 +316,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             constexpr int last = (p + D < NF - 1) ? p + D : NF - 1;
             constexpr int n_b128 = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
             constexpr int n_tr = (last - p) - n_b128;
+#if defined(KL_ASM_MFMA) && !defined(KL_ABL_NOLDS) && !defined(KL_ABL_NOMFMA)
+            // wait + matrix instruction as one asm statement (no compiler-added s_nop per MFMA; see mfma2_w)
+            if constexpr (NW == 8) {
+                if constexpr (p < N2) mfma2_wv<n_b128 + 2 * n_tr>(acc[p >> 1], ring[p % R], (p & 1) ? b1 : b0);
+                else if constexpr (p == N2) mfma1_first_w<n_b128 + 2 * n_tr>(d, ring[p % R], wf[0]);
+                else mfma1_acc_w<n_b128 + 2 * n_tr>(d, ring[p % R], wf[p - N2]);
+                if constexpr (p == NF - 1) asm volatile("s_nop 15" ::: "memory");   // wait states before VALU reads of d
+                return;
+            }
+#endif
 #ifndef KL_ABL_NOLDS
             lds_wait<n_b128 + 2 * n_tr>(ring[p % R]);
 #endif
@@ -282,15 +355,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     };
     // the ratios of tile tg as packed in b0 / b1, for the column pass (k_colpass_q2): written once, read once by
     // another kernel -> non-temporal
-    auto store_q = [&](int tg) {
+    auto store_q2 = [&](int tg, const bf16x8 &b0, const bf16x8 &b1) {
         if (MODE == ROW_UPDATE && qlane) {
 #ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
             unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
 #else
             unsigned char *qp = qlane + (int64_t)tg * qstride;
 #endif
+#ifdef KL_ABL_QPLAIN       // experiment: ordinary stores instead of non-temporal ones
+            *(bf16x8 *)qp = b0;
+            *(bf16x8 *)(qp + 1024) = b1;
+#else
             __builtin_nontemporal_store(b0, (bf16x8 *)qp);
             __builtin_nontemporal_store(b1, (bf16x8 *)(qp + 1024));
+#endif
+        }
+    };
+    auto store_q = [&](int tg) { store_q2(tg, b0, b1); };
+    auto store_q_half = [&](int tg, const bf16x8 &b, int off) {
+        if (MODE == ROW_UPDATE && qlane) {
+#ifdef KL_ABL_QSMALL
+            unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
+#else
+            unsigned char *qp = qlane + (int64_t)tg * qstride;
+#endif
+            __builtin_nontemporal_store(b, (bf16x8 *)(qp + off));
         }
     };
     // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
@@ -363,10 +452,122 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #endif
     };
 
+
+    // ---- FUSED order (NW = 4, update pass).  Interval t of a wave:
+    //        [ MFMA-2 of tile t-1  with the epilogue of tile t issued between its MFMAs ]  [ MFMA-1 of tile t+1 ]
+    // MFMA-1 runs one tile ahead, so that the epilogue (needs W.H of tile t, gives the Q operands of tile t) has an
+    // independent matrix stream to hide under: an MFMA occupies the pipe for 32 cycles and its issue slot for 4, the
+    // 2-3 VALU instructions placed behind it (half an element of the tile: rcp, mul, fma | log, fma, cvt) issue in
+    // its shadow.  Source order is pinned per MFMA with sched_barrier(0).  Costs 8 registers (two Q operand sets);
+    // W.H of tile t+1 is written only after the last epilogue step of tile t has read W.H of tile t (same registers).
+    // Images: interval t reads those of tiles t-1 (rows) and t+1 (transposed); the copy of tile t+2 goes out behind
+    // the interval's barrier into the object of tile t-2 and is awaited (vmcnt(0) + barrier) at the next one.
+    // Epilogue of one tile in 33 steps, software-pipelined by one step so that no result of a transcendental is used in
+    // the step that issues it (the TRANS -> VALU wait state would otherwise cost an s_nop per use):
+    //   even step 2e  : loss term and bf16 packing of element e-1 (its log comes from step 2e-1), rcp for element e
+    //   odd step 2e+1 : ratio of element e (rcp from step 2e), its log
+    float rinv = 0.f, lg = 0.f;
+    auto e_step = [&](auto Hh, const f16x8 &va, const f16x8 &vb, bf16x8 &o0, bf16x8 &o1) {
+        constexpr int hh = decltype(Hh)::value, e = hh >> 1;
+        if constexpr ((hh & 1) == 0) {
+            if constexpr (e >= 1) {
+                constexpr int ep = e - 1;
+                const float xp = (float)(ep < 8 ? va[ep & 7] : vb[ep & 7]);
+                s1 = fmaf(xp, lg, s1);
+                asm volatile("" : "+v"(s1));      // the loss term is computed HERE (hipcc otherwise sinks all 16 past the interval)
+                if constexpr ((ep & 1) == 1) {
+                    bf16x8 &o = ep < 8 ? o0 : o1;
+                    o[(ep & 7) - 1] = (__bf16)qv[0];
+                    o[ep & 7] = (__bf16)qv[1];
+                }
+            }
+            if constexpr (e < 16) {
+                rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);
+                asm volatile("" : "+v"(rinv));
+            }
+        } else {
+            const float x = (float)(e < 8 ? va[e & 7] : vb[e & 7]);
+            qv[e & 1] = fmaf(x, rinv, eps * rinv);
+            lg = __builtin_amdgcn_logf(qv[e & 1]);
+            asm volatile("" : "+v"(lg));
+        }
+    };
+    auto seg_F = [&](auto TS, int tg) {
+        constexpr int ts = decltype(TS)::value;
+        static_assert(!FUSED || (NF % R == 0 && D <= N2 && D <= N1), "fragment ring of the FUSED order");
+        f16x8 &va = vreg[2 * (ts & 1)], &vb = vreg[2 * (ts & 1) + 1];                 // V of tile tg (landed at mid tg-1)
+        f16x8 &na = vreg[2 * ((ts + 1) & 1)], &nb = vreg[2 * ((ts + 1) & 1) + 1];     // V of tile tg+1 (lands at mid tg)
+        bf16x8 &p0 = bq[(ts + 1) & 1][0], &p1 = bq[(ts + 1) & 1][1];      // tile tg-1: consumed
+        bf16x8 &c0 = bq[ts & 1][0], &c1 = bq[ts & 1][1];                  // tile tg: produced
+        const unsigned ra = lds_addr(Hobj((ts + 3) % 4));                 // image of tile tg-1 (row reads)
+        const unsigned ta = lds_addr(Hobj((ts + 1) % 4));                 // image of tile tg+1 (transposed reads)
+        const unsigned rn = lds_addr(Hobj(ts % 4));                       // image of tile tg: the next interval's row reads
+#ifdef KL_STAMPS
+        unsigned long long f0, f1, f2, f3, f5; KL_STAMP(f0);
+#endif
+        // ---- first half: MFMA-2 of tile tg-1, the epilogue of tile tg between its MFMAs.  No VMEM instruction here: with
+        // the epilogue steps the gaps of this half are full (an LDS-DMA piece costs 60-180 issue cycles beside them).
+        // Fragments 0..D-1 were requested by the previous interval's last gaps.
+        static_for<0, N2>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            if constexpr (p + D < N2) issue(std::integral_constant<int, p + D>{}, ra, 0u);
+            constexpr int young = (p + D < N2 - 1 ? p + D : N2 - 1) - p;               // row reads younger than fragment p's
+            mfma2_w<young>(acc[m2_block(p, KT, FUSED_ORDER)], ring[p % R], m2_kstep(p, KT, FUSED_ORDER) ? p1 : p0);
+            constexpr int h_lo = (p * 32 + N2 - 1) / N2, h_hi = ((p + 1) * 32 + N2 - 1) / N2;
+#ifndef KL_ABL_NOESTEP
+            static_for<h_lo, h_hi>([&](auto Hh) { e_step(Hh, va, vb, c0, c1); });
+#else
+            if constexpr (p == 5) { c0 = p0; c1 = p1; }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        e_step(std::integral_constant<int, 32>{}, va, vb, c0, c1);
+#ifdef KL_STAMPS
+        KL_STAMP(f1);
+#endif
+        // ---- middle: the ONE wait and barrier of the interval.  Everything this wave requested in the second half of the
+        // previous interval (at least a whole first half ago) has landed: V of tile tg+1, its slices of image tg+1; behind
+        // the barrier image tg+1 is complete and every wave is done with image tg-1.
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(na), "+v"(nb)::"memory");
+#ifdef KL_STAMPS
+        KL_STAMP(f2);
+#endif
+        barrier();
+#ifdef KL_STAMPS
+        KL_STAMP(f3);
+#endif
+        // ---- second half: MFMA-1 of tile tg+1 (W.H one tile ahead).  Its gaps have issue slots to spare: the interval's
+        // VMEM work goes here -- V of tile tg+2 into the registers the epilogue just released, the ratio tile of tg, the
+        // rounds of the copy of dictionary tile tg+2 (into the object of tile tg-2) -- all awaited at the next middle.
+        static_for<0, D>([&](auto S) { issue(std::integral_constant<int, N2 + decltype(S)::value>{}, 0u, ta); });
+        static_for<0, N1>([&](auto S) {
+            constexpr int sI = decltype(S)::value;
+            if constexpr (sI + D < N1) issue(std::integral_constant<int, N2 + sI + D>{}, 0u, ta);
+            else issue(std::integral_constant<int, sI + D - N1>{}, rn, 0u);             // the next interval's first row reads
+            constexpr int n_tr = (sI + D < N1 - 1 ? sI + D : N1 - 1) - sI;             // younger transposed fragments (2 reads each)
+            constexpr int n_rd = D - n_tr;                                             // younger row reads of the next interval
+            if constexpr (sI == 0) mfma1_first_w<2 * n_tr + n_rd>(d, ring[(N2 + sI) % R], wf[0]);
+            else mfma1_acc_w<2 * n_tr + n_rd>(d, ring[(N2 + sI) % R], wf[sI]);
+            if constexpr (sI == 1) v_tile_load(va, vb, vlane + (int64_t)min(tg + 2, a.nct - 1) * TB);
+            if constexpr (sI >= 3 && (sI - 3) % 3 == 0 && (sI - 3) / 3 < kRounds)
+                dma_round((ts + 2) % 4, tg + 2, std::integral_constant<int, (sI - 3) / 3>{});
+            if constexpr (sI == N1 - 4) store_q_half(tg, c0, 0);
+            if constexpr (sI == N1 - 2) store_q_half(tg, c1, 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 15" ::: "memory");       // wait states between the last MFMA-1 and the first VALU read of d
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef KL_STAMPS
+        KL_STAMP(f5);
+        ph[0] += f1 - f0; ph[2] += f2 - f1; ph[3] += f3 - f2; ph[1] += f5 - f3;
+#endif
+    };
+
     // ---- prologue: dictionary tiles 0 and 1 and V tile 0 in flight; the object of "tile -1" zero-filled
     dma(0, 0);
     dma(1, 1);
     v_tile_load(vreg[0], vreg[1], vlane);
+    if constexpr (FUSED) v_tile_load(vreg[2], vreg[3], vlane + (int64_t)min(1, a.nct - 1) * TB);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int e = tid; e < IMG / 16; e += kThreads4) ((KL_LDS u32x4 *)h3)[e] = z;
@@ -375,8 +576,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #pragma unroll
         for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1])::"memory");
+    if constexpr (FUSED) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1]), "+v"(vreg[2]), "+v"(vreg[3])::"memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1])::"memory");
     barrier();
+    if constexpr (FUSED) {          // W.H of tile 0 (every later tile's is computed one interval ahead)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bq[1][0][j] = (__bf16)0.f; bq[1][1][j] = (__bf16)0.f; }
+        const unsigned ta = lds_addr(Hobj(0));
+        static_for<0, N1>([&](auto S) {
+            constexpr int sI = decltype(S)::value;
+            lds_read_tr_pair<(16 * sI) * kRow4B>(ring[0], ta + off_tr0, ta + off_tr1);
+            if constexpr (sI == 0) mfma1_first_w<0>(d, ring[0], wf[0]);
+            else mfma1_acc_w<0>(d, ring[0], wf[sI]);
+        });
+        asm volatile("s_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (N2 > 0) {         // what the E segment of "tile -1" would have primed
         const unsigned ra = lds_addr(Hobj(3));
         static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
@@ -386,6 +601,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     unsigned long long tkP; KL_STAMP(tkP);
 #endif
     // ---- main loop: 4 tiles per body (nct is a multiple of 4)
+    if constexpr (FUSED) {
+        for (int t4 = 0; t4 < a.nct; t4 += 4)
+            static_for<0, 4>([&](auto I) { seg_F(I, t4 + decltype(I)::value); });
+        // tail: MFMA-2 of the last tile (slot 3: its row reads were primed by the last interval)
+        const unsigned ra = lds_addr(Hobj(3));
+        static_for<0, N2>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            if constexpr (p + D < N2) issue(std::integral_constant<int, p + D>{}, ra, 0u);
+            constexpr int last = (p + D < N2 - 1) ? p + D : N2 - 1;
+            mfma2_w<last - p>(acc[m2_block(p, KT, FUSED_ORDER)], ring[p % R], m2_kstep(p, KT, FUSED_ORDER) ? bq[1][1] : bq[1][0]);
+        });
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // wait states before the W rule reads G
+    } else {
     for (int t4 = 0; t4 < a.nct; t4 += 4) {
         static_for<0, 4>([&](auto I) {
             seg_M(I, t4 + decltype(I)::value);
@@ -398,6 +626,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #ifndef KL_QSTORE_EARLY
     store_q(a.nct - 1);
 #endif
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
 #ifdef KL_STAMPS
     unsigned long long tkL; KL_STAMP(tkL);
