@@ -138,10 +138,6 @@ __device__ __forceinline__ void mfma2_w(f32x16 &acc, const bf16x8 &a, const bf16
     asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void mfma2_wv(f32x16 &acc, const bf16x8 &a, const bf16x8 &b) {      // accumulator in VGPRs
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "n"(N));
-}
-template <int N>
 __device__ __forceinline__ void mfma1_first_w(f32x16 &d, const bf16x8 &a, const bf16x8 &b) {
     asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(N));
 }
@@ -316,16 +312,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             constexpr int last = (p + D < NF - 1) ? p + D : NF - 1;
             constexpr int n_b128 = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
             constexpr int n_tr = (last - p) - n_b128;
-#if defined(KL_ASM_MFMA) && !defined(KL_ABL_NOLDS) && !defined(KL_ABL_NOMFMA)
-            // wait + matrix instruction as one asm statement (no compiler-added s_nop per MFMA; see mfma2_w)
-            if constexpr (NW == 8) {
-                if constexpr (p < N2) mfma2_wv<n_b128 + 2 * n_tr>(acc[p >> 1], ring[p % R], (p & 1) ? b1 : b0);
-                else if constexpr (p == N2) mfma1_first_w<n_b128 + 2 * n_tr>(d, ring[p % R], wf[0]);
-                else mfma1_acc_w<n_b128 + 2 * n_tr>(d, ring[p % R], wf[p - N2]);
-                if constexpr (p == NF - 1) asm volatile("s_nop 15" ::: "memory");   // wait states before VALU reads of d
-                return;
-            }
-#endif
 #ifndef KL_ABL_NOLDS
             lds_wait<n_b128 + 2 * n_tr>(ring[p % R]);
 #endif
