@@ -56,9 +56,10 @@ def make_H0(seed, f, k):
     return h / (1e-16 + h.sum(axis=1, keepdims=True))
 
 
-def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192):
+def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192, vscale=1.0):
     """Synthetic non-negative V = Wt.Ht/k + 0.05*U (factorisable + noise, SURVEY 8d
-    shape), generated block-wise on the GPU and fed to the tiling upload."""
+    shape), generated block-wise on the GPU and fed to the tiling upload.  `vscale` multiplies the matrix on its way
+    in (the upload's per-modality coefficient, learner.py:53-56): tests use it for the homogeneity property."""
     dev = torch.device('cuda', torch.cuda.current_device())
     g = torch.Generator(device=dev)
     g.manual_seed(seed)                       # Ht identical on every rank
@@ -79,11 +80,11 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192):
     vmax = 0.0
     for r0 in range(0, n_local, block):
         vmax = max(vmax, float(block_of(min(block, n_local - r0)).max().item()))
-    model.set_v_max(vmax)
+    model.set_v_max(vmax * vscale)
     g.set_state(state)
     for r0 in range(0, n_local, block):
         Vb = block_of(min(block, n_local - r0))
-        model.upload_V_device(Vb.contiguous(), row0=r0, col0=0, scale=1.0)
+        model.upload_V_device(Vb.contiguous(), row0=r0, col0=0, scale=vscale)
     torch.cuda.synchronize()
 
 
