@@ -21,6 +21,13 @@
 //   * tile images are unpadded and XOR-swizzled (h4_elem): no bank conflicts for either read pattern.
 // What was measured on the way (two barriers per tile, V through LDS, deeper prefetch, 4-wave workgroups,
 // LDS semaphores instead of the barrier, copies through registers) is in experiments/README.md.
+//
+// 256 < k <= 512 (KT = 10..16): the accumulators of 32 rows fill half the register file, so a workgroup is 4 waves,
+// one per SIMD, and there is no partner wave.  The update pass then runs the FUSED order (seg_F below): the wave
+// issues the epilogue of tile t between the MFMA-2 of tile t-1, computes W.H one tile ahead (inline-asm MFMAs with a
+// VGPR accumulator), takes ONE vmcnt(0) + barrier per tile between the two halves and issues all its VMEM work in
+// the gaps of the MFMA-1 half.  Rule for the asm MFMAs: every VGPR operand comes from LDS / memory or from VALU code
+// that a sched_barrier keeps at least two instructions away (hipcc pads only its own MFMAs).
 #pragma once
 #include <type_traits>
 
