@@ -110,6 +110,8 @@ struct klnmf_ctx {
     int KT = 0, KP = 0, ks = 0;
     int64_t n_pad = 0, f_pad = 0, w_rows = 0;
     int nrt = 0, nct = 0, nct_used = 0, nst = 0, ncb = 0, nchunks = 0, stages_per_chunk = 0;
+    int row_chunks = 1, row_ct_chunk = 0;     // column-split update pass (few rows): chunks, column tiles per chunk
+    float *Gpart = nullptr;                   // [row_chunks][nrt * 32][KP] partial Q.H^T
     void *VtA = nullptr, *VtB = nullptr;
     unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
     int col_gen = 2;
@@ -206,23 +208,24 @@ void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
 }
 
 template <int MODE>
-void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid) {
+void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int grid_y = 1) {
+    const dim3 grid(grid_x, grid_y);
     const int odd = 2 * c->KT - c->ks;
     const bool ep = c->kc >= 0;
 #define KL_ROW4_CASE(KTV)                                                                                       \
     case KTV:                                                                                                   \
         if (ep) {                                                                                               \
-            if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1>), dim3(grid), dim3(kThreads4), 0, c->stream, a);  \
-            else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
+            if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+            else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
         } else {                                                                                                \
-            if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0>), dim3(grid), dim3(kThreads4), 0, c->stream, a);  \
-            else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0>), dim3(grid), dim3(kThreads4), 0, c->stream, a);      \
+            if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0>), grid, dim3(kThreads4), 0, c->stream, a);  \
+            else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0>), grid, dim3(kThreads4), 0, c->stream, a);      \
         }                                                                                                       \
         break;
 #define KL_ROW4_BIG(KTV)                                                                                        \
     case KTV:                                                                                                   \
-        if (ep) hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 4>), dim3(grid), dim3(256), 0, c->stream, a);   \
-        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4>), dim3(grid), dim3(256), 0, c->stream, a);      \
+        if (ep) hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 4>), grid, dim3(256), 0, c->stream, a);   \
+        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4>), grid, dim3(256), 0, c->stream, a);      \
         break;
     switch (c->KT) {
 #ifdef KL_DEV_BUILD
@@ -292,6 +295,19 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
         RowPass4Args a4{a, c->Ht4};
         const int nw = c->KT > 8 ? 4 : kWaves4;
         const int grid4 = (c->nrt + nw - 1) / nw;
+        if (mode == ROW_UPDATE && c->row_chunks > 1) {     // few rows: column chunks in blockIdx.y, W rule from the slabs
+            a4.base.gpart = c->Gpart;
+            a4.base.ct_chunk = c->row_ct_chunk;
+            launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4, c->row_chunks);
+            const int64_t rows = (int64_t)c->nrt * 32;
+            hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
+                               (const float *)c->Gpart, c->row_chunks, rows * c->KP, (const float *)c->W32[c->cur],
+                               c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
+                               (const DevState *)c->st);
+            HIPCHK(hipGetLastError());
+            if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+            return;
+        }
         switch (mode) {
             case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
             case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
@@ -519,8 +535,8 @@ void piece_rowpass(klnmf_ctx *c, int fit) {
     } else {
         fast_rowpass(c, ROW_UPDATE, fit);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
-                           (const float2 *)c->loss_part2, (int64_t)c->nrt, (const DevState *)c->st,
-                           1.0 / c->v_scale, c->loss_xchg);
+                           (const float2 *)c->loss_part2, (int64_t)c->nrt * (c->pingpong() ? c->row_chunks : 1),
+                           (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg);
         HIPCHK(hipGetLastError());
     }
 }
@@ -826,6 +842,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             fail(KLNMF_ERR_UNSUPP, "dimension too large");
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
+        c->Gpart = nullptr; c->row_chunks = 1;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = false;
@@ -918,7 +935,25 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->stages_per_chunk = (total_stages + nch - 1) / nch;
             c->NpartF = (float *)c->dalloc((size_t)nch * c->KP * c->f_pad * 4);
             c->numerF = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
-            c->loss_part2 = (float2 *)c->dalloc(sizeof(float2) * c->nrt);
+            // Column-split update pass: with fewer than half as many 8-wave workgroups as CUs (n < ~32 000 rows; the
+            // reference's own data sets have 10^2..10^3) split every row block's columns over blockIdx.y so that the grid
+            // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
+            c->row_chunks = 1;
+            c->row_ct_chunk = c->nct;
+            if (c->pingpong() && c->KT <= 7) {
+                const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
+                int want = (2 * nwg <= c->cu_count) ? c->cu_count / nwg : 1;
+                if (const char *g = std::getenv("KLNMF_ROW_SPLIT")) want = std::max(1, std::atoi(g));
+                want = std::min(want, c->nct / 4);
+                const int64_t slab_bytes = (int64_t)c->nrt * 32 * c->KP * 4;
+                while (want > 1 && want * slab_bytes > (int64_t)256 << 20) --want;
+                if (want > 1) {
+                    c->row_ct_chunk = 4 * ((c->nct / 4 + want - 1) / want);
+                    c->row_chunks = (c->nct + c->row_ct_chunk - 1) / c->row_ct_chunk;
+                }
+                if (c->row_chunks > 1) c->Gpart = (float *)c->dalloc((size_t)c->row_chunks * slab_bytes);
+            }
+            c->loss_part2 = (float2 *)c->dalloc(sizeof(float2) * c->nrt * c->row_chunks);
         }
         reset_state(c);
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -934,6 +969,7 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         if (n > (1LL << 30) || f > (1LL << 30) || k > (1LL << 20)) fail(KLNMF_ERR_UNSUPP, "dimension too large");
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
+        c->Gpart = nullptr; c->row_chunks = 1;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = true;

@@ -225,6 +225,11 @@ struct RowPassArgs {
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
     float eps;                // c * 1e-8 (scaled units)
+    // Column-split update pass of the ping-pong kernel (few rows: one workgroup per 256 rows would leave the chip idle):
+    // blockIdx.y = column chunk of ct_chunk tiles; the workgroup leaves its part of Q.H^T in gpart[chunk][row][KP] and
+    // its loss terms in loss_part[chunk * nrt + rt]; k_wrule_slabs sums the chunks and applies the W rule.  null: whole rows.
+    float *gpart;
+    int ct_chunk;
 };
 
 // LDS per stage buffer: [dictionary image | V tiles of the 8 waves (16-bit V only)]

@@ -227,6 +227,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     const float eps = a.eps;
     const unsigned char *ht = (const unsigned char *)aa.Ht4;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
+    // column tiles [ct0, ct1) of this workgroup: all of them, or one chunk of the column-split update pass
+    const bool split = MODE == ROW_UPDATE && a.gpart != nullptr;
+    const int ct0 = split ? (int)blockIdx.y * a.ct_chunk : 0;
+    const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
 
     auto Hobj = [&](int o) -> KL_LDS unsigned char * {      // o in 0..3 (static after unrolling)
         return (KL_LDS unsigned char *)(o == 0 ? h0 : (o == 1 ? h1 : (o == 2 ? h2 : h3)));
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
 #endif
 #ifndef KL_QSTORE_EARLY   // the previous tile's ratios (still in b0 / b1) leave here, a whole tile interval before the next wait
-        if (tg > 0) store_q(tg - 1);
+        if (tg > ct0) store_q(tg - 1);
 #endif
 #ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
         v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)((tg + 1) & 3) * TB);
@@ -557,9 +561,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     };
 
     // ---- prologue: dictionary tiles 0 and 1 and V tile 0 in flight; the object of "tile -1" zero-filled
-    dma(0, 0);
-    dma(1, 1);
-    v_tile_load(vreg[0], vreg[1], vlane);
+    dma(0, ct0);
+    dma(1, ct0 + 1);
+    v_tile_load(vreg[0], vreg[1], vlane + (int64_t)ct0 * TB);
     if constexpr (FUSED) v_tile_load(vreg[2], vreg[3], vlane + (int64_t)min(1, a.nct - 1) * TB);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         const unsigned ra = lds_addr(Hobj(3));
         static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
     }
-    if (grpY) dma(2, 2);            // Y's "E(-1)": its slices of tile 2 (X issues its own in E(0), same interval)
+    if (grpY) dma(2, ct0 + 2);      // Y's "E(-1)": its slices of tile 2 (X issues its own in E(0), same interval)
 #ifdef KL_STAMPS
     unsigned long long tkP; KL_STAMP(tkP);
 #endif
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         });
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // wait states before the W rule reads G
     } else {
-    for (int t4 = 0; t4 < a.nct; t4 += 4) {
+    for (int t4 = ct0; t4 < ct1; t4 += 4) {
         static_for<0, 4>([&](auto I) {
             seg_M(I, t4 + decltype(I)::value);
             seg_E(I, t4 + decltype(I)::value);
@@ -615,9 +619,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     }
     // ---- tail: MFMA-2 of the last tile (no copies are in flight into anything it reads; no barrier needed)
     tail = true;
-    seg_M(std::integral_constant<int, 0>{}, a.nct);
+    seg_M(std::integral_constant<int, 0>{}, ct1);
 #ifndef KL_QSTORE_EARLY
-    store_q(a.nct - 1);
+    store_q(ct1 - 1);
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
@@ -626,6 +630,30 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #endif
 
     if (!active) return;
+    if (split) {
+        // column-split pass: this chunk's part of Q.H^T and of the loss; the W rule runs in k_wrule_slabs.
+        // sum(W.H) does not depend on the columns: chunk 0 contributes it.
+        if (blockIdx.y == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) a.loss_part[(int64_t)blockIdx.y * a.nrt + rt] = make_float2(s1, s2);
+        float *gp = a.gpart + ((int64_t)blockIdx.y * a.nrt * 32 + (int64_t)rt * 32 + r) * KP;
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[m][4 * g + t];
+                *(f32x4 *)(gp + 32 * m + 8 * g + 4 * h) = v;
+            }
+        return;
+    }
     if (MODE != ROW_INIT) {
         // sum over this wave's rows of (W.H) = sum_c W[row][c] * hsum[c]; hsum from LDS (staged in the prologue:
         // read from global memory here it was KS dependent round trips on the kernel's tail)
@@ -690,6 +718,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
     }
 #endif
+}
+
+// W rule of the column-split update pass: G = sum over the chunks' slabs, W_new = W_old * G (fp32 master + swizzled bf16
+// image with the eps carrier column, exactly as the tail of k_rowpass4 writes them).  One thread per 4 components.
+__global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nchunk, int64_t slab, const float *W32_old,
+                                                     float *W32_new, __bf16 *Wb_new, int64_t rows, int kp, int wld, int kc,
+                                                     const DevState *st) {
+    if (st->stop) return;
+    const int64_t total = rows * (kp / 4);
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / (kp / 4);
+        const int comp = 4 * (int)(e % (kp / 4));
+        const int64_t off = row * kp + comp;
+        f32x4 g = *(const f32x4 *)(gpart + off);
+        for (int z = 1; z < nchunk; ++z) g += *(const f32x4 *)(gpart + z * slab + off);
+        f32x4 w = *(const f32x4 *)(W32_old + off);
+        bf16x4 wb;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            w[t] *= g[t];
+            wb[t] = (comp + t == kc) ? (__bf16)1.f : (__bf16)w[t];
+        }
+        *(f32x4 *)(W32_new + off) = w;
+        *(bf16x4 *)(Wb_new + row * wld + wb_col((int)(row & 31), comp)) = wb;
+    }
 }
 
 }  // namespace klnmf

@@ -469,6 +469,7 @@ def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
     X = orc.synthetic_V(5, n, f, k)
     H0 = orc.synthetic_H0(5, f, k)
     out = {}
+    monkeypatch.setenv('KLNMF_ROW_SPLIT', '0')      # whole rows per wave in both (the column-split pass sums in another order)
     for gen in ('1', '4'):
         monkeypatch.setenv('KLNMF_ROWPASS', gen)
         m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
@@ -481,6 +482,34 @@ def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
         assert_allclose(out['4'][0], out['1'][0], rtol=2e-4, atol=1e-5 * np.abs(out['1'][0]).max())
         assert_allclose(out['4'][1], out['1'][1], rtol=2e-4, atol=1e-5 * np.abs(out['1'][1]).max())
         assert_allclose(out['4'][2], out['1'][2], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k,split', [(300, 700, 24, None), (2048, 512, 96, None), (1000, 2000, 50, '3'), (4096, 1024, 200, '8'),
+                                         (33, 130, 7, None)])
+def test_column_split_update_pass_agrees_with_whole_rows(monkeypatch, n, f, k, split):
+    """Few rows: the update pass splits every row block's columns over blockIdx.y (partial Q.H^T slabs, W rule in
+    k_wrule_slabs) so that the grid fills the chip.  Same arithmetic per element, another summation order over the
+    column chunks: fit, transform and the stop rule must agree with the whole-row pass to fp32 summation noise,
+    for the automatic chunk count and for forced ones (ragged last chunk)."""
+    X = orc.synthetic_V(9, n, f, k)
+    H0 = orc.synthetic_H0(9, f, k)
+    out = {}
+    for mode in ('0', split):
+        if mode is None:
+            monkeypatch.delenv('KLNMF_ROW_SPLIT', raising=False)
+        else:
+            monkeypatch.setenv('KLNMF_ROW_SPLIT', mode)
+        m, W, errors, _ = fit_gpu(X, H0, k, 4, 0, precision='bf16')
+        mt = nmf.KLdivNMF(n_components=k, max_iter=2, tol=0, precision='bf16')
+        mt.components_ = m.components_
+        with contextlib.redirect_stderr(io.StringIO()):
+            Wt = mt.transform(X[: max(1, n // 2)])
+        out[mode] = (W, m.components_.copy(), np.asarray(errors), Wt)
+    a, b = out['0'], out[split]
+    assert_allclose(b[2], a[2], rtol=2e-5)
+    for i in (0, 1, 3):
+        assert np.linalg.norm(b[i] - a[i]) <= 2e-3 * np.linalg.norm(a[i])
 
 
 @pytest.mark.gpu
