@@ -106,6 +106,25 @@ struct EpiW {
     __device__ void finish(double *) {}
 };
 
+// Split contraction of the W rule (few rows: n*k/4096 output tiles would leave the chip idle while each walks all of
+// f): blockIdx.z = chunk of the feature axis, partial Q.H^T into slab z; k_wrule_exact sums the slabs in a fixed order.
+template <typename T>
+struct EpiWpart {
+    T *P; int64_t k; int64_t slab;      // slab = n*k
+    __device__ void apply(int r, int c, T g) { P[blockIdx.z * slab + (int64_t)r * k + c] = g; }
+    __device__ void finish(double *) {}
+};
+template <typename T>
+__global__ void k_wrule_exact(const T *part, int nslab, int64_t count, const T *Wold, T *Wnew, int multiply,
+                              const DevState *st) {
+    if (st && st->stop) return;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        T g = T(0);
+        for (int z = 0; z < nslab; ++z) g += part[z * count + e];
+        Wnew[e] = multiply ? Wold[e] * g : g;
+    }
+}
+
 // Plain store C[r][c] = acc (reconstruction GEMM, learner.py:80-84).
 template <typename T>
 struct EpiStore {

@@ -97,6 +97,8 @@ struct klnmf_ctx {
     double *loss_part = nullptr;
     int64_t loss_part_count = 0;
     int nsplit = 1, kchunk = 0;
+    int wsplit = 1, wchunk = 0;       // exact modes: feature chunks of the W rule's contraction (few rows), slabs in Wpart
+    void *Wpart = nullptr;
 
     // CSR input in the exact modes (sparse.hip.h): structure of X in CSR and CSC order, ratio values, H^T
     bool sparse = false;
@@ -466,6 +468,20 @@ void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
         hipLaunchKernelGGL((k_sp_w<T>), dim3((unsigned)c->n), dim3(spw_threads), 0, c->stream, (const int64_t *)c->sp_indptr,
                            (const int64_t *)c->sp_indices, (const T *)qsrc, (const T *)c->W[c->cur], (const T *)c->HT,
                            (T *)c->W[c->cur ^ 1], c->k, multiply, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+    if (c->wsplit > 1) {     // few rows: contraction over f split into chunks (blockIdx.z), W rule from the slabs
+        EpiWpart<T> epip{(T *)c->Wpart, c->k, c->n * c->k};
+        dim3 gridp((unsigned)((c->k + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), (unsigned)c->wsplit);
+        hipLaunchKernelGGL((k_gemm<T, EpiWpart<T>>), gridp, dim3(256), 0, c->stream, (int)c->n, (int)c->k,
+                           (int)c->f, (const T *)qsrc, (int64_t)c->f, (int64_t)1, (const T *)c->H,
+                           (int64_t)1, (int64_t)c->f, c->wchunk, (const DevState *)c->st, epip);
+        HIPCHK(hipGetLastError());
+        const int64_t count = c->n * c->k;
+        hipLaunchKernelGGL((k_wrule_exact<T>), dim3(grid_for(count)), dim3(256), 0, c->stream, (const T *)c->Wpart,
+                           c->wsplit, count, (const T *)c->W[c->cur], (T *)c->W[c->cur ^ 1], multiply,
+                           (const DevState *)c->st);
         HIPCHK(hipGetLastError());
         return;
     }
@@ -843,6 +859,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
         c->Gpart = nullptr; c->row_chunks = 1;
+        c->Wpart = nullptr; c->wsplit = 1;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = false;
@@ -869,6 +886,21 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->kchunk = (int)chunk;
             c->Npart = c->dalloc((size_t)s * k * f * es);
             c->numer = c->dalloc((size_t)k * f * es);
+            // W rule: n*k/4096 output tiles, each contracting over all of f.  With fewer tiles than CUs split f so that
+            // the grid covers the chip about twice (KLNMF_W_SPLIT = 0 / N forces it off / to N chunks).
+            {
+                const int64_t wtiles = ((k + GT - 1) / GT) * ((n + GT - 1) / GT);
+                int64_t ws = wtiles < c->cu_count ? (2 * (int64_t)c->cu_count + wtiles - 1) / wtiles : 1;
+                if (const char *g = std::getenv("KLNMF_W_SPLIT")) ws = std::max(1, std::atoi(g));
+                ws = std::min<int64_t>(ws, (f + 4 * GK - 1) / (4 * GK));
+                while (ws > 1 && ws * n * k * (int64_t)es > ((int64_t)256 << 20)) --ws;
+                int64_t wch = (f + ws - 1) / ws;
+                wch = (wch + GK - 1) / GK * GK;
+                ws = (f + wch - 1) / wch;
+                c->wsplit = (int)ws;
+                c->wchunk = (int)wch;
+                if (ws > 1) c->Wpart = c->dalloc((size_t)ws * n * k * es);
+            }
             c->loss_part_count = ((f + GT - 1) / GT) * ((n + GT - 1) / GT);
             c->loss_part = (double *)c->dalloc(sizeof(double) * c->loss_part_count);
         } else {
@@ -970,6 +1002,7 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
         c->Gpart = nullptr; c->row_chunks = 1;
+        c->Wpart = nullptr; c->wsplit = 1;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = true;
