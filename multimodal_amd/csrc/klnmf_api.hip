@@ -876,7 +876,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->H = c->dalloc((size_t)k * f * es);
             const int64_t tiles = ((k + GT - 1) / GT) * ((f + GT - 1) / GT);
             int64_t s = (4 * (int64_t)c->cu_count + tiles - 1) / tiles;
-            const int64_t smax = (n + 255) / 256;
+            const int64_t smax = (n + 63) / 64;          // at least four contraction steps per chunk
             if (s > smax) s = smax;
             if (s < 1) s = 1;
             int64_t chunk = (n + s - 1) / s;
