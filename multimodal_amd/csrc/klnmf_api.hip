@@ -332,7 +332,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
 }
 
-void fast_colpass_q(klnmf_ctx *c) {
+void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     ColPassQArgs a{};
     a.Qt = c->Qt;
     a.Wb_new = c->Wb[c->cur ^ 1];
@@ -366,6 +366,7 @@ void fast_colpass_q(klnmf_ctx *c) {
 #undef KL_COLQ_CASE
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (!sum_slabs) return;          // the H rule sums them itself (fast_pack_H from_slabs)
     const int64_t count = (int64_t)c->KP * c->f_pad;
     hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4)), dim3(256), 0, c->stream,
                        (const float *)c->NpartF, c->numerF, count / 4, c->nchunks,
@@ -402,11 +403,11 @@ void fast_colpass(klnmf_ctx *c) {
     HIPCHK(hipGetLastError());
 }
 
-void fast_pack_H(klnmf_ctx *c, int do_update) {
+void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false) {
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
-                       (const float *)c->numerF, c->Ht, c->Ht4, c->HTb, c->hsum, c->f, c->f_pad, c->KP, do_update,
-                       do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
-                       (float)(kEpsRatio * c->v_scale));
+                       (const float *)(from_slabs ? c->NpartF : c->numerF), c->Ht, c->Ht4, c->HTb, c->hsum, c->f, c->f_pad,
+                       c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
+                       (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad);
     HIPCHK(hipGetLastError());
 }
 
@@ -543,7 +544,8 @@ void reset_state(klnmf_ctx *c) {
     HIPCHK(hipGetLastError());
 }
 
-void piece_rowpass(klnmf_ctx *c, int fit) {
+// fused_tol != nullptr (klnmf_run): the stop rule rides in the loss kernel of the bf16 modes (no k_decide launch)
+void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
     // the W rule is the same for fit and transform (nmf.py:251-253); a fit also keeps the ratios for the H rule
     if (c->is_exact()) {
         EXACT_CALL(c, exact_Q, 1);
@@ -552,7 +554,8 @@ void piece_rowpass(klnmf_ctx *c, int fit) {
         fast_rowpass(c, ROW_UPDATE, fit);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const float2 *)c->loss_part2, (int64_t)c->nrt * (c->pingpong() ? c->row_chunks : 1),
-                           (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg);
+                           (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
+                           fused_tol ? *fused_tol : 0.0, c->errors, c->cap);
         HIPCHK(hipGetLastError());
     }
 }
@@ -1266,12 +1269,26 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         check_v_overflow(c);
         reset_state(c);
         c->loop_start_cur = c->cur;
+        // bf16 modes: the stop rule inside the loss kernel -- one launch fewer per iteration (a small problem's
+        // iteration IS its kernel latencies: 7 launches of 4-10 us each).  Summing the column pass's slabs inside the
+        // H rule as well (from_slabs) was measured and is NOT used: its k blocks walk the slabs serially, 47 -> 68 us.
+        const bool fused = !c->is_exact();
+        const bool slabs = false;
         for (int64_t it = 0; it < max_iter; ++it) {
-            piece_rowpass(c, fit);
-            piece_decide(c, tol_abs);
+            if (fused) {
+                piece_rowpass(c, fit, &tol_abs);
+            } else {
+                piece_rowpass(c, fit);
+                piece_decide(c, tol_abs);
+            }
             if (fit) {
-                piece_colpass(c);
-                piece_update_H(c);
+                if (slabs) {
+                    fast_colpass_q(c, false);
+                    fast_pack_H(c, 1, true);
+                } else {
+                    piece_colpass(c);
+                    piece_update_H(c);
+                }
             }
             c->cur ^= 1;
             if (tol_abs > 0 && (it & 15) == 15) {

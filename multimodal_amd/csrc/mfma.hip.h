@@ -790,7 +790,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
                                                        __bf16 *Ht4, __bf16 *HTb, float *hsum, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
-                                                       const DevState *st, int kc, float eps_pad) {
+                                                       const DevState *st, int kc, float eps_pad,
+                                                       int nslab = 0, int64_t slab = 0) {
     if (st && st->stop) return;
     if (kc >= 0 && blockIdx.x == 0) {
         const __bf16 ev = (__bf16)eps_pad;
@@ -807,7 +808,9 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
         const float *nrow = num + (int64_t)a * f_pad;
         double s = 0;
         for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
-            const float v = row[j] * nrow[j];
+            float nj = nrow[j];
+            for (int z = 1; z < nslab; ++z) nj += nrow[z * slab + j];      // nslab > 0: num = the column pass's slabs,
+            const float v = row[j] * nj;                                    // summed here in k_sum_partials_f32's order
             row[j] = v;
             s += (double)v;
         }
@@ -909,9 +912,13 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
 }
 
 // loss_local = (ln2 * sum(s1) + sum(s2) - sum_x - C) / c   (fixed summation order)
+// decide != 0 (single-context loop, klnmf_run): the stop rule of nmf.py:214-220 in the same launch (k_decide's body;
+// one kernel latency less per iteration, which is what a small problem's iteration consists of).
 __global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, int64_t count,
                                                           const DevState *st, double inv_c,
-                                                          double *out) {
+                                                          double *out, int decide = 0, DevState *st_rw = nullptr,
+                                                          double tol_abs = 0.0, double *errors = nullptr,
+                                                          int64_t cap = 0) {
     if (st->stop) return;
     __shared__ double red[16];
     double a = 0, b = 0;
@@ -923,8 +930,18 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, in
     const double ta = block_sum(a, red);
     const double tb = block_sum(b, red);
     if (threadIdx.x == 0) {
-        out[0] = (kLn2 * ta + tb - st->sum_x - st->corr_c) * inv_c;
+        const double err = (kLn2 * ta + tb - st->sum_x - st->corr_c) * inv_c;
+        out[0] = err;
         out[1] = 0;
+        if (decide) {
+            if (st_rw->prev_err - err < tol_abs) {
+                st_rw->stop = 1;
+            } else {
+                st_rw->prev_err = err;
+                if (st_rw->n_done < cap) errors[st_rw->n_done] = err;
+                st_rw->n_done += 1;
+            }
+        }
     }
 }
 
