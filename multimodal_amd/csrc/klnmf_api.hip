@@ -216,6 +216,18 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
     const bool ep = c->kc >= 0;
 #define KL_ROW4_CASE(KTV)                                                                                       \
     case KTV:                                                                                                   \
+        if constexpr (MODE == ROW_UPDATE) {                                                                     \
+            if (grid_y > 1) {         /* column-split pass: its own instantiations (SPLIT = 1) */               \
+                if (ep) {                                                                                       \
+                    if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                    else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                } else {                                                                                        \
+                    if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                    else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                }                                                                                               \
+                break;                                                                                          \
+            }                                                                                                   \
+        }                                                                                                       \
         if (ep) {                                                                                               \
             if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
             else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
@@ -975,7 +987,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
             c->row_chunks = 1;
             c->row_ct_chunk = c->nct;
-            if (c->pingpong() && c->KT <= 7) {
+            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 int want = (2 * nwg <= c->cu_count) ? c->cu_count / nwg : 1;
                 if (const char *g = std::getenv("KLNMF_ROW_SPLIT")) want = std::max(1, std::atoi(g));

@@ -161,7 +161,7 @@ __device__ __forceinline__ void lds_wait(bf16x8 &v) {
 // the whole 512-register file -- accumulators in AGPRs -- for 8 <= KT <= 16, i.e. k <= 512: every wave then runs the X
 // order alone on its SIMD, matrix and epilogue segments in sequence; with 2*KT + KS >= 48 matrix instructions per tile
 // the epilogue is the smaller part).
-template <int KT, int ODD, int MODE, int EP = 0, int NW = kWaves4>
+template <int KT, int ODD, int MODE, int EP = 0, int NW = kWaves4, int SPLIT = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4Args aa) {
     constexpr int kWaves4 = NW, kThreads4 = 64 * NW;
     const RowPassArgs &a = aa.base;
@@ -228,7 +228,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     const unsigned char *ht = (const unsigned char *)aa.Ht4;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
     // column tiles [ct0, ct1) of this workgroup: all of them, or one chunk of the column-split update pass
-    const bool split = MODE == ROW_UPDATE && a.gpart != nullptr;
+    // SPLIT is a template parameter, not a runtime flag: the whole-row instantiation must stay the instruction stream it
+    // was (a runtime branch cost 2 % at the headline shape and spilled at KT = 16)
+    static_assert(SPLIT == 0 || (NW == 8 && MODE == ROW_UPDATE), "column-split pass: 8-wave update kernels only");
+    constexpr bool split = SPLIT != 0;
     const int ct0 = split ? (int)blockIdx.y * a.ct_chunk : 0;
     const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
 
