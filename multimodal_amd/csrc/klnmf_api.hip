@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -72,6 +74,48 @@ struct EventPair {
 
 }  // namespace
 
+// Device blocks of destroyed / re-shaped contexts are kept for the next one (per process, per device, by size class).
+// At the reference's data sizes a fit is a few milliseconds of kernels, and ~25 hipMalloc + hipFree per context cost as
+// much again (experiment.py and samples/launcher.py run many small fits and transforms in sequence).  Blocks are handed
+// back only after the owning stream has been synchronised (klnmf_destroy, klnmf_set_problem), and every block is
+// zero-filled on hand-out as a fresh one is.  KLNMF_ALLOC_CACHE_MB (default 1024; 0 = off) bounds what is kept;
+// blocks above 64 MiB are never kept.
+struct DevBlockCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;
+    size_t held = 0;
+    static size_t limit() {
+        static const size_t v = [] {
+            const char *e = std::getenv("KLNMF_ALLOC_CACHE_MB");
+            return (size_t)(e ? std::max(0, std::atoi(e)) : 1024) << 20;
+        }();
+        return v;
+    }
+    static size_t size_class(size_t bytes) {          // next power of two up to 1 MiB, then multiples of 1 MiB
+        if (bytes <= 256) return 256;
+        if (bytes <= ((size_t)1 << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+        return (bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
+    }
+    void *take(int device, size_t cls) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = free_blocks.find({device, cls});
+        if (it == free_blocks.end() || it->second.empty()) return nullptr;
+        void *p = it->second.back();
+        it->second.pop_back();
+        held -= cls;
+        return p;
+    }
+    bool give(int device, size_t cls, void *p) {
+        if (cls > ((size_t)64 << 20)) return false;
+        std::lock_guard<std::mutex> g(mu);
+        if (held + cls > limit()) return false;
+        free_blocks[{device, cls}].push_back(p);
+        held += cls;
+        return true;
+    }
+};
+static DevBlockCache g_block_cache;
+
 struct klnmf_ctx {
     int device = 0;
     int prec = KLNMF_PREC_F64;
@@ -89,7 +133,7 @@ struct klnmf_ctx {
     DevState *st = nullptr;
     double *errors = nullptr;
     double *loss_xchg = nullptr;
-    std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> allocs;      // (block, size class)
 
     // exact modes (T = double or float)
     void *V = nullptr, *W[2] = {nullptr, nullptr}, *H = nullptr, *Q = nullptr;
@@ -143,15 +187,17 @@ struct klnmf_ctx {
     size_t vsize() const { return prec == KLNMF_PREC_BF16 ? 2 : 4; }
 
     void *dalloc(size_t bytes, bool zero = true) {
-        void *p = nullptr;
         if (bytes == 0) bytes = 16;
-        HIPCHK(hipMalloc(&p, bytes));
-        allocs.push_back(p);
+        const size_t cls = DevBlockCache::size_class(bytes);
+        void *p = g_block_cache.take(device, cls);
+        if (!p) HIPCHK(hipMalloc(&p, cls));
+        allocs.push_back({p, cls});
         if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, stream));
         return p;
     }
-    void free_all() {
-        for (void *p : allocs) (void)hipFree(p);
+    void free_all() {      // callers have synchronised the stream: no kernel of this context still touches the blocks
+        for (auto &b : allocs)
+            if (!g_block_cache.give(device, b.second, b.first)) (void)hipFree(b.first);
         allocs.clear();
         for (auto &e : ev_row) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : ev_col) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
