@@ -250,7 +250,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // one round (this thread's 16 bytes of every NW KiB) of the copy of dictionary tile tg into object o: the FUSED
     // order issues the rounds one per MFMA instead of back to back (a lone wave's VMEM issue is not covered by a partner)
     constexpr int kRounds = IMG / (NW * 1024);
-    constexpr int kDmaEvery = (N2 - 3) / (kRounds > 0 ? kRounds : 1) > 0 ? (N2 - 3) / (kRounds > 0 ? kRounds : 1) : 1;
     unsigned wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave index as a scalar
     auto dma_round = [&](int o, int tg, auto Rr) {
         constexpr int rr = decltype(Rr)::value;
