@@ -167,11 +167,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal of the N > 1 code path on a one-GPU box (scripts/README.md): KLNMF_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and exchanges over gloo.  The driver's runs use one GPU per rank and RCCL ("nccl").
+    rehearsal = os.environ.get('KLNMF_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if rehearsal else 'nccl', rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
 
     n, f, k = args.n, args.f, args.k
