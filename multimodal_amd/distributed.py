@@ -117,6 +117,13 @@ class ShardedKLNMF(object):
         if self.dist is not None and self.world_size > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def _all_reduce_async(self, t):
+        """Start the collective now (it waits for what this rank's stream has enqueued so far) and return its
+        handle; the caller's later kernels are NOT ordered behind it until `handle.wait()`."""
+        if self.dist is not None and self.world_size > 1:
+            return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
     def begin(self):
         self.ctx.loop_begin()
         self.iterations_enqueued = 0
@@ -127,12 +134,16 @@ class ShardedKLNMF(object):
         self.ctx.iter_rowpass(fit)
         if fit:
             # The column pass does not depend on the stop decision (it needs W_new and the old ratio only), so
-            # it runs before the exchange and both all-reduces go out back to back: the GPUs do not idle
-            # between the two passes waiting for a 16-byte collective.  If the stop rule fires, this
+            # it runs before the numerator exchange: the GPUs do not idle between the two passes waiting for
+            # a 16-byte collective.  If the stop rule fires, this
             # iteration's numerator is simply not applied (iter_update_H is a no-op once stopped).
+            # The 16-byte loss exchange starts as soon as the row pass has left the local loss and runs on the
+            # collective's own stream WHILE the column pass computes: only the numerator exchange is exposed.
+            pending = self._all_reduce_async(self.loss_t)
             self.ctx.iter_colpass()
-            self._all_reduce(self.loss_t)
             self._all_reduce(self.numer_xchg)
+            if pending is not None:
+                pending.wait()
             self.ctx.iter_decide(tol_abs)
             self.ctx.iter_update_H()
         else:
