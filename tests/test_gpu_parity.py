@@ -684,3 +684,20 @@ def test_nearest_neighbour_measures_match_reference_golden():
     with pytest.raises(ValueError):
         ev.all_distances(A, B, unknown)
     assert ev.found_labels_to_score([1, 2, 3, 4], [1, 2, 0, 4]) == 0.75
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['bf16', 'f64'])
+def test_reused_device_blocks_do_not_change_results(precision):
+    """Contexts take their device memory from a per-process block cache (klnmf_api.hip, DevBlockCache): a fit whose
+    buffers are recycled blocks of an earlier, differently shaped problem (padding regions included) must give the
+    bits of the same fit on fresh memory."""
+    Xa, Ha = orc.synthetic_V(3, 300, 200, 12), orc.synthetic_H0(3, 200, 12)
+    Xb, Hb = orc.synthetic_V(4, 1000, 700, 40), orc.synthetic_H0(4, 700, 40)
+    first = fit_gpu(Xa, Ha, 12, 5, 0, precision=precision)
+    fit_gpu(Xb, Hb, 40, 3, 0, precision=precision)            # dirties larger blocks of every size class in between
+    fit_gpu(2.0 * Xa[:257, :130], orc.synthetic_H0(5, 130, 9), 9, 2, 0, precision=precision)
+    again = fit_gpu(Xa, Ha, 12, 5, 0, precision=precision)
+    np.testing.assert_array_equal(first[1], again[1])          # W
+    np.testing.assert_array_equal(first[0].components_, again[0].components_)
+    np.testing.assert_array_equal(np.asarray(first[2]), np.asarray(again[2]))
