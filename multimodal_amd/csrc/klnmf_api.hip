@@ -462,8 +462,12 @@ void fast_colpass(klnmf_ctx *c) {
 }
 
 void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false) {
+    // ping-pong row pass + stored-ratio column pass read only the Ht4 tile images (KLNMF_ROWPASS / KLNMF_COLPASS are read
+    // once, in klnmf_set_problem, so the choice cannot change under a context)
+    const bool lean = c->pingpong() && c->Qt != nullptr;
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
-                       (const float *)(from_slabs ? c->NpartF : c->numerF), c->Ht, c->Ht4, c->HTb, c->hsum, c->f, c->f_pad,
+                       (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (__bf16 *)nullptr : c->Ht, c->Ht4,
+                       lean ? (__bf16 *)nullptr : c->HTb, c->hsum, c->f, c->f_pad,
                        c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
                        (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad);
     HIPCHK(hipGetLastError());

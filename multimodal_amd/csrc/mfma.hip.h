@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
         const __bf16 ev = (__bf16)eps_pad;
         for (int64_t j = threadIdx.x; j < f_pad; j += blockDim.x) {
             if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(kc, (int)(j % 32))] = ev;
-            HTb[j * kp + kc] = ev;
+            if (HTb) HTb[j * kp + kc] = ev;
         }
     }
     __shared__ double red[16];
@@ -824,9 +824,11 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     double hs = 0;
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
         const __bf16 v = (__bf16)row[j];
-        Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + h_col_perm((int)(j % kStageCols))] = v;
+        // Ht / HTb: images of the generation-1 row pass and of the recomputing column pass -- null where the ping-pong row
+        // pass and the stored-ratio column pass run (the transposed 2-byte stores of HTb were most of this kernel's time)
+        if (Ht) Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + h_col_perm((int)(j % kStageCols))] = v;
         if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(a, (int)(j % 32))] = v;   // mfma4.hip.h tile images (swizzled)
-        HTb[j * kp + a] = v;
+        if (HTb) HTb[j * kp + a] = v;
         hs += (double)(float)v;
     }
     const double ths = block_sum(hs, red);
