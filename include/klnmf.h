@@ -152,6 +152,11 @@ int klnmf_bind_exchange(klnmf_ctx *ctx, void *loss_ptr, void *numer_ptr);
  * methods).  Synchronous. */
 /* error(X, W, H)                      nmf.py:297-310 + metrics.py:18-20 */
 int klnmf_error(klnmf_ctx *ctx, double *loss);
+/* Diagnostic: the terms klnmf_error assembles in the 16-bit modes, in the caller's units:
+ * terms[0] = sum x~ ln((x~+eps)/(W.H+eps)), [1] = sum W.H, [2] = sum x~ (V as stored),
+ * [3] = the storage-rounding correction C = KL(x~ || x); loss = [0] + [1] - [2] - [3]
+ * (metrics.py:18-20 split into its three sums).  KLNMF_ERR_UNSUPP in the exact modes. */
+int klnmf_loss_terms(klnmf_ctx *ctx, double *terms);
 /* one _update(X, W, _fit) without stop rule: nmf.py:232-257 */
 int klnmf_update(klnmf_ctx *ctx, int fit);
 /* eps of klnmf_step_Q (the `eps=` argument of _Q, nmf.py:325; default 1e-8).

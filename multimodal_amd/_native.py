@@ -61,6 +61,7 @@ SIGNATURES = {
                                           _c.POINTER(_c.c_int)]),
     'klnmf_bind_exchange': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_void_p]),
     'klnmf_error': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double)]),
+    'klnmf_loss_terms': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double)]),
     'klnmf_update': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_set_ratio_eps': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_step_Q': (_c.c_int, [_ctx_p]),
@@ -398,6 +399,11 @@ class Context(object):
         out = _c.c_double(0)
         _check(self._lib.klnmf_error(self._h, ctypes.byref(out)))
         return out.value
+
+    def loss_terms(self):
+        out = (ctypes.c_double * 4)()
+        _check(self._lib.klnmf_loss_terms(self._h, out))
+        return [float(v) for v in out]
 
     def update(self, fit=True):
         _check(self._lib.klnmf_update(self._h, 1 if fit else 0))

@@ -167,10 +167,10 @@ struct klnmf_ctx {
     __bf16 *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
     int row_gen = 4;
     int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
-    float *hsum = nullptr;
+    double *hsum = nullptr;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     float *NpartF = nullptr, *numerF = nullptr;
-    float2 *loss_part2 = nullptr;
+    double2 *loss_part2 = nullptr;
 
     // profiling
     double ratio_eps = kEpsRatio;   // only the step API honours a non-default value
@@ -615,7 +615,7 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
     } else {
         fast_rowpass(c, ROW_UPDATE, fit);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
-                           (const float2 *)c->loss_part2, (int64_t)c->nrt * (c->pingpong() ? c->row_chunks : 1),
+                           (const double2 *)c->loss_part2, (int64_t)c->nrt * (c->pingpong() ? c->row_chunks : 1),
                            (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
                            fused_tol ? *fused_tol : 0.0, c->errors, c->cap);
         HIPCHK(hipGetLastError());
@@ -1013,7 +1013,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
             // carrier column at 1) and a spare component inside the MFMA-1 contraction range
             c->kc = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
-            c->hsum = (float *)c->dalloc((size_t)c->KP * 4);
+            c->hsum = (double *)c->dalloc((size_t)c->KP * 8);
 #ifdef KL_STAMPS
             c->stamps = (unsigned long long *)c->dalloc((size_t)c->nrt * 8 * 8);
 #endif
@@ -1050,7 +1050,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
                 }
                 if (c->row_chunks > 1) c->Gpart = (float *)c->dalloc((size_t)c->row_chunks * slab_bytes);
             }
-            c->loss_part2 = (float2 *)c->dalloc(sizeof(float2) * c->nrt * c->row_chunks);
+            c->loss_part2 = (double2 *)c->dalloc(sizeof(double2) * c->nrt * c->row_chunks);
         }
         reset_state(c);
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1404,7 +1404,7 @@ int klnmf_error(klnmf_ctx *c, double *loss) {
         } else {
             fast_rowpass(c, ROW_LOSS);
             hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
-                               (const float2 *)c->loss_part2, (int64_t)c->nrt,
+                               (const double2 *)c->loss_part2, (int64_t)c->nrt,
                                (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg);
             HIPCHK(hipGetLastError());
         }
@@ -1412,6 +1412,27 @@ int klnmf_error(klnmf_ctx *c, double *loss) {
         HIPCHK(hipMemcpyAsync(h, c->loss_xchg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (loss) *loss = h[0];
+    });
+}
+
+int klnmf_loss_terms(klnmf_ctx *c, double *terms) {
+    return guarded([&] {
+        need_problem(c);
+        if (c->is_exact()) fail(KLNMF_ERR_UNSUPP, "klnmf_loss_terms: the exact modes evaluate the loss per element");
+        if (!terms) fail(KLNMF_ERR_ARG, "null destination");
+        reset_state(c);
+        fast_rowpass(c, ROW_LOSS);
+        std::vector<double2> parts((size_t)c->nrt);
+        DevState hs{};
+        HIPCHK(hipMemcpyAsync(parts.data(), c->loss_part2, sizeof(double2) * parts.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        double a = 0, b = 0;
+        for (const double2 &p : parts) { a += p.x; b += p.y; }
+        terms[0] = kLn2 * a / c->v_scale;
+        terms[1] = b / c->v_scale;
+        terms[2] = hs.sum_x / c->v_scale;
+        terms[3] = hs.corr_c / c->v_scale;
     });
 }
 

@@ -217,8 +217,8 @@ struct RowPassArgs {
     const float *W32_old;     // [n_pad][KP]
     __bf16 *Wb_new;
     float *W32_new;
-    float2 *loss_part;        // [nrt] (sum x*log2 q, sum y)
-    const float *hsum;        // [KP] row sums of the bf16-rounded dictionary (for sum(W.H))
+    double2 *loss_part;       // [nrt] (sum x*log2 q, sum y)
+    const double *hsum;       // [KP] row sums of the 16-bit dictionary image (for sum(W.H)), see row_sum_wh
     unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
     unsigned char *Qt;            // ratio tiles for k_colpass_q ([nct][nrt][2 KiB], see there), or null (ping-pong pass only)
     int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f;
     const float eps = a.eps;
 
     const unsigned char *ht = (const unsigned char *)a.Ht;
@@ -444,13 +444,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
         // sum_j (W.H)_ij = sum_a W_ia * rowsum(H)_a (the reference's sparse branch uses the
         // same identity, nmf.py:303-304); with the bf16 operands the MFMA sees, so it equals
         // the accumulated W.H up to fp32 summation order.  Lane (r,h) holds W[r][16s+8h+j].
+        double s2d = 0.0;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], a.hsum[16 * s + 8 * h + j], s2);
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) a.loss_part[rt] = make_float2(s1, s2);
+            for (int j = 0; j < 8; ++j) s2d = fma((double)(float)wf[s][j], a.hsum[16 * s + 8 * h + j], s2d);
+        const double s1w = wave_sum((double)s1);
+        s2d = wave_sum(s2d);
+        if (lane == 0) a.loss_part[rt] = make_double2(s1w, s2d);
     }
     if (MODE != ROW_LOSS) {
         // acc[m] reg (g,t): component 32m + 8g + 4h + t of sample row r
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 // images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
 // loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
 __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
-                                                       __bf16 *Ht4, __bf16 *HTb, float *hsum, int64_t f,
+                                                       __bf16 *Ht4, __bf16 *HTb, double *hsum, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
                                                        const DevState *st, int kc, float eps_pad,
                                                        int nslab = 0, int64_t slab = 0) {
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
         hs += (double)(float)v;
     }
     const double ths = block_sum(hs, red);
-    if (threadIdx.x == 0) hsum[a] = (float)ths;
+    if (threadIdx.x == 0) hsum[a] = ths;
 }
 
 __global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wld, int kc) {
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
 // loss_local = (ln2 * sum(s1) + sum(s2) - sum_x - C) / c   (fixed summation order)
 // decide != 0 (single-context loop, klnmf_run): the stop rule of nmf.py:214-220 in the same launch (k_decide's body;
 // one kernel latency less per iteration, which is what a small problem's iteration consists of).
-__global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, int64_t count,
+__global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, int64_t count,
                                                           const DevState *st, double inv_c,
                                                           double *out, int decide = 0, DevState *st_rw = nullptr,
                                                           double tol_abs = 0.0, double *errors = nullptr,
@@ -925,9 +926,9 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const float2 *part, in
     __shared__ double red[16];
     double a = 0, b = 0;
     for (int64_t e = threadIdx.x; e < count; e += blockDim.x) {
-        const float2 p = part[e];
-        a += (double)p.x;
-        b += (double)p.y;
+        const double2 p = part[e];
+        a += p.x;
+        b += p.y;
     }
     const double ta = block_sum(a, red);
     const double tb = block_sum(b, red);

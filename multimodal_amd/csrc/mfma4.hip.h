@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     __shared__ __attribute__((aligned(16))) unsigned char h1[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char h2[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char h3[OBJ];
-    __shared__ __attribute__((aligned(16))) float hsum_lds[KP];      // row sums of H, for the sum(W.H) term of the loss
+    __shared__ __attribute__((aligned(16))) double hsum_lds[KP];     // row sums of H, for the sum(W.H) term of the loss
     if (a.st->stop) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f;
+    double s2 = 0.0;
     const float eps = a.eps;
     const unsigned char *ht = (const unsigned char *)aa.Ht4;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
@@ -639,11 +640,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
+                for (int j = 0; j < 8; ++j) s2 = fma((double)(float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
         }
-        s1 = wave_sum(s1);
+        const double s1w = wave_sum((double)s1);
         s2 = wave_sum(s2);
-        if (lane == 0) a.loss_part[(int64_t)blockIdx.y * a.nrt + rt] = make_float2(s1, s2);
+        if (lane == 0) a.loss_part[(int64_t)blockIdx.y * a.nrt + rt] = make_double2(s1w, s2);
         float *gp = a.gpart + ((int64_t)blockIdx.y * a.nrt * 32 + (int64_t)rt * 32 + r) * KP;
 #pragma unroll
         for (int m = 0; m < KT; ++m)
@@ -658,14 +659,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     }
     if (MODE != ROW_INIT) {
         // sum over this wave's rows of (W.H) = sum_c W[row][c] * hsum[c]; hsum from LDS (staged in the prologue:
-        // read from global memory here it was KS dependent round trips on the kernel's tail)
+        // read from global memory here it was KS dependent round trips on the kernel's tail).  In DOUBLE: the rows
+        // of a fitted dictionary sum to 1 up to the rounding of its 16-bit image (hsum = 1 + 1e-5), the W operands
+        // have 8-11 significant bits, so in an fp32 chain every product's deviation from W falls below the
+        // rounding step of the running sum in the SAME way for every row -- sum_a colsum(W)_a (hsum_a - 1) was
+        // lost or kept as a whole, +-2e-7 of sum(V) per evaluation, 1e-4 of the loss at 250000 x 12288, k = 500
+        // (scripts/loss_terms_check.py; this, not operand rounding, is what tripped tol = 0 in round 1).
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s2 = fmaf((float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
-        s1 = wave_sum(s1);
+            for (int j = 0; j < 8; ++j) s2 = fma((double)(float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
+        const double s1w = wave_sum((double)s1);
         s2 = wave_sum(s2);
-        if (lane == 0) a.loss_part[rt] = make_float2(s1, s2);
+        if (lane == 0) a.loss_part[rt] = make_double2(s1w, s2);
     }
     if (MODE != ROW_LOSS) {
         // W rule.  All loads of the old fp32 master are issued before the first use (the operand fragments,

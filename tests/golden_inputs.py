@@ -86,3 +86,18 @@ def g8_edge_inputs():
     X[4, :] = 0
     X[:, 2] = 0
     return X, H0
+
+
+def synthetic_problem(seed, n, f, k, block=8192):
+    """The seeded synthetic workload of SURVEY.md section 8d (factorisable + noise, per-row-block RandomState
+    streams) and its H0 -- the inputs of the large fixtures (tests/golden/make_golden_large.py) and of bench.py
+    (multimodal_amd/synthetic.py generates the same blocks; tests/test_host_cpu.py checks they agree)."""
+    Ht = np.random.RandomState(seed).gamma(0.5, 1.0, (k, f))
+    X = np.empty((n, f))
+    for b, r0 in enumerate(range(0, n, block)):
+        r1 = min(n, r0 + block)
+        rs = np.random.RandomState(seed + 1 + b)
+        Wt = rs.gamma(1.0, 1.0, (r1 - r0, k))
+        X[r0:r1] = Wt.dot(Ht) / k + 0.05 * rs.random_sample((r1 - r0, f))
+    H0 = _normalize_rows(np.random.RandomState(seed - 1).random_sample((k, f)) + .01)
+    return X, H0
