@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: KL-NMF update-iterations/s at V = 1M x 4096, k = 200
-(BASELINE.json `metric`, config 4), V row-sharded over N GPUs of one node.
+(BASELINE.json `metric`, configs[3]), V row-sharded over N GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+    python bench.py --gpus 1 --steps 40 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one fit iteration of reference nmf.py:212-222: loss + ratio +
-W rule (row pass), stop rule, H numerator (column pass), all-reduce of the
-k x f numerator over the ranks, H rule + row normalisation.  Inputs (V tiles, W0,
-H0) are resident in HBM before the timed region.  Rank 0 prints one JSON line.
+A "step" is one fit iteration of reference nmf.py:212-222: loss + ratio + W rule (row pass), stop rule with
+tol = 0 as MultimodalLearner.train sets it (learner.py:39-40), H numerator (column pass), all-reduce of the k x f
+numerator over the ranks, H rule + row normalisation.  Inputs (V tiles, W0, H0) are resident in HBM before the
+timed region.  Protocol: `--repeats` (5) independent fits from the same start; in each, W untimed
+warm-up iterations, then EXACTLY K iterations timed between barrier + synchronize fences, the maximum over ranks
+taken per segment; `value` = K / median segment time.  Rank 0 prints one JSON line.
 
-Strong scaling: the total problem (n rows) is fixed, each rank holds n/N rows.
+Data: the seeded block-wise synthetic V of SURVEY.md 8d (multimodal_amd/synthetic.py: per-row-block RandomState
+streams), the same bytes the CPU baseline sees.  Strong scaling: the problem (n rows) is fixed, rank r holds n/N rows.
+
+Roofline accounting: the dominant kernel's ALGORITHMIC work per launch -- 4 n f k flops (W.H and
+Q.H^T, unpadded k) and n f s_V + 2 n k 4 bytes (V once, fp32 W in and out) -- divided by its HIP-event time; what
+the schedule additionally moves (ratio tiles, 16-bit W images) is reported beside it as `schedule_bytes_per_launch`
+and the PMC-measured HBM bytes as `traffic`.
 """
 import argparse
 import json
 import os
+import platform
+import statistics
 import sys
 import time
 
@@ -28,44 +38,56 @@ if ROOT not in sys.path:
 # MI355X peaks (MI355X_MICROARCH.md): dense bf16 MFMA, HBM3E
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--steps', type=int, default=40)
     p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--repeats', type=int, default=5, help='independent timed segments of --steps iterations (median reported)')
     p.add_argument('--n', type=int, default=1000000)
     p.add_argument('--f', type=int, default=4096)
     p.add_argument('--k', type=int, default=200)
     p.add_argument('--precision', default='bf16', choices=['bf16', 'bf16_v32', 'f32', 'f64'])
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-rows', type=int, default=8192)
+    p.add_argument('--cpu-rows', type=int, default=100000, help='rows of the same V the CPU baseline is timed on (BASELINE.md 3)')
+    p.add_argument('--cpu-iters', type=int, default=3)
     p.add_argument('--seed', type=int, default=1234)
-    p.add_argument('--tol', type=float, default=None,
-                   help='stop-rule tolerance of nmf.py:207,215 (relative; x n x f inside).  Default: the rule is evaluated every '
-                        'iteration but can never fire, so that exactly --steps full iterations are timed: with tol = 0 '
-                        '(MultimodalLearner.train) a loss that rises by bf16 rounding noise on the plateau of the synthetic '
-                        'problem would stop the loop and the remaining timed launches would return at their first instruction')
-    return p.parse_args()
+    p.add_argument('--data', default='blocks', choices=['blocks', 'device'],
+                   help="blocks: the seeded RandomState blocks of SURVEY 8d (host-generated, identical to the CPU baseline's "
+                        "data); device: a torch generator on the GPU (fast set-up for profiling runs, different values)")
+    p.add_argument('--tol', type=float, default=0.0,
+                   help='stop-rule tolerance of nmf.py:207,215 (relative; x n x f inside).  0 = MultimodalLearner.train')
+    return p.parse_args(argv)
 
 
 def make_H0(seed, f, k):
     """Row-normalised |U(0,1)| + 0.01 (the reference's init rule, nmf.py:149-151)."""
-    h = np.random.RandomState(seed - 1).random_sample((k, f)) + .01
-    return h / (1e-16 + h.sum(axis=1, keepdims=True))
+    from multimodal_amd import synthetic
+    return synthetic.H0_of(seed, f, k)
+
+
+def fill_shard_blocks(model, seed, r0, r1, n, f, k, vscale=1.0):
+    """Global rows [r0, r1) of the seeded synthetic V into the model's shard.  Two passes over the block
+    generator: the 16-bit storage factor needs the GLOBAL maximum before the first upload."""
+    from multimodal_amd import synthetic
+    vmax = synthetic.for_each_block(seed, r0, r1, n, f, k, None)
+    model.set_v_max(vmax * vscale)
+    synthetic.for_each_block(seed, r0, r1, n, f, k,
+                             lambda lo, arr: model.upload_V(arr, row0=lo, col0=0, scale=vscale))
 
 
 def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192, vscale=1.0):
-    """Synthetic non-negative V = Wt.Ht/k + 0.05*U (factorisable + noise, SURVEY 8d
-    shape), generated block-wise on the GPU and fed to the tiling upload.  `vscale` multiplies the matrix on its way
-    in (the upload's per-modality coefficient, learner.py:53-56): tests use it for the homogeneity property."""
+    """Synthetic non-negative V = Wt.Ht/k + 0.05*U of the same family, generated block-wise ON the GPU and fed to the
+    tiling upload (seconds instead of a minute at 1M rows; used by profiling runs and the full-size property tests).
+    `vscale` multiplies the matrix on its way in (the upload's per-modality coefficient, learner.py:53-56)."""
     dev = torch.device('cuda', torch.cuda.current_device())
     g = torch.Generator(device=dev)
     g.manual_seed(seed)                       # Ht identical on every rank
     # Gamma(1/2) = N(0,1)^2 / 2 and Gamma(1) = -log(U): built from randn / rand only, whose streams are reproduced
-    # exactly by restoring the generator state (torch._standard_gamma's rejection sampler is not: a second pass
-    # produced different values, the maximum of the first pass was exceeded and fp16 storage overflowed)
+    # exactly by restoring the generator state (torch._standard_gamma's rejection sampler is not)
     Ht = torch.randn((k, f), device=dev, generator=g).square_().mul_(0.5)
     g.manual_seed(seed + 1000 * (rank + 1))
 
@@ -74,8 +96,6 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192, vscal
         Vb = torch.rand((rows, f), device=dev, generator=g).mul_(0.05)
         Vb.addmm_(Wt, Ht, alpha=1.0 / k)
         return Vb
-    # the 16-bit storage factor needs the global max before the first upload:
-    # generate once for the max, then regenerate the identical stream for the upload
     state = g.get_state()
     vmax = 0.0
     for r0 in range(0, n_local, block):
@@ -89,58 +109,105 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192, vscal
 
 
 def measured_traffic(args, n_local):
-    """HBM bytes per row-pass launch from the committed PMC run of this exact workload
-    (profiles/r01_pmc_traffic.json, produced by scripts/pmc_profile.sh); None if the
-    workload differs -- the counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    """HBM bytes per launch of the hot kernels from the committed PMC passes of this exact workload
+    (profiles/r02_pmc_traffic.json, produced by scripts/pmc_profile.sh: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs, gfx950 correction applied); None if the workload differs -- counters cannot be read in-process."""
     try:
-        d = json.load(open(path))
+        d = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
     except Exception:
-        return None
-    w = d.get('workload', {})
-    if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) != (n_local, args.f, args.k, args.precision):
-        return None
-    for name, v in d.get('kernels', {}).items():
-        if 'k_rowpass' in name:
-            return v['hbm_bytes_per_launch']
-    return None
+        return None, None
+    for entry in d.get('workloads', []):
+        w = entry.get('workload', {})
+        if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision):
+            row = col = None
+            for name, v in entry.get('kernels', {}).items():
+                if 'k_rowpass' in name:
+                    row = v['hbm_bytes_per_launch']
+                elif 'k_colpass' in name:
+                    col = v['hbm_bytes_per_launch']
+            return row, col
+    return None, None
+
+
+def host_info():
+    info = {'cpu_model': platform.processor() or 'unknown', 'numpy': np.__version__}
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                info['cpu_model'] = line.split(':', 1)[1].strip()
+                break
+    except Exception:
+        pass
+    try:
+        info['cores'] = len(os.sched_getaffinity(0))
+    except Exception:
+        info['cores'] = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        info['blas'] = [{k: v for k, v in t.items() if k in ('internal_api', 'version', 'num_threads', 'threading_layer', 'architecture')}
+                        for t in threadpool_info() if t.get('user_api') == 'blas']
+    except Exception:
+        info['blas'] = None
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                info['mem_available_gb'] = int(line.split()[1]) / 1e6
+    except Exception:
+        pass
+    return info
 
 
 def cpu_baseline(args):
-    """The oracle (numpy restatement of the reference loop, fp64, same redundant
-    work) timed on this host's cores on a bounded row sample of the workload."""
+    """The oracle (numpy restatement of the reference loop: fp64, a separate W.H for the loss and for the ratio, all
+    temporaries) timed on this host's cores on the first `cpu_rows` rows of the SAME seeded V the GPU run uses, plus
+    the "optimised CPU" variant (one W.H, float32).  Work is exactly linear in n, so the sample's rate scales to n."""
     from oracle import klnmf_oracle as orc
+    from multimodal_amd import synthetic
+    host = host_info()
     rows, f, k = min(args.cpu_rows, args.n), args.f, args.k
-    X = orc.synthetic_V(args.seed, rows, f, k)
+    # the faithful restatement holds ~6 n x f float64 arrays: shrink the sample rather than risk the box
+    need_gb = 7 * rows * f * 8 / 1e9
+    avail = host.get('mem_available_gb')
+    if avail is not None and need_gb > 0.5 * avail:
+        rows = max(8192, int(rows * 0.5 * avail / need_gb) // 8192 * 8192)
+    X = synthetic.rows_of(args.seed, 0, rows, args.n, f, k)
     H0 = make_H0(args.seed, f, k)
     W, H = orc.init_factors(X, k, H0=H0)
-    t_total, iters = 0.0, 0
-    losses = []
-    while iters < 2 or (t_total < 8.0 and iters < 6):
+    losses, times = [], []
+    for it in range(1 + args.cpu_iters):              # the first iteration is the warm-up (page faults, BLAS threads)
         t0 = time.perf_counter()
         losses.append(orc.kl_error(X, W, H))
         W, H = orc.update_step(X, W, H, fit=True)
-        t_total += time.perf_counter() - t0
-        iters += 1
+        times.append(time.perf_counter() - t0)
     final = orc.kl_error(X, W, H)
-    per_iter = t_total / iters
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count()
-    its_sample = 1.0 / per_iter
-    return {
-        'value': its_sample * rows / args.n,          # work is exactly linear in n
+    per_iter = statistics.median(times[1:])
+    X32 = X.astype(np.float32)
+    W32, H32 = (a.astype(np.float32) for a in orc.init_factors(X, k, H0=H0))
+    t32 = []
+    for it in range(1 + args.cpu_iters):
+        t0 = time.perf_counter()
+        _, W32, H32 = orc.fit_iteration_lean32(X32, W32, H32)
+        t32.append(time.perf_counter() - t0)
+    lean = statistics.median(t32[1:])
+    del X32, W32, H32
+    base = {
+        'value': (1.0 / per_iter) * rows / args.n,
         'unit': 'it/s',
-        'cores': cores,
+        'cores': host.get('cores'),
         'kind': 'port',
-        'sample': 'n=%d of %d rows at f=%d, k=%d, %d fp64 iterations of the numpy oracle '
-                  '(%.2f s/iter on the sample), scaled linearly in n' % (rows, args.n, f, k, iters, per_iter),
-    }, (X, H0, iters, losses, final)
+        'sample': 'rows [0, %d) of the same seeded %d x %d V, k=%d: 1 warm-up + %d timed fp64 iterations of the numpy '
+                  'restatement of nmf.py:212-222 (median %.2f s/iteration on the sample), scaled linearly in n (extrapolated)'
+                  % (rows, args.n, f, k, args.cpu_iters, per_iter),
+        'cpu_model': host.get('cpu_model'), 'numpy': host.get('numpy'), 'blas': host.get('blas'),
+        'optimised_cpu': {'value': (1.0 / lean) * rows / args.n, 'unit': 'it/s',
+                          'what': 'one W.H per iteration, float32, temporaries reused (oracle.fit_iteration_lean32), '
+                                  'median %.2f s/iteration on the same sample' % lean},
+    }
+    return base, (X, H0, len(times), losses, final)
 
 
 def gpu_parity_on_sample(args, sample):
-    """Same row sample through the HIP path: final KL relative to the oracle."""
+    """The CPU baseline's row sample through the HIP path: every recorded loss and the final KL against the oracle."""
     from multimodal_amd import _native
     X, H0, iters, losses, final = sample
     with _native.Context(args.precision, device=0) as ctx:
@@ -151,8 +218,9 @@ def gpu_parity_on_sample(args, sample):
         errs, n_done, stopped = ctx.run(iters, True, 0.0)
         g_final = ctx.error()
     return {'final_kl_rel_err': abs(g_final - final) / abs(final),
-            'first_loss_rel_err': abs(errs[0] - losses[0]) / abs(losses[0]),
-            'iterations': iters, 'rows': int(X.shape[0])}
+            'max_loss_rel_err': float(max(abs(a - b) / abs(b) for a, b in zip(errs, losses))) if len(errs) == len(losses) else None,
+            'len_errors': [int(len(errs)), int(len(losses))],
+            'iterations': iters, 'rows': int(X.shape[0]), 'tolerance': 1e-4}
 
 
 def main():
@@ -180,64 +248,97 @@ def main():
     n_gpus = world if world > 1 else 1
 
     n, f, k = args.n, args.f, args.k
-    tol = -1e300 / (float(n) * f) if args.tol is None else args.tol
     r0, r1 = row_partition(n, n_gpus)[rank]
     n_local = r1 - r0
-    total_iters = args.warmup + args.steps
-    model = ShardedKLNMF(n, n_local, f, k, max_iter=total_iters, precision=args.precision)
-    fill_shard_device(torch, model, args.seed, rank, n_local, f, k)
-    model.set_H(make_H0(args.seed, f, k))
-    model.init_W()
+    iters_per_fit = args.warmup + args.steps
+    t_setup = time.perf_counter()
+    model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision)
+    if args.data == 'blocks':
+        fill_shard_blocks(model, args.seed, r0, r1, n, f, k)
+    else:
+        fill_shard_device(torch, model, args.seed, rank, n_local, f, k)
+    H0 = make_H0(args.seed, f, k)
     info = _native.device_info(local_rank)
+    t_setup = time.perf_counter() - t_setup
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    model.begin()
-    for _ in range(args.warmup):
-        model.iterate(fit=True, tol=tol)
-    model.ctx.profile_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.iterate(fit=True, tol=tol)
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = model.ctx.profile_read(reset=True)
-    model.ctx.profile_enable(False)
-    errors, n_done, stopped = model.end()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    segments, fits = [], []
+    prof_tot = {'rowpass_ms': 0.0, 'rowpass_launches': 0, 'colpass_ms': 0.0, 'colpass_launches': 0}
+    for rep in range(max(1, args.repeats)):
+        model.set_H(H0)
+        model.init_W()
+        model.begin()
+        for _ in range(args.warmup):
+            model.iterate(fit=True, tol=args.tol)
+        model.ctx.profile_enable(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.iterate(fit=True, tol=args.tol)
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = model.ctx.profile_read(reset=True)
+        model.ctx.profile_enable(False)
+        errors, n_done, stopped = model.end()
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        segments.append(float(t.item()))
+        fits.append((list(errors), int(n_done), bool(stopped)))
+        for key in prof_tot:
+            prof_tot[key] += prof[key]
 
     if rank == 0:
+        elapsed = statistics.median(segments)
         ms_per_step = 1e3 * elapsed / args.steps
         its = args.steps / elapsed
-        row_ms = prof['rowpass_ms'] / max(1, prof['rowpass_launches'])
-        col_ms = prof['colpass_ms'] / max(1, prof['colpass_launches'])
-        flops_row = 4.0 * n_local * f * k          # W.H and Q.H^T, unpadded k
-        flops_col = 2.0 * n_local * f * k          # W_new^T.Q
+        row_ms = prof_tot['rowpass_ms'] / max(1, prof_tot['rowpass_launches'])
+        col_ms = prof_tot['colpass_ms'] / max(1, prof_tot['colpass_launches'])
         vbytes = 2 if args.precision == 'bf16' else 4
         pingpong = (args.precision == 'bf16' and (k <= 224 or 256 < k <= 512)
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
-        # the H rule runs on the ratios the row pass stores (2 B per element of V) unless the recomputing kernel is forced
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
-        # bytes the row-pass launch must move by its contract: V once, W fp32 in and out, W bf16 in and out,
-        # and -- stored-ratio schedule -- the ratio tiles out
-        bytes_row = n_local * f * vbytes + n_local * k * (4 + 4 + 2 + 2) + (n_local * f * 2 if stored_q else 0)
-        bytes_col = (n_local * f * 2 + n_local * k * 2) if stored_q else (n_local * f * vbytes + 2 * n_local * k * 2)
-        row_tflops = flops_row / (row_ms * 1e-3) / 1e12 if row_ms > 0 else None
-        row_gbs = bytes_row / (row_ms * 1e-3) / 1e9 if row_ms > 0 else None
-        mfma_view = {'achieved': row_tflops, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': row_tflops / PEAK_BF16_TFLOPS if row_tflops else None}
-        hbm_view = {'achieved': row_gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': row_gbs / 8000.0 if row_gbs else None}
-        # binding roofline of the launch = the larger of the two lower bounds (t_min = max(flops/P, bytes/BW))
-        hbm_bound = bytes_row / 8000e9 > flops_row / (PEAK_BF16_TFLOPS * 1e12)
-        head, other = (hbm_view, mfma_view) if hbm_bound else (mfma_view, hbm_view)
+        qbytes = _native.ratio_tile_bytes() if stored_q else 0
+        # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures
+        flops_row = 4.0 * n_local * f * k
+        alg_bytes_row = n_local * f * vbytes + 2 * n_local * k * 4
+        sched_bytes_row = alg_bytes_row + 2 * n_local * k * 2 + n_local * f * qbytes      # + 16-bit W images in/out + ratio tiles out
+        flops_col = 2.0 * n_local * f * k
+        sched_bytes_col = (n_local * f * qbytes + n_local * k * 2) if stored_q else (n_local * f * vbytes + 2 * n_local * k * 2)
+        t_mfma = flops_row / (PEAK_BF16_TFLOPS * 1e12)
+        t_hbm = alg_bytes_row / (PEAK_HBM_GBS * 1e9)
+        mfma_bound = t_mfma >= t_hbm
+        row_s = row_ms * 1e-3
+        row_tflops = flops_row / row_s / 1e12 if row_s > 0 else None
+        row_gbs = alg_bytes_row / row_s / 1e9 if row_s > 0 else None
+        traffic_row, traffic_col = measured_traffic(args, n_local)
+        roofline = {
+            'kernel': ('k_rowpass4' if pingpong else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule'
+                      + (', ratio tiles stored for the H rule)' if stored_q else ')'),
+            'bound': 'mfma' if mfma_bound else 'hbm',
+            'achieved': row_tflops if mfma_bound else row_gbs,
+            'peak': PEAK_BF16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+            'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+            'frac': ((row_tflops / PEAK_BF16_TFLOPS) if mfma_bound else (row_gbs / PEAK_HBM_GBS)) if row_s > 0 else None,
+            'traffic': traffic_row,
+            'traffic_source': PMC_TRAFFIC_FILE if traffic_row else None,
+            'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'],
+            'algorithmic_flops_per_launch': flops_row,
+            'algorithmic_bytes_per_launch': alg_bytes_row,
+            'schedule_bytes_per_launch': sched_bytes_row,
+            'traffic_over_algorithmic': traffic_row / alg_bytes_row if traffic_row else None,
+            't_min_ms': {'mfma': t_mfma * 1e3, 'hbm': t_hbm * 1e3},
+            'other_roof': {'bound': 'hbm' if mfma_bound else 'mfma',
+                           'achieved': row_gbs if mfma_bound else row_tflops,
+                           'frac': (row_gbs / PEAK_HBM_GBS if mfma_bound else row_tflops / PEAK_BF16_TFLOPS) if row_s > 0 else None},
+            'schedule_hbm_gbs': sched_bytes_row / row_s / 1e9 if row_s > 0 else None,
+        }
+        errors, n_done, stopped = fits[-1]
+        all_full = all(nd == iters_per_fit and not st for _, nd, st in fits)
         out = {
             'metric': 'nmf_update_iterations_per_sec',
             'value': its,
@@ -253,36 +354,34 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'KL-NMF fit iteration, V %dx%d (row-sharded), k=%d' % (n, f, k),
                        'n': n, 'f': f, 'k': k, 'rows_per_gpu': n_local,
-                       'precision': args.precision,
-                       'parallelism': 'rows/%d' % n_gpus},
+                       'precision': args.precision, 'parallelism': 'rows/%d' % n_gpus,
+                       'generator': 'seeded RandomState row blocks (SURVEY 8d), seed %d' % args.seed if args.data == 'blocks'
+                                    else 'torch generator on the device, seed %d' % args.seed,
+                       'timing': 'median of %d segments of %d iterations, each after a fresh init + %d warm-up iterations'
+                                 % (len(segments), args.steps, args.warmup)},
             'samples_per_sec': its * n,
+            'segments_ms_per_step': [1e3 * s / args.steps for s in segments],
+            'setup_s': t_setup,
             'iterations_done': n_done,
             'stopped_early': bool(stopped),
-            'valid': bool(n_done == total_iters and not stopped),     # every timed launch did its full work
+            'valid': bool(all_full),        # every timed launch of every segment did its full work
             'loss_first': errors[0] if errors else None,
             'loss_last': errors[-1] if errors else None,
-            'stop_rule': 'evaluated, cannot fire' if args.tol is None else 'tol=%g' % args.tol,
+            'stop_rule': 'tol=%g (nmf.py:207,215%s)' % (args.tol, '; learner.py:39-40' if args.tol == 0 else ''),
             'loss_finite_and_decreasing': bool(len(errors) > 1 and all(e == e and abs(e) != float('inf') for e in errors)
                                                and all(b < a for a, b in zip(errors, errors[1:]))),
             'device': info,
-            'roofline': dict(
-                kernel=('k_rowpass4' if pingpong else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule'
-                       + (', ratio tiles stored for the H rule)' if stored_q else ')'),
-                bound='hbm' if hbm_bound else 'mfma', achieved=head['achieved'], peak=head['peak'], unit=head['unit'],
-                frac=head['frac'], traffic=measured_traffic(args, n_local),
-                avg_launch_ms=row_ms, launches=prof['rowpass_launches'],
-                algorithmic_flops_per_launch=flops_row, algorithmic_hbm_bytes_per_launch=bytes_row,
-                t_min_ms={'mfma': flops_row / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 'hbm': bytes_row / 8000e9 * 1e3},
-                **{('mfma' if hbm_bound else 'hbm'): other}),
+            'roofline': roofline,
             'kernels': {
                 ('k_colpass_q2' if stored_q else 'k_colpass'): {
-                    'avg_launch_ms': col_ms, 'launches': prof['colpass_launches'],
+                    'avg_launch_ms': col_ms, 'launches': prof_tot['colpass_launches'],
                     'algorithmic_tflops': flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
-                    'executed_tflops': (1 if stored_q else 2) * flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
-                    'algorithmic_hbm_bytes_per_launch': bytes_col,
-                    'hbm_gbs': bytes_col / (col_ms * 1e-3) / 1e9 if col_ms > 0 else None,
-                    'hbm_frac': bytes_col / (col_ms * 1e-3) / 1e9 / 8000.0 if col_ms > 0 else None},
-                'iteration_hbm_bytes_by_contract': bytes_row + bytes_col,
+                    'frac_of_bf16_peak': flops_col / (col_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if col_ms > 0 else None,
+                    'schedule_bytes_per_launch': sched_bytes_col,
+                    'schedule_hbm_gbs': sched_bytes_col / (col_ms * 1e-3) / 1e9 if col_ms > 0 else None,
+                    'traffic': traffic_col},
+                'iteration_algorithmic_bytes': n * f * vbytes + 2 * n * k * 4 + 3 * k * f * 4,
+                'iteration_schedule_bytes': (sched_bytes_row + sched_bytes_col) * n_gpus,
                 'iteration_algorithmic_tflops': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12,
                 'iteration_frac_of_bf16_peak': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
             },

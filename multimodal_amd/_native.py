@@ -189,6 +189,11 @@ def all_distances(A, B, metric, device=0):
     return out
 
 
+def ratio_tile_bytes():
+    """Bytes per element of V of the ratio tiles the row pass leaves for the column pass (stored-ratio schedule)."""
+    return 2
+
+
 def selftest(device=0):
     lib = load()
     failed = _c.c_int(-1)

@@ -129,6 +129,26 @@ def update_step(X, W, H, fit=True, scale_W=False):
     return W_new, H_new
 
 
+def fit_iteration_lean32(X32, W, H, eps=EPS_RATIO):
+    """The "optimised CPU" baseline of BASELINE.md section 3: the same iteration (loss before the update, old
+    ratio with the new W in the H rule, row normalisation: nmf.py:212-222, 232-257) without the reference's
+    avoidable work -- ONE W.H product shared by the loss and the ratio, float32 arrays, temporaries reused.
+    Returns (loss, W_new, H_new).  bench.py times it next to the faithful restatement so that the GPU figure is
+    not only compared with the reference's waste; tests check it against `update_step` to float32 accuracy."""
+    WH = W.dot(H)                                  # float32 [n, f]
+    sum_wh = WH.sum(dtype=np.float64)
+    WH += np.float32(eps)
+    Q = X32 + np.float32(eps)
+    Q /= WH                                        # the ratio; WH is scratch from here on
+    np.log(Q, out=WH)
+    WH *= X32
+    loss = WH.sum(dtype=np.float64) - X32.sum(dtype=np.float64) + sum_wh
+    W_new = W * Q.dot(H.T)
+    H_new = H * W_new.T.dot(Q)
+    H_new /= (np.float32(EPS_NORMALIZE) + H_new.sum(axis=1, keepdims=True))
+    return loss, W_new, H_new
+
+
 # ------------------------------------------------------------ the hot loop ---
 
 def init_factors(X, k, H0=None, rng=None):

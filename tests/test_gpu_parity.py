@@ -9,16 +9,17 @@ Tolerances (stated per mode):
   bf16  -- bf16 MFMA operands (W, H, Q rounded to bf16), fp32 accumulate and
            masters.  Every recorded loss within 1e-3 of the fp64 oracle, W/H
            within 3e-2 of the matrix max, and the TRUE loss of the trained model
-           (evaluated in fp64 on the exact data) within 5e-4 on the tiny
-           over-parameterised cases below and within 1e-4 (the north-star
-           tolerance) at config-4 shape (test_config4_*).
+           (evaluated in fp64 on the exact data) within 1e-4 (the north-star
+           tolerance) -- 5e-4 on the two smallest cases (37 x 53; 500 x 1000 with
+           k = 10 over 50 iterations), measured 2.6e-4 .. 2.8e-4 there.
            The loss the bf16 mode REPORTS is KL(V~ || WH) - KL(V~ || V) with V~
            = V as stored (power-of-two-scaled fp16, 11 significant bits); the
            identity KL(V||WH) = KL(V~||WH) - KL(V~||V) + sum (V~-V) ln(WH/V)
            is exact and the dropped last term is zero-mean and second order
-           (DESIGN.md "loss with rounded V").  Reported-loss tolerance: 5e-4 on
-           the tiny cases below (few thousand elements: the dropped term is
-           O(1/sqrt(N))), 1e-4 at config-4 shape (numpy emulation: 2e-6).
+           (DESIGN.md "loss with rounded V").  Reported-loss tolerance: the same
+           as for the true loss (the evaluation itself is within 1e-4 of the true
+           loss of its model in every case: measured <= 9e-5 at 2 000 elements,
+           <= 3e-5 from 20 000 elements on, 1e-6 at config shapes).
            `bf16_v32` stores V in fp32 (no such term).
 """
 import io
@@ -331,12 +332,15 @@ def test_bf16_fit_matches_oracle(n, f, k, iters, prec):
     assert_allclose(errors, eo, rtol=1e-3)
     final_o = orc.kl_error(X, Wo, Ho)
     final_g = m.error(X, W)                                # as the bf16 mode reports it
-    tol_reported = 5e-4
-    assert abs(final_g - final_o) <= tol_reported * abs(final_o), (final_g, final_o)
+    # 1e-4 (the north star's tolerance) everywhere but the two smallest problems, where 8-bit-significand operands
+    # drift without rows to average over: measured 2.8e-4 at 37 x 53 (2 000 elements) and 2.6e-4 after 50 iterations
+    # at 500 x 1000, k = 10 (scripts/tolerance_survey.py; every other case <= 3e-5)
+    tol_final = 5e-4 if (n, f) in ((37, 53), (500, 1000)) else 1e-4
+    assert abs(final_g - final_o) <= tol_final * abs(final_o), (final_g, final_o)
     # quality of the trained model itself: exact fp64 loss on the exact data
     m64 = nmf.KLdivNMF(n_components=k, precision='f64')
     true_g = m64.error(X, W, H=m.components_)
-    assert abs(true_g - final_o) <= 5e-4 * abs(final_o), (true_g, final_o)
+    assert abs(true_g - final_o) <= tol_final * abs(final_o), (true_g, final_o)
     assert np.all(W >= 0) and np.all(m.components_ >= 0)
     assert_allclose(m.components_.sum(axis=1), 1.0, rtol=1e-5)
     assert _rel_to_max(W, Wo) < 3e-2

@@ -171,3 +171,47 @@ def test_learner_bookkeeping():
     lr2 = MultimodalLearner(['a'], [3], [1.], 2, sparseness='data')
     with pytest.raises(TypeError):               # `raise NotImplemented`, learner.py:37-38
         lr2.train([blocks[0]], 1)
+
+
+def test_synthetic_generators_agree():
+    """bench.py's block generator (multimodal_amd/synthetic.py), the fixtures' (tests/golden_inputs.py) and the
+    oracle's are the same seeded streams: any row range, any thread count, bit for bit."""
+    from multimodal_amd import synthetic as syn
+    from oracle import klnmf_oracle as orc
+    from tests import golden_inputs as gi
+    n, f, k = 20000, 96, 6
+    X, H0 = gi.synthetic_problem(11, n, f, k)
+    assert np.array_equal(X, orc.synthetic_V(11, n, f, k)) and np.array_equal(H0, orc.synthetic_H0(11, f, k))
+    assert np.array_equal(H0, syn.H0_of(11, f, k))
+    assert np.array_equal(X[5000:17001], syn.rows_of(11, 5000, 17001, n, f, k))
+    got = np.zeros((12001, f), dtype=np.float32)
+    pieces = []
+
+    def consume(lo, arr):
+        pieces.append(lo)
+        got[lo:lo + arr.shape[0]] = arr
+    vmax = syn.for_each_block(11, 5000, 17001, n, f, k, consume, workers=3)
+    assert pieces == sorted(pieces) and np.array_equal(got, X[5000:17001].astype(np.float32))
+    assert vmax == X[5000:17001].max()
+
+
+def test_lean_cpu_iteration_is_the_same_iteration():
+    """bench.py's "optimised CPU" baseline (one W.H, float32) against the faithful restatement."""
+    from oracle import klnmf_oracle as orc
+    X = orc.synthetic_V(5, 300, 200, 8)
+    H0 = orc.synthetic_H0(5, 200, 8)
+    W, H = orc.init_factors(X, 8, H0=H0)
+    W32, H32, X32 = W.astype(np.float32), H.astype(np.float32), X.astype(np.float32)
+    for it in range(4):
+        loss = orc.kl_error(X, W, H)
+        W, H = orc.update_step(X, W, H)
+        l32, W32, H32 = orc.fit_iteration_lean32(X32, W32, H32)
+        assert abs(l32 - loss) <= 2e-6 * loss
+        assert np.abs(W32 - W).max() <= 2e-5 * np.abs(W).max() and np.abs(H32 - H).max() <= 2e-5 * np.abs(H).max()
+
+
+def test_bench_defaults_follow_the_measurement_contract():
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.n, a.f, a.k, a.precision) == (1, 1000000, 4096, 200, 'bf16')      # BASELINE.json configs[3]
+    assert a.tol == 0.0 and a.repeats == 5 and a.cpu_rows == 100000 and a.data == 'blocks'
