@@ -38,8 +38,11 @@ extern "C" {
 /* arithmetic modes */
 #define KLNMF_PREC_F64      0        /* fp64 everywhere (reference arithmetic)      */
 #define KLNMF_PREC_F32      1        /* fp32 everywhere                              */
-#define KLNMF_PREC_BF16     2        /* bf16 MFMA operands, fp32 accumulate/masters, V stored 16-bit (scaled fp16) */
-#define KLNMF_PREC_BF16_V32 3        /* as BF16 but V stored fp32                    */
+#define KLNMF_PREC_F16      2        /* fp16 MFMA operands (power-of-two-scaled images, saturating conversion), fp32
+                                      * accumulate and masters, V stored 16-bit (scaled fp16): the throughput mode */
+#define KLNMF_PREC_F16_V32  3        /* as F16 but V stored fp32                     */
+#define KLNMF_PREC_BF16     KLNMF_PREC_F16      /* round-1 names of the two modes (their operands were bf16 then) */
+#define KLNMF_PREC_BF16_V32 KLNMF_PREC_F16_V32
 
 /* host element types for uploads / downloads */
 #define KLNMF_DT_F32        0

@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get('KLNMF_LIB') or os.path.join(_HERE, 'csrc', 'libklnmf.
 PREC_F64, PREC_F32, PREC_BF16, PREC_BF16_V32 = 0, 1, 2, 3
 PRECISIONS = {'f64': PREC_F64, 'fp64': PREC_F64, 'float64': PREC_F64,
               'f32': PREC_F32, 'fp32': PREC_F32, 'float32': PREC_F32,
+              'f16': PREC_BF16, 'fp16': PREC_BF16, 'float16': PREC_BF16, 'f16_v32': PREC_BF16_V32,
+              # the 16-bit modes' historical names (their MFMA operands were bf16 in round 1; fp16 with power-of-two
+              # scaling since: same matrix rate, 8x smaller operand rounding -- csrc/mfma.hip.h)
               'bf16': PREC_BF16, 'bf16_v32': PREC_BF16_V32}
 DT_F32, DT_F64 = 0, 1
 STREAM_DEFAULT = (1 << 64) - 1        # KLNMF_STREAM_DEFAULT: (void *)(intptr_t)-1

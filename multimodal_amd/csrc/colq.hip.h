@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         }
     };
     auto compute = [&](unsigned base) {
-        bf16x8 ring[3];
+        opx8 ring[3];
         s16x4 q0, q1, q2, q3;
         lds_read_tr(q0, base + off_q);
         lds_read_tr(q1, base + off_q + 8 * 64);
@@ -134,14 +134,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         // the ratio reads are older than every W_new read: they have landed when fragment 0 has
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(ring[0]));
         // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7));
+        const opx8 b0 = __builtin_bit_cast(opx8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
+        const opx8 b1 = __builtin_bit_cast(opx8, __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7));
         static_for<0, N3>([&](auto J) {
             constexpr int j = decltype(J)::value;
             fetch(std::integral_constant<int, j + 2>{});
             constexpr int younger = (j + 2 < N3 ? 2 : N3 - 1 - j);      // fragments issued after fragment j
             lds_wait<2 * younger>(ring[j % 3]);
-            acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+            acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
         });
     };
     auto fence = [&]() {          // my copies of the next stage have landed; then everybody's

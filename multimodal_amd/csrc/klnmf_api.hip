@@ -162,12 +162,13 @@ struct klnmf_ctx {
     unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
     int col_gen = 2;
     float *W32[2] = {nullptr, nullptr};
-    __bf16 *Wb[2] = {nullptr, nullptr};
+    opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
-    __bf16 *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
+    opnd_t *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
     int row_gen = 4;
     int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
     double *hsum = nullptr;
+    float *hs = nullptr;         // [KP] per-component power-of-two scale of the dictionary image (mfma.hip.h, opnd_t)
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     float *NpartF = nullptr, *numerF = nullptr;
     double2 *loss_part2 = nullptr;
@@ -340,6 +341,8 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.W32_new = c->W32[c->cur ^ 1];
     a.loss_part = c->loss_part2;
     a.hsum = c->hsum;
+    a.hs = c->hs;
+    a.fit = (store_q && mode == ROW_UPDATE) ? 1 : 0;
     a.stamps = c->stamps;
     a.kc = c->kc;
     a.st = c->st;
@@ -363,7 +366,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
             hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
                                (const float *)c->Gpart, c->row_chunks, rows * c->KP, (const float *)c->W32[c->cur],
                                c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
-                               (const DevState *)c->st);
+                               (const DevState *)c->st, (const float *)c->hs, a.fit);
             HIPCHK(hipGetLastError());
             if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
             return;
@@ -466,8 +469,8 @@ void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false) {
     // once, in klnmf_set_problem, so the choice cannot change under a context)
     const bool lean = c->pingpong() && c->Qt != nullptr;
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
-                       (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (__bf16 *)nullptr : c->Ht, c->Ht4,
-                       lean ? (__bf16 *)nullptr : c->HTb, c->hsum, c->f, c->f_pad,
+                       (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (opnd_t *)nullptr : c->Ht, c->Ht4,
+                       lean ? (opnd_t *)nullptr : c->HTb, c->hsum, c->hs, c->f, c->f_pad,
                        c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
                        (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad);
     HIPCHK(hipGetLastError());
@@ -1004,16 +1007,22 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;
             for (int i = 0; i < 2; ++i) {
                 c->W32[i] = (float *)c->dalloc((size_t)c->n_pad * c->KP * 4);
-                c->Wb[i] = (__bf16 *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
+                c->Wb[i] = (opnd_t *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
             }
             c->H32 = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
-            c->Ht = (__bf16 *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
-            c->Ht4 = (__bf16 *)c->dalloc((size_t)c->nct * h4_tile_bytes(c->KP) + kObj4);
-            c->HTb = (__bf16 *)c->dalloc((size_t)c->f_pad * c->KP * 2);
+            c->Ht = (opnd_t *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
+            c->Ht4 = (opnd_t *)c->dalloc((size_t)c->nct * h4_tile_bytes(c->KP) + kObj4);
+            c->HTb = (opnd_t *)c->dalloc((size_t)c->f_pad * c->KP * 2);
             // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
             // carrier column at 1) and a spare component inside the MFMA-1 contraction range
             c->kc = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
             c->hsum = (double *)c->dalloc((size_t)c->KP * 8);
+            c->hs = (float *)c->dalloc((size_t)c->KP * 4);
+            {
+                const std::vector<float> ones((size_t)c->KP, 1.f);      // until a dictionary is packed (k_update_pack_H)
+                HIPCHK(hipMemcpyAsync(c->hs, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+            }
 #ifdef KL_STAMPS
             c->stamps = (unsigned long long *)c->dalloc((size_t)c->nrt * 8 * 8);
 #endif
@@ -1207,7 +1216,14 @@ int klnmf_set_H(klnmf_ctx *c, const void *src, int dtype) {
         if (!src) fail(KLNMF_ERR_ARG, "null source");
         if (!c->is_exact()) HIPCHK(hipMemsetAsync(c->H32, 0, (size_t)c->KP * c->f_pad * 4, c->stream));
         set_matrix(c, src, dtype, c->k, c->f, c->H, c->H32, c->f_pad);
-        if (!c->is_exact()) fast_pack_H(c, 0);
+        if (!c->is_exact()) {
+            fast_pack_H(c, 0);
+            // the W image carries the inverse of the dictionary image's per-component scale: re-pack it for the new one
+            hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n_pad * c->KP, 256, 8192)), dim3(256), 0,
+                               c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n_pad, c->KP,
+                               w_ld(c->KP), c->kc, (const float *)c->hs);
+            HIPCHK(hipGetLastError());
+        }
     });
 }
 
@@ -1220,7 +1236,7 @@ int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
             // all padded rows too: the eps-carrying pad column must be 1 in every row a tile can contain
             hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n_pad * c->KP, 256, 8192)), dim3(256), 0,
                                c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n_pad, c->KP,
-                               w_ld(c->KP), c->kc);
+                               w_ld(c->KP), c->kc, (const float *)c->hs);
             HIPCHK(hipGetLastError());
         }
     });

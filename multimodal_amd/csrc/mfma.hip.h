@@ -32,7 +32,7 @@
 // 16-byte-per-lane stream (row pass: global_load_lds into a wave-private LDS
 // slot one stage ahead; column pass: straight to registers).
 //
-// MFMA: v_mfma_f32_32x32x16_bf16.  Operand maps (guide section 3):
+// MFMA: v_mfma_f32_32x32x16_f16.  Operand maps (guide section 3):
 //   A[row = l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col = l&31], j = 0..7
 //   D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg = 0..15
 #pragma once
@@ -40,8 +40,23 @@
 
 namespace klnmf {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// MFMA operand element of the 16-bit modes: IEEE half (11 significant bits) with power-of-two scaling of the images
+// and saturating conversion (MODE.FP16_OVFL), not bf16 (8 bits): same matrix rate (v_mfma_f32_32x32x16_f16), 8x smaller
+// operand rounding.  Scaling (exact, powers of two): per component a, hs_a = the power of two >= rowsum(H_a) (1 for a
+// row-normalised dictionary);  H image = half(H * 2^13 / hs_a),  W image = half(W32 * hs_a * 2^-13)  -- the product of
+// the two scales is 1 for every component, so W.H, the ratio, the loss terms and every rule are unscaled; only the two
+// places that turn an accumulator back into a master apply a per-component factor (the W rule: G * hs_a * 2^-13; the
+// H rule: its factor is constant along a dictionary row and cancels in the row normalisation).
+typedef _Float16 opnd_t;
+typedef __attribute__((ext_vector_type(8))) opnd_t opx8;
+typedef __attribute__((ext_vector_type(4))) opnd_t opx4;
+constexpr float kOpScaleH = 8192.f;              // 2^13
+constexpr float kOpScaleW = 1.f / 8192.f;
+constexpr float kCarrierW = 1.f / 1024.f;        // eps carrier: W image column kc holds 2^-10, H image row kc eps * 2^10
+// f32 -> f16 conversions that overflow give the largest finite half instead of infinity (MODE bit 23, FP16_OVFL; true
+// infinities stay): a ratio beyond 65504 (x > 0 where W.H ~ 0) or an operand beyond the image range then perturbs one
+// update instead of poisoning the factors with inf - inf.  Set once per kernel (the mode is per wave).
+#define KL_FP16_SATURATE() asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -114,23 +129,23 @@ enum RowMode { ROW_UPDATE = 0, ROW_INIT = 1, ROW_LOSS = 2 };
     } while (0)
 
 // ---- small device helpers ---------------------------------------------------
-__device__ __forceinline__ bf16x8 tr_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+__device__ __forceinline__ opx8 tr_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
     // two ds_read_b64_tr_b16: each gives this lane one column of a 4-row x 16-col block
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p0);
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p1);
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(opx8, v);
 }
-__device__ __forceinline__ bf16x8 b64_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+__device__ __forceinline__ opx8 b64_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
     s16x4 lo = *(const KL_LDS s16x4 *)p0;
     s16x4 hi = *(const KL_LDS s16x4 *)p1;
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(opx8, v);
 }
-__device__ __forceinline__ bf16x8 pack8(const float *q) {
-    bf16x8 r;
+__device__ __forceinline__ opx8 pack8(const float *q) {
+    opx8 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)q[j];
+    for (int j = 0; j < 8; ++j) r[j] = (opnd_t)q[j];
     return r;
 }
 
@@ -212,15 +227,17 @@ __device__ __forceinline__ void stage_v_tile(const unsigned char *gtile, KL_LDS 
 
 struct RowPassArgs {
     const void *VtA;          // [nrt][nct][64 lanes][16] tiles, layout A
-    const __bf16 *Ht;         // [nst][KP][kHRow] dictionary stage images
-    const __bf16 *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
+    const opnd_t *Ht;         // [nst][KP][kHRow] dictionary stage images
+    const opnd_t *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
     const float *W32_old;     // [n_pad][KP]
-    __bf16 *Wb_new;
+    opnd_t *Wb_new;
     float *W32_new;
     double2 *loss_part;       // [nrt] (sum x*log2 q, sum y)
     const double *hsum;       // [KP] row sums of the 16-bit dictionary image (for sum(W.H)), see row_sum_wh
     unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
     unsigned char *Qt;            // ratio tiles for k_colpass_q ([nct][nrt][2 KiB], see there), or null (ping-pong pass only)
+    const float *hs;              // [KP] per-component power of two of the current dictionary image (see opnd_t)
+    int fit;                      // the H rule follows (the new W image is scaled for a row-normalised dictionary, hs = 1)
     int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
@@ -259,6 +276,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char bufB[BUF];
     if (a.st->stop) return;
     KL_WAVE_PRIORITY();
+    KL_FP16_SATURATE();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -273,11 +291,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
     //  row read (MFMA2 A operand): row = component r, 16 contiguous bytes of its 16-column group
     const int off_row = r * kHRowB + 16 * h;
 
-    bf16x8 wf[KS];
+    opx8 wf[KS];
     if (MODE != ROW_INIT) {
-        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
+        const opnd_t *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + wb_col(r, 16 * s + 8 * h));
+        for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(wrow + wb_col(r, 16 * s + 8 * h));
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
             const KL_LDS unsigned char *p2 = img + off_row + (32 * u) * 2;
             constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
             constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
-            bf16x8 ring[KL_RING];
+            opx8 ring[KL_RING];
             auto fetch = [&](int idx) {                    // idx is a compile-time constant after unrolling
 #ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
                 if (idx < N1 + N2) { ring[idx % KL_RING] = wf[idx % KS]; asm volatile("" : "+v"(ring[idx % KL_RING])); }
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                     ring[idx % KL_RING] = tr_pair(p1 + (16 * idx) * kHRowB, p1 + (16 * idx + 4) * kHRowB);
                 } else if (idx < N1 + N2) {
                     const int j = idx - N1, m = j >> 1, hh = j & 1;
-                    ring[idx % KL_RING] = *(const KL_LDS bf16x8 *)(p2 + (32 * m) * kHRowB + 32 * hh);
+                    ring[idx % KL_RING] = *(const KL_LDS opx8 *)(p2 + (32 * m) * kHRowB + 32 * hh);
                 }
             };
             unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     fetch(s + KL_RING - 1);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % KL_RING], wf[s], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s % KL_RING], wf[s], d, 0, 0, 0);
                 }
                 KL_STAMP(t2);
 #pragma unroll
@@ -374,12 +392,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
                 }
             }
             if (MODE != ROW_LOSS) {
-                const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+                const opx8 b0 = pack8(q), b1 = pack8(q + 8);
                 KL_STAMP(t3);
 #pragma unroll
                 for (int j = 0; j < N2; ++j) {
                     fetch(N1 + j + KL_RING - 1);
-                    acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(N1 + j) % KL_RING], (j & 1) ? b1 : b0,
+                    acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(N1 + j) % KL_RING], (j & 1) ? b1 : b0,
                                                                           acc[j >> 1], 0, 0, 0);
                 }
                 KL_STAMP(t4);
@@ -472,13 +490,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int comp = 32 * m + 8 * g + 4 * h;
+                const f32x4 hsv = *(const f32x4 *)(a.hs + comp);
+                opx4 wb;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) w[g][t] *= acc[m][4 * g + t];
+                for (int t = 0; t < 4; ++t) {
+                    const float ginv = hsv[t] * kOpScaleW;                  // the accumulator saw the scaled dictionary image
+                    w[g][t] *= acc[m][4 * g + t] * ginv;
+                    wb[t] = (opnd_t)(w[g][t] * (a.fit ? kOpScaleW : ginv));
+                }
                 *(f32x4 *)(a.W32_new + row * KP + comp) = w[g];
-                bf16x4 wb;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) wb[t] = (__bf16)w[g][t];
-                *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
+                *(opx4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
             }
         }
     }
@@ -486,9 +507,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 
 struct ColPassArgs {
     const void *VtB;          // [nct][nrt][64][16] tiles, layout B
-    const __bf16 *HTb;        // [f_pad][KP] transposed dictionary (this wave's B fragments)
-    const __bf16 *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
-    const __bf16 *Wb_new;
+    const opnd_t *HTb;        // [f_pad][KP] transposed dictionary (this wave's B fragments)
+    const opnd_t *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
+    const opnd_t *Wb_new;
     float *Npart;             // [nchunks][KP][f_pad]
     const DevState *st;
     int nrt, nct, ncb, nchunks, stages_per_chunk;   // nrt even; a stage = 2 row tiles
@@ -512,6 +533,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char bufB[2 * IMG];
     if (a.st->stop) return;
     KL_WAVE_PRIORITY();
+    KL_FP16_SATURATE();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -537,11 +559,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     const int off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
     const int off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
 
-    bf16x8 hf[KS];
+    opx8 hf[KS];
     {
-        const __bf16 *hrow = a.HTb + (int64_t)(ct * 32 + r) * KP + 8 * h;
+        const opnd_t *hrow = a.HTb + (int64_t)(ct * 32 + r) * KP + 8 * h;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) hf[s] = *(const bf16x8 *)(hrow + 16 * s);
+        for (int s = 0; s < KS; ++s) hf[s] = *(const opx8 *)(hrow + 16 * s);
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -571,10 +593,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
             const KL_LDS unsigned char *p30 = img_new + off_tr0 + (32 * u) * WLDB;
             const KL_LDS unsigned char *p31 = img_new + off_tr1 + (32 * u) * WLDB;
             constexpr int N3 = 2 * KT;
-            bf16x8 ring[3];
+            opx8 ring[3];
             auto fetch = [&](int idx) {
                 if (idx < KS) {
-                    ring[idx % 3] = *(const KL_LDS bf16x8 *)(((idx & 1) ? p1o : p1e) + 64 * (idx >> 1));
+                    ring[idx % 3] = *(const KL_LDS opx8 *)(((idx & 1) ? p1o : p1e) + 64 * (idx >> 1));
                 } else if (idx < KS + N3) {
                     const int j = idx - KS, m = j >> 1, hh = j & 1;
                     ring[idx % 3] = tr_pair(p30 + (16 * hh) * WLDB + (32 * m) * 2,
@@ -594,7 +616,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 fetch(s + 2);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3], hf[s], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s % 3], hf[s], d, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
@@ -604,11 +626,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
                 const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps is already in d (pad component)
                 q[e] = fmaf(x[e], rinv, eps * rinv);
             }
-            const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+            const opx8 b0 = pack8(q), b1 = pack8(q + 8);
 #pragma unroll
             for (int j = 0; j < N3; ++j) {
                 fetch(KS + j + 2);
-                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(KS + j) % 3], (j & 1) ? b1 : b0,
+                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(KS + j) % 3], (j & 1) ? b1 : b0,
                                                                       acc[j >> 1], 0, 0, 0);
             }
         }
@@ -664,7 +686,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 // fragments; the 32 lanes of a read's first pass touch 256 consecutive bytes (conflict-free).
 struct ColPassQArgs {
     const unsigned char *Qt;
-    const __bf16 *Wb_new;     // [n_pad(+pad)][w_ld(KP)]
+    const opnd_t *Wb_new;     // [n_pad(+pad)][w_ld(KP)]
     float *Npart;             // [nchunks][KP][f_pad]
     const DevState *st;
     int nrt, nct, ncb, nchunks, stages_per_chunk;
@@ -733,7 +755,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
             const KL_LDS unsigned char *p31 = img + off_tr1 + (32 * u) * WLDB;
             const KL_LDS unsigned char *pq = img + IMG + off_q + u * kQTile;
             constexpr int N3 = 2 * KT;
-            bf16x8 ring[3];
+            opx8 ring[3];
             auto fetch = [&](int j) {
                 if (j < N3) {
                     const int m = j >> 1, hh = j & 1;
@@ -743,11 +765,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
             fetch(0);
             fetch(1);
             // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
-            const bf16x8 b0 = tr_pair(pq, pq + 8 * 64), b1 = tr_pair(pq + 16 * 64, pq + 24 * 64);
+            const opx8 b0 = tr_pair(pq, pq + 8 * 64), b1 = tr_pair(pq + 16 * 64, pq + 24 * 64);
 #pragma unroll
             for (int j = 0; j < N3; ++j) {
                 fetch(j + 2);
-                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
             }
         }
     };
@@ -788,14 +810,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 // matrix product: row kc of the dictionary images holds eps in every column, column kc of the bf16 W
 // images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
 // loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
-__global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, __bf16 *Ht,
-                                                       __bf16 *Ht4, __bf16 *HTb, double *hsum, int64_t f,
+__global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
+                                                       opnd_t *Ht4, opnd_t *HTb, double *hsum, float *hs, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
                                                        const DevState *st, int kc, float eps_pad,
                                                        int nslab = 0, int64_t slab = 0) {
     if (st && st->stop) return;
+    KL_FP16_SATURATE();
     if (kc >= 0 && blockIdx.x == 0) {
-        const __bf16 ev = (__bf16)eps_pad;
+        const opnd_t ev = (opnd_t)(eps_pad / kCarrierW);          // x the carrier column of the W image = eps
         for (int64_t j = threadIdx.x; j < f_pad; j += blockDim.x) {
             if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(kc, (int)(j % 32))] = ev;
             if (HTb) HTb[j * kp + kc] = ev;
@@ -805,6 +828,7 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     __shared__ double total;
     const int a = blockIdx.x;
     float *row = H32 + (int64_t)a * f_pad;
+    float hs_a = 1.f;                  // a row-normalised dictionary row: sum 1, every entry <= 1
     if (do_update) {
         const float *nrow = num + (int64_t)a * f_pad;
         double s = 0;
@@ -812,8 +836,8 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
             float nj = nrow[j];
             for (int z = 1; z < nslab; ++z) nj += nrow[z * slab + j];      // nslab > 0: num = the column pass's slabs,
             const float v = row[j] * nj;                                    // summed here in k_sum_partials_f32's order
-            row[j] = v;
-            s += (double)v;
+            row[j] = v;                // (num carries the W image's per-component scale: constant along the row, it
+            s += (double)v;            //  cancels in the normalisation below)
         }
         const double t = block_sum(s, red);
         if (threadIdx.x == 0) total = t;
@@ -821,27 +845,43 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
         const float d = (float)(kEpsNorm + total);
         for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
         __syncthreads();
+    } else {
+        // a dictionary as given (set_H: transform on a column slice, an unnormalised initial dictionary): scale the
+        // image row by the power of two at or above its sum, so that its entries use the half range as a normalised row's
+        double s = 0;
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) s += (double)row[j];
+        const double t = block_sum(s, red);
+        if (threadIdx.x == 0) total = t;
+        __syncthreads();
+        int e = 0;
+        if (total > 0 && total < 1e300) { (void)frexp(total, &e); hs_a = ldexpf(1.f, e); }
+        __syncthreads();
     }
-    double hs = 0;
+    const float sc = kOpScaleH / hs_a;
+    double hsm = 0;
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
-        const __bf16 v = (__bf16)row[j];
+        const opnd_t v = (opnd_t)(row[j] * sc);
         // Ht / HTb: images of the generation-1 row pass and of the recomputing column pass -- null where the ping-pong row
         // pass and the stored-ratio column pass run (the transposed 2-byte stores of HTb were most of this kernel's time)
         if (Ht) Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + h_col_perm((int)(j % kStageCols))] = v;
         if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(a, (int)(j % 32))] = v;   // mfma4.hip.h tile images (swizzled)
         if (HTb) HTb[j * kp + a] = v;
-        hs += (double)(float)v;
+        hsm += (double)(float)v;
     }
-    const double ths = block_sum(hs, red);
-    if (threadIdx.x == 0) hsum[a] = ths;
+    const double ths = block_sum(hsm, red);
+    if (threadIdx.x == 0) {
+        hsum[a] = ths;                 // row sum of the IMAGE (scaled): x the W image's scale it is sum_j (W.H)_ij exactly
+        hs[a] = hs_a;
+    }
 }
 
-__global__ void k_pack_W(const float *W32, __bf16 *Wb, int64_t n, int kp, int wld, int kc) {
+__global__ void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *hs) {
+    KL_FP16_SATURATE();
     const int64_t total = n * kp;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / kp, c = e % kp;
-        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (c == kc) ? (__bf16)1.f : (__bf16)W32[e];
+        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (c == kc) ? (opnd_t)kCarrierW : (opnd_t)(W32[e] * hs[c] * kOpScaleW);
     }
 }
 

@@ -69,7 +69,7 @@ __host__ __device__ constexpr int m2_kstep(int p, int kt, bool split) { return s
 
 struct RowPass4Args {
     RowPassArgs base;
-    const __bf16 *Ht4;        // [nct][KP][kRow4] per-tile dictionary images
+    const opnd_t *Ht4;        // [nct][KP][kRow4] per-tile dictionary images
 };
 
 // prefetch distance of the operand-fragment stream, in fragments (ring = KL_PF + 1 registers sets)
@@ -90,20 +90,16 @@ __device__ __forceinline__ void static_for(F &&f) {
 // was ever issued into.  Completion is awaited with explicit counted lgkmcnt waits that carry
 // the destination as an in/out operand, so no use can be scheduled above its wait.
 template <int OFF>
-__device__ __forceinline__ void lds_read_b128(bf16x8 &dst, unsigned addr) {
+__device__ __forceinline__ void lds_read_b128(opx8 &dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 template <int OFF>
-__device__ __forceinline__ void lds_read_b128(f16x8 &dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read_tr_pair(bf16x8 &dst, unsigned addr0, unsigned addr1) {
+__device__ __forceinline__ void lds_read_tr_pair(opx8 &dst, unsigned addr0, unsigned addr1) {
     s16x4 lo, hi;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr0), "n"(OFF));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr1), "n"(OFF));
     s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    dst = __builtin_bit_cast(bf16x8, v);
+    dst = __builtin_bit_cast(opx8, v);
 }
 // V tile of this lane straight to registers (2 x 16 B), ordinary loads.  Two measured reasons not to hand-issue
 // them: (1) an inline-asm load whose destination overlaps the address pair of the load before it misses the
@@ -141,19 +137,19 @@ __device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LD
 // the fragment as an in/out operand hipcc adds an `s_nop 0` before every MFMA (it must assume a VALU write), and a lone
 // wave's issue slots are the scarce resource of that schedule.  G accumulates in AGPRs ("a"), W.H in VGPRs ("v").
 template <int N>
-__device__ __forceinline__ void mfma2_w(f32x16 &acc, const bf16x8 &a, const bf16x8 &b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
+__device__ __forceinline__ void mfma2_w(f32x16 &acc, const opx8 &a, const opx8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void mfma1_first_w(f32x16 &d, const bf16x8 &a, const bf16x8 &b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(N));
+__device__ __forceinline__ void mfma1_first_w(f32x16 &d, const opx8 &a, const opx8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void mfma1_acc_w(f32x16 &d, const bf16x8 &a, const bf16x8 &b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
+__device__ __forceinline__ void mfma1_acc_w(f32x16 &d, const opx8 &a, const opx8 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void lds_wait(bf16x8 &v) {
+__device__ __forceinline__ void lds_wait(opx8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
@@ -195,7 +191,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     __shared__ __attribute__((aligned(16))) unsigned char h2[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char h3[OBJ];
     __shared__ __attribute__((aligned(16))) double hsum_lds[KP];     // row sums of H, for the sum(W.H) term of the loss
+    __shared__ __attribute__((aligned(16))) float hs_lds[KP];        // per-component scale of the dictionary image (W rule)
     if (a.st->stop) return;
+    KL_FP16_SATURATE();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -212,11 +210,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     const unsigned off_row0 = 2 * h4_elem(r, 4 * h);             // logical columns 4h.. and 8+4h.. = one permuted chunk
     const unsigned off_row1 = 2 * h4_elem(r, 16 + 4 * h);
 
-    bf16x8 wf[KS > 0 ? KS : 1];
+    opx8 wf[KS > 0 ? KS : 1];
     if (MODE != ROW_INIT) {
-        const __bf16 *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
+        const opnd_t *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8 *)(wrow + wb_col(r, 16 * s + 8 * h));
+        for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(wrow + wb_col(r, 16 * s + 8 * h));
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -282,11 +280,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     unsigned long long tk0; KL_STAMP(tk0);
 #endif
     bool tail = false;
-    bf16x8 bq[2][2];                // FUSED: Q operands of the even / odd tile slot (one consumed while the other is produced)
+    opx8 bq[2][2];                // FUSED: Q operands of the even / odd tile slot (one consumed while the other is produced)
     float qv[2] = {0.f, 0.f};       // FUSED: the ratio pair being built
-    bf16x8 ring[R];
+    opx8 ring[R];
     f32x16 d;                       // W.H of the tile between its M and E segments
-    bf16x8 b0, b1;                  // Q operands of the tile between its E segment and the next M segment
+    opx8 b0, b1;                  // Q operands of the tile between its E segment and the next M segment
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = 0.f;
 
@@ -334,13 +332,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             if constexpr (false)
 #endif
             if constexpr (p < N2) {
-                acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+                acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
             } else {
                 if constexpr (p == N2) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) d[e] = 0.f;
                 }
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[p % R], wf[p - N2], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % R], wf[p - N2], d, 0, 0, 0);
             }
         });
 #ifdef KL_STAMPS
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     };
     // the ratios of tile tg as packed in b0 / b1, for the column pass (k_colpass_q2): written once, read once by
     // another kernel -> non-temporal
-    auto store_q2 = [&](int tg, const bf16x8 &b0, const bf16x8 &b1) {
+    auto store_q2 = [&](int tg, const opx8 &b0, const opx8 &b1) {
         if (MODE == ROW_UPDATE && qlane) {
 #ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
             unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
@@ -363,23 +361,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             unsigned char *qp = qlane + (int64_t)tg * qstride;
 #endif
 #ifdef KL_ABL_QPLAIN       // experiment: ordinary stores instead of non-temporal ones
-            *(bf16x8 *)qp = b0;
-            *(bf16x8 *)(qp + 1024) = b1;
+            *(opx8 *)qp = b0;
+            *(opx8 *)(qp + 1024) = b1;
 #else
-            __builtin_nontemporal_store(b0, (bf16x8 *)qp);
-            __builtin_nontemporal_store(b1, (bf16x8 *)(qp + 1024));
+            __builtin_nontemporal_store(b0, (opx8 *)qp);
+            __builtin_nontemporal_store(b1, (opx8 *)(qp + 1024));
 #endif
         }
     };
     auto store_q = [&](int tg) { store_q2(tg, b0, b1); };
-    auto store_q_half = [&](int tg, const bf16x8 &b, int off) {
+    auto store_q_half = [&](int tg, const opx8 &b, int off) {
         if (MODE == ROW_UPDATE && qlane) {
 #ifdef KL_ABL_QSMALL
             unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
 #else
             unsigned char *qp = qlane + (int64_t)tg * qstride;
 #endif
-            __builtin_nontemporal_store(b, (bf16x8 *)(qp + off));
+            __builtin_nontemporal_store(b, (opx8 *)(qp + off));
         }
     };
     // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
@@ -467,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     //   even step 2e  : loss term and bf16 packing of element e-1 (its log comes from step 2e-1), rcp for element e
     //   odd step 2e+1 : ratio of element e (rcp from step 2e), its log
     float rinv = 0.f, lg = 0.f;
-    auto e_step = [&](auto Hh, const f16x8 &va, const f16x8 &vb, bf16x8 &o0, bf16x8 &o1) {
+    auto e_step = [&](auto Hh, const f16x8 &va, const f16x8 &vb, opx8 &o0, opx8 &o1) {
         constexpr int hh = decltype(Hh)::value, e = hh >> 1;
         if constexpr ((hh & 1) == 0) {
             if constexpr (e >= 1) {
@@ -476,9 +474,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 s1 = fmaf(xp, lg, s1);
                 asm volatile("" : "+v"(s1));      // the loss term is computed HERE (hipcc otherwise sinks all 16 past the interval)
                 if constexpr ((ep & 1) == 1) {
-                    bf16x8 &o = ep < 8 ? o0 : o1;
-                    o[(ep & 7) - 1] = (__bf16)qv[0];
-                    o[ep & 7] = (__bf16)qv[1];
+                    opx8 &o = ep < 8 ? o0 : o1;
+                    o[(ep & 7) - 1] = (opnd_t)qv[0];
+                    o[ep & 7] = (opnd_t)qv[1];
                 }
             }
             if constexpr (e < 16) {
@@ -497,8 +495,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         static_assert(!FUSED || (NF % R == 0 && D <= N2 && D <= N1), "fragment ring of the FUSED order");
         f16x8 &va = vreg[2 * (ts & 1)], &vb = vreg[2 * (ts & 1) + 1];                 // V of tile tg (landed at mid tg-1)
         f16x8 &na = vreg[2 * ((ts + 1) & 1)], &nb = vreg[2 * ((ts + 1) & 1) + 1];     // V of tile tg+1 (lands at mid tg)
-        bf16x8 &p0 = bq[(ts + 1) & 1][0], &p1 = bq[(ts + 1) & 1][1];      // tile tg-1: consumed
-        bf16x8 &c0 = bq[ts & 1][0], &c1 = bq[ts & 1][1];                  // tile tg: produced
+        opx8 &p0 = bq[(ts + 1) & 1][0], &p1 = bq[(ts + 1) & 1][1];      // tile tg-1: consumed
+        opx8 &c0 = bq[ts & 1][0], &c1 = bq[ts & 1][1];                  // tile tg: produced
         const unsigned ra = lds_addr(Hobj((ts + 3) % 4));                 // image of tile tg-1 (row reads)
         const unsigned ta = lds_addr(Hobj((ts + 1) % 4));                 // image of tile tg+1 (transposed reads)
         const unsigned rn = lds_addr(Hobj(ts % 4));                       // image of tile tg: the next interval's row reads
@@ -573,15 +571,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         for (int e = tid; e < IMG / 16; e += kThreads4) ((KL_LDS u32x4 *)h3)[e] = z;
         if (MODE != ROW_INIT)
             for (int e = tid; e < KP; e += kThreads4) hsum_lds[e] = a.hsum[e];
+        if (MODE != ROW_LOSS)
+            for (int e = tid; e < KP; e += kThreads4) hs_lds[e] = a.hs[e];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { b0[j] = (__bf16)0.f; b1[j] = (__bf16)0.f; }
+        for (int j = 0; j < 8; ++j) { b0[j] = (opnd_t)0.f; b1[j] = (opnd_t)0.f; }
     }
     if constexpr (FUSED) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1]), "+v"(vreg[2]), "+v"(vreg[3])::"memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vreg[0]), "+v"(vreg[1])::"memory");
     barrier();
     if constexpr (FUSED) {          // W.H of tile 0 (every later tile's is computed one interval ahead)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { bq[1][0][j] = (__bf16)0.f; bq[1][1][j] = (__bf16)0.f; }
+        for (int j = 0; j < 8; ++j) { bq[1][0][j] = (opnd_t)0.f; bq[1][1][j] = (opnd_t)0.f; }
         const unsigned ta = lds_addr(Hobj(0));
         static_for<0, N1>([&](auto S) {
             constexpr int sI = decltype(S)::value;
@@ -705,13 +705,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     const int m = m0 + mm;
                     const int comp = 32 * m + 8 * g + 4 * h;
                     f32x4 w = wold[mm][g];
+                    const f32x4 hsv = *(const KL_LDS f32x4 *)(hs_lds + comp);
+                    opx4 wb;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) w[t] *= acc[m][4 * g + t];
+                    for (int t = 0; t < 4; ++t) {
+                        const float ginv = hsv[t] * kOpScaleW;              // the accumulator saw the scaled dictionary image
+                        w[t] *= acc[m][4 * g + t] * ginv;
+                        wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW                       // eps carrier
+                                                         : (opnd_t)(w[t] * (a.fit ? kOpScaleW : ginv));
+                    }
                     *(f32x4 *)(a.W32_new + row * KP + comp) = w;
-                    bf16x4 wb;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) wb[t] = (EP && comp + t == a.kc) ? (__bf16)1.f : (__bf16)w[t];   // eps carrier
-                    *(bf16x4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
+                    *(opx4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
                 }
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
         }
@@ -731,9 +735,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 // W rule of the column-split update pass: G = sum over the chunks' slabs, W_new = W_old * G (fp32 master + swizzled bf16
 // image with the eps carrier column, exactly as the tail of k_rowpass4 writes them).  One thread per 4 components.
 __global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nchunk, int64_t slab, const float *W32_old,
-                                                     float *W32_new, __bf16 *Wb_new, int64_t rows, int kp, int wld, int kc,
-                                                     const DevState *st) {
+                                                     float *W32_new, opnd_t *Wb_new, int64_t rows, int kp, int wld, int kc,
+                                                     const DevState *st, const float *hs, int fit) {
     if (st->stop) return;
+    KL_FP16_SATURATE();
     const int64_t total = rows * (kp / 4);
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = e / (kp / 4);
@@ -742,14 +747,16 @@ __global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nch
         f32x4 g = *(const f32x4 *)(gpart + off);
         for (int z = 1; z < nchunk; ++z) g += *(const f32x4 *)(gpart + z * slab + off);
         f32x4 w = *(const f32x4 *)(W32_old + off);
-        bf16x4 wb;
+        const f32x4 hsv = *(const f32x4 *)(hs + comp);
+        opx4 wb;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            w[t] *= g[t];
-            wb[t] = (comp + t == kc) ? (__bf16)1.f : (__bf16)w[t];
+            const float ginv = hsv[t] * kOpScaleW;
+            w[t] *= g[t] * ginv;
+            wb[t] = (comp + t == kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * (fit ? kOpScaleW : ginv));
         }
         *(f32x4 *)(W32_new + off) = w;
-        *(bf16x4 *)(Wb_new + row * wld + wb_col((int)(row & 31), comp)) = wb;
+        *(opx4 *)(Wb_new + row * wld + wb_col((int)(row & 31), comp)) = wb;
     }
 }
 

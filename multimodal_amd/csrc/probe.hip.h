@@ -12,16 +12,16 @@ namespace klnmf {
 // P1: D = A[32x16] . B[16x32] through the documented fragment maps.
 __global__ void k_probe_mfma(const float *A, const float *B, float *D) {
     const int l = threadIdx.x, r = l & 31, h = l >> 5;
-    bf16x8 a, b;
+    opx8 a, b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        a[j] = (__bf16)A[r * 16 + 8 * h + j];
-        b[j] = (__bf16)B[(8 * h + j) * 32 + r];
+        a[j] = (opnd_t)A[r * 16 + 8 * h + j];
+        b[j] = (opnd_t)B[(8 * h + j) * 32 + r];
     }
     f32x16 d;
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = 0.f;
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, d, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -41,7 +41,7 @@ __global__ void k_probe_tr(short *out, int s, int u) {
     const int h = l >> 5, i16 = l & 15, tq = i16 >> 2, tp = i16 & 3, half = (l >> 4) & 1;
     const int off = (8 * h + tq) * kHRowB + h_col_perm(16 * half + 4 * tp) * 2;
     const KL_LDS unsigned char *p = (const KL_LDS unsigned char *)img + off + (16 * s) * kHRowB + (32 * u) * 2;
-    bf16x8 v = tr_pair(p, p + 4 * kHRowB);
+    opx8 v = tr_pair(p, p + 4 * kHRowB);
     s16x8 w = __builtin_bit_cast(s16x8, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[l * 8 + j] = w[j];
@@ -49,7 +49,7 @@ __global__ void k_probe_tr(short *out, int s, int u) {
     // column 32u + 16s + 8(j>>2) + 4h + (j&3) of row r
     const int r = l & 31;
     const KL_LDS unsigned char *p2 = (const KL_LDS unsigned char *)img + r * kHRowB + 16 * h + (32 * u) * 2 + 32 * s;
-    s16x8 w2 = __builtin_bit_cast(s16x8, *(const KL_LDS bf16x8 *)p2);
+    s16x8 w2 = __builtin_bit_cast(s16x8, *(const KL_LDS opx8 *)p2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[512 + l * 8 + j] = w2[j];
 }
@@ -58,29 +58,29 @@ __global__ void k_probe_tr(short *out, int s, int u) {
 // as the B operand of Y = A2[32x32] . X with the permuted k order.
 __global__ void k_probe_chain(const float *A0, const float *B0, const float *A2, float *Y) {
     const int l = threadIdx.x, r = l & 31, h = l >> 5;
-    bf16x8 a, b;
+    opx8 a, b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        a[j] = (__bf16)A0[r * 16 + 8 * h + j];
-        b[j] = (__bf16)B0[(8 * h + j) * 32 + r];
+        a[j] = (opnd_t)A0[r * 16 + 8 * h + j];
+        b[j] = (opnd_t)B0[(8 * h + j) * 32 + r];
     }
     f32x16 x;
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.f;
-    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, x, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, x, 0, 0, 0);
     float q[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) q[e] = x[e];
-    const bf16x8 b0 = pack8(q), b1 = pack8(q + 8);
+    const opx8 b0 = pack8(q), b1 = pack8(q + 8);
     f32x16 y;
 #pragma unroll
     for (int e = 0; e < 16; ++e) y[e] = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        bf16x8 a2;
+        opx8 a2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a2[j] = (__bf16)A2[r * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
-        y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, s == 0 ? b0 : b1, y, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) a2[j] = (opnd_t)A2[r * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+        y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, s == 0 ? b0 : b1, y, 0, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {

@@ -6,21 +6,20 @@ Tolerances (stated per mode):
            rtol 1e-9 on W/H, 1e-10 on losses, identical iteration counts.
   f32   -- fp32 everywhere: losses rtol 2e-5, W/H rtol 2e-3 (vs the fp32 run of
            the reference, fixture G7, and vs the fp64 oracle).
-  bf16  -- bf16 MFMA operands (W, H, Q rounded to bf16), fp32 accumulate and
+  bf16  -- (historical name; = 'f16') fp16 MFMA operands: W, H, Q rounded to 11 significant bits with
+           power-of-two-scaled images and saturating conversion, fp32 accumulate and
            masters.  Every recorded loss within 1e-3 of the fp64 oracle, W/H
-           within 3e-2 of the matrix max, and the TRUE loss of the trained model
-           (evaluated in fp64 on the exact data) within 1e-4 (the north-star
-           tolerance) -- 5e-4 on the two smallest cases (37 x 53; 500 x 1000 with
-           k = 10 over 50 iterations), measured 2.6e-4 .. 2.8e-4 there.
-           The loss the bf16 mode REPORTS is KL(V~ || WH) - KL(V~ || V) with V~
+           within 5e-3 of the matrix max (measured <= 5e-4), and the TRUE loss of the trained
+           model (evaluated in fp64 on the exact data) within 1e-4 -- the north-star
+           tolerance -- on every case (measured <= 7e-5; scripts/tolerance_survey.py).
+           The loss the mode REPORTS is KL(V~ || WH) - KL(V~ || V) with V~
            = V as stored (power-of-two-scaled fp16, 11 significant bits); the
            identity KL(V||WH) = KL(V~||WH) - KL(V~||V) + sum (V~-V) ln(WH/V)
            is exact and the dropped last term is zero-mean and second order
            (DESIGN.md "loss with rounded V").  Reported-loss tolerance: the same
-           as for the true loss (the evaluation itself is within 1e-4 of the true
-           loss of its model in every case: measured <= 9e-5 at 2 000 elements,
-           <= 3e-5 from 20 000 elements on, 1e-6 at config shapes).
-           `bf16_v32` stores V in fp32 (no such term).
+           1e-4 (the evaluation itself is within 6e-5 of the true loss of its model at
+           2 000 elements, <= 3e-5 from 20 000 elements on, 3e-6 at config shapes).
+           `bf16_v32` / `f16_v32` stores V in fp32 (no such term).
 """
 import io
 import contextlib
@@ -332,10 +331,9 @@ def test_bf16_fit_matches_oracle(n, f, k, iters, prec):
     assert_allclose(errors, eo, rtol=1e-3)
     final_o = orc.kl_error(X, Wo, Ho)
     final_g = m.error(X, W)                                # as the bf16 mode reports it
-    # 1e-4 (the north star's tolerance) everywhere but the two smallest problems, where 8-bit-significand operands
-    # drift without rows to average over: measured 2.8e-4 at 37 x 53 (2 000 elements) and 2.6e-4 after 50 iterations
-    # at 500 x 1000, k = 10 (scripts/tolerance_survey.py; every other case <= 3e-5)
-    tol_final = 5e-4 if (n, f) in ((37, 53), (500, 1000)) else 1e-4
+    # 1e-4 (the north star's tolerance) on every case: measured <= 7e-5 (500 x 1000, k = 10 after 50 iterations),
+    # 2.5e-5 at 37 x 53, <= 2e-6 elsewhere (scripts/tolerance_survey.py; bf16 operands needed 5e-4 on the two smallest)
+    tol_final = 1e-4
     assert abs(final_g - final_o) <= tol_final * abs(final_o), (final_g, final_o)
     # quality of the trained model itself: exact fp64 loss on the exact data
     m64 = nmf.KLdivNMF(n_components=k, precision='f64')
@@ -343,8 +341,8 @@ def test_bf16_fit_matches_oracle(n, f, k, iters, prec):
     assert abs(true_g - final_o) <= tol_final * abs(final_o), (true_g, final_o)
     assert np.all(W >= 0) and np.all(m.components_ >= 0)
     assert_allclose(m.components_.sum(axis=1), 1.0, rtol=1e-5)
-    assert _rel_to_max(W, Wo) < 3e-2
-    assert _rel_to_max(m.components_, Ho) < 3e-2
+    assert _rel_to_max(W, Wo) < 5e-3
+    assert _rel_to_max(m.components_, Ho) < 5e-3
 
 
 def test_bf16_pieces_match_oracle():
@@ -363,8 +361,8 @@ def test_bf16_pieces_match_oracle():
         ctx.update(True)
         W1, H1 = ctx.get_W(), ctx.get_H()
     Wo, Ho = orc.update_step(X, W0, H, fit=True)
-    assert _rel_to_max(W1, Wo) < 1e-2
-    assert _rel_to_max(H1, Ho) < 1e-2
+    assert _rel_to_max(W1, Wo) < 5e-3
+    assert _rel_to_max(H1, Ho) < 5e-3
 
 
 def test_bf16_transform_and_learner():
@@ -389,13 +387,13 @@ def test_bf16_transform_and_learner():
     try:
         lr = MultimodalLearner(['a', 'b'], list(dims), coefs, k)
         lr.train(blocks, 15)
-        assert _rel_to_max(lr.dico, dico_o) < 3e-2
+        assert _rel_to_max(lr.dico, dico_o) < 5e-3
         test = [np.abs(rs.random_sample((9, d))) for d in dims]
         Wi = lr.reconstruct_internal('a', test[0], 10)
     finally:
         L.NMF = orig
     Wo = orc.learner_internal([test[0]], [coefs[0]], [lr.dico[:, :dims[0]]], 10)
-    assert _rel_to_max(Wi, Wo) < 3e-2
+    assert _rel_to_max(Wi, Wo) < 5e-3
 
 
 def test_bf16_stop_rule_fires_like_oracle():
@@ -461,14 +459,14 @@ def test_config4_k_and_f_at_reduced_rows_bf16():
     true_g = nmf.KLdivNMF(n_components=k, precision='f64').error(X, W, H=m.components_)
     print("config4-shape: true fp64 loss of the bf16 model rel %.3e" % ((true_g - fo) / fo))
     assert abs(true_g - fo) <= 1e-4 * abs(fo)
-    assert _rel_to_max(m.components_, Ho) < 3e-2
+    assert _rel_to_max(m.components_, Ho) < 5e-3
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,f,k', [(2048, 256, 40), (2048, 512, 96), (4096, 1024, 17), (2048, 256, 128)])
 def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
     """The ping-pong row pass (mfma4.hip.h) and the generation-1 kernel run the same MFMA
-    sequence per wave: errors, W and H must be bit-identical.  Shapes chosen where the
+    sequence per wave: errors, W and H must agree to fp32 rounding.  Shapes chosen where the
     hand-scheduled variant once fetched V tiles from stale addresses (k <= 96, f > 128)."""
     X = orc.synthetic_V(5, n, f, k)
     H0 = orc.synthetic_H0(5, f, k)
@@ -478,14 +476,13 @@ def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
         monkeypatch.setenv('KLNMF_ROWPASS', gen)
         m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
         out[gen] = (W, m.components_.copy(), errors)
-    if k % 16 == 0:         # same MFMA sequence and arithmetic: bit-identical
-        np.testing.assert_array_equal(out['1'][0], out['4'][0])
-        np.testing.assert_array_equal(out['1'][1], out['4'][1])
-        assert_allclose(out['4'][2], out['1'][2], rtol=1e-12)
-    else:                   # the ping-pong path carries eps through a pad component (bf16(eps) instead of eps)
-        assert_allclose(out['4'][0], out['1'][0], rtol=2e-4, atol=1e-5 * np.abs(out['1'][0]).max())
-        assert_allclose(out['4'][1], out['1'][1], rtol=2e-4, atol=1e-5 * np.abs(out['1'][1]).max())
-        assert_allclose(out['4'][2], out['1'][2], rtol=1e-5)
+    # Same arithmetic per element.  The generation-1 path recomputes W.H and the ratio in its column pass with the operand
+    # roles of W and H swapped, the ping-pong path stores the row pass's ratios, and (k not a multiple of 16) carries eps
+    # through a pad component.  With bf16 operands (16-bit products, exact partial sums) the two were bit-identical for
+    # k % 16 == 0; with 11-bit operands the MFMA's internal summation order shows in the last fp32 bits: 3e-5 after 3 updates.
+    assert_allclose(out['4'][0], out['1'][0], rtol=2e-4, atol=1e-5 * np.abs(out['1'][0]).max())
+    assert_allclose(out['4'][1], out['1'][1], rtol=2e-4, atol=1e-5 * np.abs(out['1'][1]).max())
+    assert_allclose(out['4'][2], out['1'][2], rtol=1e-5)
 
 
 @pytest.mark.gpu

@@ -199,18 +199,18 @@ def test_real_iteration_counts_tol0_against_reference(name):
     assert len(e) == len(ref)                                    # no spurious stop under tol = 0
     assert np.all(np.diff(e) < 0)
     assert_allclose(e[:3], ref[:3], rtol=1e-3)                   # the first updates drop the loss by decades
-    # G12 leaves its plateau around iteration 60 and then descends by 0.7-0.9 % PER ITERATION up to the last one: a
-    # run that is 0.02 iterations ahead on that slope differs by 1.5e-4 (scripts/fixture_profile.py, 8-bit-significand
-    # operands); G11 is on its plateau (1.6e-4 per iteration) and agrees to 4e-6
-    tol = KL_TOL if name.startswith('g11') else 2 * KL_TOL
+    # every recorded loss at the north star's tolerance: measured 3e-6 (G11) and 7e-6 (G12, whose last 140 iterations
+    # descend by 0.7-0.9 % each: with 8-bit-significand operands the run was 0.02 iterations ahead there = 1.5e-4;
+    # scripts/fixture_profile.py)
+    tol = KL_TOL
     assert_allclose(e[3:], ref[3:], rtol=tol)
     final_ref = float(g['final'])
     assert abs(m.error(X, W) - final_ref) <= tol * final_ref                          # reported final loss
     true_g = nmf.KLdivNMF(n_components=k, precision='f64').error(X, W, H=m.components_)
     assert abs(true_g - final_ref) <= tol * final_ref                                 # true fp64 loss of the returned model
-    assert abs(m.error(X, W) - true_g) <= 0.2 * KL_TOL * true_g                       # the loss evaluation itself
+    assert abs(m.error(X, W) - true_g) <= 0.1 * KL_TOL * true_g                       # the loss evaluation itself (3e-6)
     sn, sf = n // 64, f // 64
-    assert_allclose(W[::sn], g['W_rows'], rtol=3e-2, atol=3e-3 * np.abs(g['W_rows']).max())
-    assert_allclose(m.components_[:, ::sf], g['H_cols'], rtol=3e-2, atol=3e-3 * np.abs(g['H_cols']).max())
+    assert_allclose(W[::sn], g['W_rows'], rtol=1e-2, atol=1e-3 * np.abs(g['W_rows']).max())
+    assert_allclose(m.components_[:, ::sf], g['H_cols'], rtol=1e-2, atol=1e-3 * np.abs(g['H_cols']).max())
     assert_allclose(m.components_.sum(axis=1), 1.0, rtol=1e-5)
     assert_allclose(W.sum(axis=0), g['W_colsum'], rtol=2e-3)
