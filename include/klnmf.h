@@ -79,6 +79,11 @@ int klnmf_set_problem(klnmf_ctx *ctx, int64_t n, int64_t f, int64_t k,
  * blocks (and all ranks: the factor must be common) before the first upload.
  * Without it c = 1 (fine for data in fp16's range).  No-op in the other modes. */
 int klnmf_set_v_max(klnmf_ctx *ctx, double vmax);
+/* Forget the uploaded matrix: zero V and the sums the upload kernels accumulate (sum of V as stored, the
+ * storage-rounding correction of the loss, the count of values beyond the announced maximum), so that the same
+ * context can take another matrix of the same shape; klnmf_set_v_max may be called again afterwards.  (Uploading
+ * a block twice without this counts it twice in the reported loss.) */
+int klnmf_reset_V(klnmf_ctx *ctx);
 /* Upload the sub-block V[row0:row0+rows, col0:col0+cols] = scale * src, src a
  * host array with leading dimension ld (elements).  One call per modality
  * block replaces learner.py:53-56 (`safe_hstack([c * m ...])`): the scale,

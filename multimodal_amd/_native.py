@@ -38,6 +38,7 @@ SIGNATURES = {
     'klnmf_destroy': (_c.c_int, [_ctx_p]),
     'klnmf_set_problem': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64]),
     'klnmf_set_v_max': (_c.c_int, [_ctx_p, _c.c_double]),
+    'klnmf_reset_V': (_c.c_int, [_ctx_p]),
     'klnmf_upload_V': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64, _i64, _i64,
                                   _i64, _i64, _c.c_double]),
     'klnmf_upload_V_device_rows': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_void_p, _i64, _i64, _i64, _i64, _i64,
@@ -255,6 +256,9 @@ class Context(object):
 
     def set_v_max(self, vmax):
         _check(self._lib.klnmf_set_v_max(self._h, float(vmax)))
+
+    def reset_V(self):
+        _check(self._lib.klnmf_reset_V(self._h))
 
     def upload_V(self, block, row0=0, col0=0, scale=1.0):
         """V[row0:, col0:] block = scale * block (any strides; row-major view

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             fetch(std::integral_constant<int, j + 2>{});
             constexpr int younger = (j + 2 < N3 ? 2 : N3 - 1 - j);      // fragments issued after fragment j
             lds_wait<2 * younger>(ring[j % 3]);
-            acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+            acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
         });
     };
     auto fence = [&]() {          // my copies of the next stage have landed; then everybody's

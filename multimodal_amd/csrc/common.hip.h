@@ -22,7 +22,7 @@ struct DevState {
     int stop;          // stop rule fired (the `break` of nmf.py:216)
     int n_done;        // updates executed == len(errors)
     int v_overflow;    // uploaded values that exceeded the fp16 range announced with klnmf_set_v_max (saturated)
-    int pad1;
+    int op_range;      // components whose measured fp16 operand images could not hold both factors (max W x max H > 2^30)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -105,6 +105,14 @@ struct DevBlockCache {
         held -= cls;
         return p;
     }
+    void flush(int device) {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : free_blocks) {
+            if (kv.first.first != device) continue;
+            for (void *p : kv.second) { (void)hipFree(p); held -= kv.first.second; }
+            kv.second.clear();
+        }
+    }
     bool give(int device, size_t cls, void *p) {
         if (cls > ((size_t)64 << 20)) return false;
         std::lock_guard<std::mutex> g(mu);
@@ -168,7 +176,11 @@ struct klnmf_ctx {
     int row_gen = 4;
     int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
     double *hsum = nullptr;
-    float *hs = nullptr;         // [KP] per-component power-of-two scale of the dictionary image (mfma.hip.h, opnd_t)
+    // per-component power-of-two scales of the fp16 operand images (mfma.hip.h, opnd_t), [KP] each: of the current images;
+    // hs-based (from the dictionary's row sums); the constant 2^-13 of a row-normalised dictionary; measured from a W
+    float *tcur = nullptr, *t_hs = nullptr, *t_unit = nullptr;
+    unsigned *wmax = nullptr;
+    bool images_measured = false;    // the current images carry measured scales: valid for one update (see opnd_t)
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     float *NpartF = nullptr, *numerF = nullptr;
     double2 *loss_part2 = nullptr;
@@ -191,7 +203,15 @@ struct klnmf_ctx {
         if (bytes == 0) bytes = 16;
         const size_t cls = DevBlockCache::size_class(bytes);
         void *p = g_block_cache.take(device, cls);
-        if (!p) HIPCHK(hipMalloc(&p, cls));
+        if (!p) {
+            hipError_t e = hipMalloc(&p, cls);
+            if (e == hipErrorOutOfMemory) {        // the cache may be what is in the way: give its blocks back and retry once
+                (void)hipGetLastError();
+                g_block_cache.flush(device);
+                e = hipMalloc(&p, cls);
+            }
+            HIPCHK(e);
+        }
         allocs.push_back({p, cls});
         if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, stream));
         return p;
@@ -341,8 +361,9 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.W32_new = c->W32[c->cur ^ 1];
     a.loss_part = c->loss_part2;
     a.hsum = c->hsum;
-    a.hs = c->hs;
-    a.fit = (store_q && mode == ROW_UPDATE) ? 1 : 0;
+    a.tcur = c->tcur;
+    // the new W image goes with the NEXT dictionary image: row-normalised after an H rule (fit), else the hs-based one
+    a.tnext = mode == ROW_UPDATE ? (store_q ? c->t_unit : c->t_hs) : c->tcur;
     a.stamps = c->stamps;
     a.kc = c->kc;
     a.st = c->st;
@@ -366,7 +387,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
             hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
                                (const float *)c->Gpart, c->row_chunks, rows * c->KP, (const float *)c->W32[c->cur],
                                c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
-                               (const DevState *)c->st, (const float *)c->hs, a.fit);
+                               (const DevState *)c->st, a.tcur, a.tnext);
             HIPCHK(hipGetLastError());
             if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
             return;
@@ -464,16 +485,38 @@ void fast_colpass(klnmf_ctx *c) {
     HIPCHK(hipGetLastError());
 }
 
-void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false) {
+void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false, const unsigned *wmax = nullptr) {
     // ping-pong row pass + stored-ratio column pass read only the Ht4 tile images (KLNMF_ROWPASS / KLNMF_COLPASS are read
     // once, in klnmf_set_problem, so the choice cannot change under a context)
     const bool lean = c->pingpong() && c->Qt != nullptr;
     hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
                        (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (opnd_t *)nullptr : c->Ht, c->Ht4,
-                       lean ? (opnd_t *)nullptr : c->HTb, c->hsum, c->hs, c->f, c->f_pad,
+                       lean ? (opnd_t *)nullptr : c->HTb, c->hsum, c->tcur, c->t_hs, wmax, &c->st->op_range, c->f, c->f_pad,
                        c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
                        (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad);
     HIPCHK(hipGetLastError());
+    c->images_measured = wmax != nullptr;
+}
+
+void fast_pack_W(klnmf_ctx *c) {
+    hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n_pad * c->KP, 256, 8192)), dim3(256), 0,
+                       c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n_pad, c->KP,
+                       w_ld(c->KP), c->kc, (const float *)c->tcur);
+    HIPCHK(hipGetLastError());
+}
+
+// Both images of the current (W, H) with scales MEASURED from W's column maxima (a W that no W rule produced: W0 = V.H0^T,
+// klnmf_set_W -- see opnd_t in mfma.hip.h).  They are valid for one update; the update's W rule packs the next W image
+// with the hs-based / row-normalised scale again.
+void measure_and_pack(klnmf_ctx *c) {
+    HIPCHK(hipMemsetAsync(c->wmax, 0, (size_t)c->KP * 4, c->stream));
+    HIPCHK(hipMemsetAsync(&c->st->op_range, 0, sizeof(int), c->stream));
+    const int rows_grid = (int)std::min<int64_t>(c->n_pad, 1024);
+    hipLaunchKernelGGL(k_colmax_W, dim3(rows_grid, (c->KP + 255) / 256), dim3(256), 0, c->stream,
+                       (const float *)c->W32[c->cur], c->n_pad, c->KP, c->wmax);
+    HIPCHK(hipGetLastError());
+    fast_pack_H(c, 0, false, c->wmax);
+    fast_pack_W(c);
 }
 
 // ------------------------------------------------------------ exact pieces ---
@@ -616,7 +659,11 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
         EXACT_CALL(c, exact_Q, 1);
         EXACT_CALL(c, exact_W, c->sparse ? c->sp_q : c->Q, 1);
     } else {
+        const bool measured = c->images_measured;
         fast_rowpass(c, ROW_UPDATE, fit);
+        // measured image scales live for one update: the new W image already carries the hs-based scale (tnext); in a fit
+        // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
+        if (measured && !fit) fast_pack_H(c, 0);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const double2 *)c->loss_part2, (int64_t)c->nrt * (c->pingpong() ? c->row_chunks : 1),
                            (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
@@ -683,7 +730,7 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
         default:
             hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
                                (float *)c->VtA, (float *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
-                               ld, row0, col0, scale, c->st, row_idx);
+                               ld, row0, col0, scale * c->v_scale, c->st, row_idx);      // same units as the fp16 storage
             break;
     }
     HIPCHK(hipGetLastError());
@@ -924,6 +971,9 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         if (n <= 0 || f <= 0 || k <= 0 || cap < 0) fail(KLNMF_ERR_ARG, "n, f, k must be positive");
         if (n > (1LL << 30) || f > (1LL << 30) || k > (1LL << 20))
             fail(KLNMF_ERR_UNSUPP, "dimension too large");
+        if (c->is_exact() && n > (int64_t)65535 * GT)
+            fail(KLNMF_ERR_UNSUPP, "KLNMF_PREC_F64 / F32: more than 65535 x 64 rows per context (row tiles ride on gridDim.y); "
+                                   "shard the rows or use the 16-bit mode");
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
         c->Gpart = nullptr; c->row_chunks = 1;
@@ -1017,10 +1067,15 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // carrier column at 1) and a spare component inside the MFMA-1 contraction range
             c->kc = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
             c->hsum = (double *)c->dalloc((size_t)c->KP * 8);
-            c->hs = (float *)c->dalloc((size_t)c->KP * 4);
+            c->tcur = (float *)c->dalloc((size_t)c->KP * 4);
+            c->t_hs = (float *)c->dalloc((size_t)c->KP * 4);
+            c->t_unit = (float *)c->dalloc((size_t)c->KP * 4);
+            c->wmax = (unsigned *)c->dalloc((size_t)c->KP * 4);
+            c->images_measured = false;
             {
-                const std::vector<float> ones((size_t)c->KP, 1.f);      // until a dictionary is packed (k_update_pack_H)
-                HIPCHK(hipMemcpyAsync(c->hs, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, c->stream));
+                const std::vector<float> unit((size_t)c->KP, kOpScaleW);      // until a dictionary is packed (k_update_pack_H)
+                for (float *t : {c->tcur, c->t_hs, c->t_unit})
+                    HIPCHK(hipMemcpyAsync(t, unit.data(), unit.size() * 4, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
             }
 #ifdef KL_STAMPS
@@ -1146,7 +1201,7 @@ int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
         need_problem(c);
         if (!(vmax >= 0) || !std::isfinite(vmax)) fail(KLNMF_ERR_ARG, "vmax must be finite and >= 0");
         if (c->v_uploaded) fail(KLNMF_ERR_ARG, "klnmf_set_v_max must precede the first upload");
-        if (c->prec != KLNMF_PREC_BF16 || vmax == 0) {
+        if (c->is_exact() || vmax == 0) {
             c->v_scale = 1.0;
             return;
         }
@@ -1154,6 +1209,26 @@ int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
         (void)std::frexp(vmax, &e);             // vmax = m * 2^e, m in [0.5, 1)
         c->v_scale = std::ldexp(1.0, 15 - e);   // c * vmax in [2^14, 2^15)
         if (c->kc >= 0) fast_pack_H(c, 0);      // the eps row of the dictionary images is in scaled units
+    });
+}
+
+int klnmf_reset_V(klnmf_ctx *c) {
+    return guarded([&] {
+        need_problem(c);
+        if (c->sparse) fail(KLNMF_ERR_ARG, "klnmf_reset_V: CSR problems are re-uploaded whole (klnmf_upload_csr)");
+        // the upload kernels ACCUMULATE sum(V as stored), the storage-rounding correction and the overflow count: a second
+        // upload into a live context would count a block twice.  Clear the matrix and the three counters.
+        if (c->is_exact()) {
+            HIPCHK(hipMemsetAsync(c->V, 0, (size_t)c->n * c->f * c->esize(), c->stream));
+        } else {
+            const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * c->vsize();
+            HIPCHK(hipMemsetAsync(c->VtA, 0, vbytes, c->stream));
+            if (c->VtB) HIPCHK(hipMemsetAsync(c->VtB, 0, vbytes, c->stream));
+        }
+        HIPCHK(hipMemsetAsync(&c->st->sum_x, 0, sizeof(double) * 2, c->stream));         // sum_x, corr_c
+        HIPCHK(hipMemsetAsync(&c->st->v_overflow, 0, sizeof(int), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->v_uploaded = false;
     });
 }
 
@@ -1217,12 +1292,8 @@ int klnmf_set_H(klnmf_ctx *c, const void *src, int dtype) {
         if (!c->is_exact()) HIPCHK(hipMemsetAsync(c->H32, 0, (size_t)c->KP * c->f_pad * 4, c->stream));
         set_matrix(c, src, dtype, c->k, c->f, c->H, c->H32, c->f_pad);
         if (!c->is_exact()) {
-            fast_pack_H(c, 0);
-            // the W image carries the inverse of the dictionary image's per-component scale: re-pack it for the new one
-            hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n_pad * c->KP, 256, 8192)), dim3(256), 0,
-                               c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n_pad, c->KP,
-                               w_ld(c->KP), c->kc, (const float *)c->hs);
-            HIPCHK(hipGetLastError());
+            fast_pack_H(c, 0);          // hs-based scales (also leaves them in t_hs)
+            measure_and_pack(c);        // the W that is there (zeros, W0 of another dictionary, a klnmf_set_W) goes with it
         }
     });
 }
@@ -1232,13 +1303,7 @@ int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
         need_problem(c);
         if (!src) fail(KLNMF_ERR_ARG, "null source");
         set_matrix(c, src, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP, c->v_scale);
-        if (!c->is_exact()) {
-            // all padded rows too: the eps-carrying pad column must be 1 in every row a tile can contain
-            hipLaunchKernelGGL(k_pack_W, dim3(grid_for(c->n_pad * c->KP, 256, 8192)), dim3(256), 0,
-                               c->stream, (const float *)c->W32[c->cur], c->Wb[c->cur], c->n_pad, c->KP,
-                               w_ld(c->KP), c->kc, (const float *)c->hs);
-            HIPCHK(hipGetLastError());
-        }
+        if (!c->is_exact()) measure_and_pack(c);     // (all padded rows too: the eps carrier column in every row a tile can contain)
     });
 }
 
@@ -1267,16 +1332,23 @@ int klnmf_init_W(klnmf_ctx *c) {
         } else if (c->is_exact()) EXACT_CALL(c, exact_W, c->V, 0);
         else fast_rowpass(c, ROW_INIT);
         c->cur ^= 1;
+        if (!c->is_exact()) measure_and_pack(c);     // W0 = V.H0^T scales with H0: images with measured scales for the first update
     });
 }
 
 // fp16 storage: values above the maximum announced with klnmf_set_v_max were saturated on upload; a fit on such
 // a matrix is not the fit of the caller's data, so the loop entry points refuse it (one 4-byte read per loop).
 static void check_v_overflow(klnmf_ctx *c) {
-    if (c->prec != KLNMF_PREC_BF16 || !c->v_uploaded) return;
-    int ov = 0;
-    HIPCHK(hipMemcpyAsync(&ov, &c->st->v_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (c->is_exact()) return;
+    int flags[2] = {0, 0};       // v_overflow, op_range (adjacent in DevState)
+    HIPCHK(hipMemcpyAsync(flags, &c->st->v_overflow, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (flags[1] != 0)
+        fail(KLNMF_ERR_UNSUPP, "the factors exceed the fp16 operand range (max W x max H of " + std::to_string(flags[1]) +
+                                   " component(s) is more than 2^15 times the largest entry of V: an initial dictionary whose rows "
+                                   "sum to far more than 1?); run KLNMF_PREC_F32 / F64");
+    if (c->prec != KLNMF_PREC_BF16 || !c->v_uploaded) return;
+    const int ov = flags[0];
     if (ov != 0)
         fail(KLNMF_ERR_ARG, "uploaded V exceeds the maximum given to klnmf_set_v_max (" + std::to_string(ov) +
                                 " values out of the fp16 storage range)");
@@ -1414,9 +1486,11 @@ int klnmf_bind_exchange(klnmf_ctx *c, void *loss_ptr, void *numer_ptr) {
 int klnmf_error(klnmf_ctx *c, double *loss) {
     return guarded([&] {
         need_problem(c);
+        check_v_overflow(c);
         reset_state(c);
         if (c->is_exact()) {
-            EXACT_CALL(c, exact_Q, 0);
+            // the reference's CSR branch uses the caller's eps (nmf.py:301-308); its dense branch ignores it (nmf.py:309-310)
+            EXACT_CALL(c, exact_Q, 0, c->sparse ? c->ratio_eps : kEpsRatio);
         } else {
             fast_rowpass(c, ROW_LOSS);
             hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
@@ -1455,6 +1529,7 @@ int klnmf_loss_terms(klnmf_ctx *c, double *terms) {
 int klnmf_update(klnmf_ctx *c, int fit) {
     return guarded([&] {
         need_problem(c);
+        check_v_overflow(c);
         reset_state(c);
         piece_rowpass(c, fit);
         if (fit) {
@@ -1617,6 +1692,7 @@ int klnmf_matmul(int device, int dtype, int64_t m, int64_t n, int64_t kk, const 
             fail(KLNMF_ERR_ARG, "klnmf_matmul: bad shape");
         if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_matmul: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
         if (m == 0 || n == 0) return;
+        if (m > (int64_t)65535 * GT) fail(KLNMF_ERR_UNSUPP, "klnmf_matmul: more than 65535 x 64 rows (row tiles ride on gridDim.y)");
         if (!A || !B || !C) fail(KLNMF_ERR_ARG, "klnmf_matmul: null pointer");
         HIPCHK(hipSetDevice(device));
         if (kk == 0) { std::memset(C, 0, (size_t)(m * n) * (dtype == KLNMF_DT_F64 ? 8 : 4)); return; }

@@ -42,12 +42,27 @@ namespace klnmf {
 
 // MFMA operand element of the 16-bit modes: IEEE half (11 significant bits) with power-of-two scaling of the images
 // and saturating conversion (MODE.FP16_OVFL), not bf16 (8 bits): same matrix rate (v_mfma_f32_32x32x16_f16), 8x smaller
-// operand rounding.  Scaling (exact, powers of two): per component a, hs_a = the power of two >= rowsum(H_a) (1 for a
-// row-normalised dictionary);  H image = half(H * 2^13 / hs_a),  W image = half(W32 * hs_a * 2^-13)  -- the product of
-// the two scales is 1 for every component, so W.H, the ratio, the loss terms and every rule are unscaled; only the two
-// places that turn an accumulator back into a master apply a per-component factor (the W rule: G * hs_a * 2^-13; the
-// H rule: its factor is constant along a dictionary row and cancels in the row normalisation).
+// operand rounding.  Scaling (exact, powers of two): per component a a factor t_a;  W image = half(W32 * t_a),
+// H image = half(H / t_a)  -- the product of the two scales is 1 for every component, so W.H, the ratio, the loss terms
+// and every rule are unscaled; only the two places that turn an accumulator back into a master apply a per-component
+// factor (the W rule: G * t_a; the H rule: its factor is constant along a dictionary row and cancels in the row
+// normalisation).  Which t_a:
+//   * from the second update of a loop on,  t_a = hs_a * 2^-13  with hs_a the power of two >= rowsum(H_a) (1 for a
+//     row-normalised dictionary): H image entries <= 2^13, and after any W rule sum_a W_ia rowsum(H_a) = rowsum(V_i)
+//     (nmf.py:342 with the ratio of the same W), so W32_ia hs_a <= 2 rowsum(c V_i) <= f 2^16: W image <= 8 f;
+//     (V, hence W32, in the storage factor's units: max(c V) in [2^14, 2^15) in BOTH 16-bit modes, whatever V is stored as);
+//   * a W that did not come out of a W rule (W0 = V.H0^T of an unnormalised H0, klnmf_set_W) obeys no such bound: its
+//     images use MEASURED, balanced scales -- t_a = the power of two nearest sqrt(max_j H_aj / max_i W32_ia), so that both
+//     images of component a peak at the same magnitude sqrt(max W max H) -- for the one update they live (k_colmax_W).
+#ifdef KL_OPND_BF16        // experiment builds only (scripts/build_variant.sh): the round-1 operand type, for A/B timing
+typedef __bf16 opnd_t;
+#define KL_MFMA_BUILTIN __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define KL_MFMA_ASM "v_mfma_f32_32x32x16_bf16"
+#else
 typedef _Float16 opnd_t;
+#define KL_MFMA_BUILTIN __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define KL_MFMA_ASM "v_mfma_f32_32x32x16_f16"
+#endif
 typedef __attribute__((ext_vector_type(8))) opnd_t opx8;
 typedef __attribute__((ext_vector_type(4))) opnd_t opx4;
 constexpr float kOpScaleH = 8192.f;              // 2^13
@@ -236,8 +251,8 @@ struct RowPassArgs {
     const double *hsum;       // [KP] row sums of the 16-bit dictionary image (for sum(W.H)), see row_sum_wh
     unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
     unsigned char *Qt;            // ratio tiles for k_colpass_q ([nct][nrt][2 KiB], see there), or null (ping-pong pass only)
-    const float *hs;              // [KP] per-component power of two of the current dictionary image (see opnd_t)
-    int fit;                      // the H rule follows (the new W image is scaled for a row-normalised dictionary, hs = 1)
+    const float *tcur;            // [KP] per-component scale t_a of the CURRENT images (W image = W32 * t, H image = H / t; see opnd_t)
+    const float *tnext;           // [KP] scale the W rule packs the NEW W image with (the next dictionary image's)
     int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     fetch(s + KL_RING - 1);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s % KL_RING], wf[s], d, 0, 0, 0);
+                    d = KL_MFMA_BUILTIN(ring[s % KL_RING], wf[s], d, 0, 0, 0);
                 }
                 KL_STAMP(t2);
 #pragma unroll
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
                 for (int j = 0; j < N2; ++j) {
                     fetch(N1 + j + KL_RING - 1);
-                    acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(N1 + j) % KL_RING], (j & 1) ? b1 : b0,
+                    acc[j >> 1] = KL_MFMA_BUILTIN(ring[(N1 + j) % KL_RING], (j & 1) ? b1 : b0,
                                                                           acc[j >> 1], 0, 0, 0);
                 }
                 KL_STAMP(t4);
@@ -490,13 +505,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int comp = 32 * m + 8 * g + 4 * h;
-                const f32x4 hsv = *(const f32x4 *)(a.hs + comp);
+                const f32x4 tc = *(const f32x4 *)(a.tcur + comp), tn = *(const f32x4 *)(a.tnext + comp);
                 opx4 wb;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float ginv = hsv[t] * kOpScaleW;                  // the accumulator saw the scaled dictionary image
-                    w[g][t] *= acc[m][4 * g + t] * ginv;
-                    wb[t] = (opnd_t)(w[g][t] * (a.fit ? kOpScaleW : ginv));
+                    w[g][t] *= acc[m][4 * g + t] * tc[t];                   // the accumulator saw the dictionary image H / t
+                    wb[t] = (opnd_t)(w[g][t] * tn[t]);
                 }
                 *(f32x4 *)(a.W32_new + row * KP + comp) = w[g];
                 *(opx4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 fetch(s + 2);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s % 3], hf[s], d, 0, 0, 0);
+                d = KL_MFMA_BUILTIN(ring[s % 3], hf[s], d, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
 #pragma unroll
             for (int j = 0; j < N3; ++j) {
                 fetch(KS + j + 2);
-                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[(KS + j) % 3], (j & 1) ? b1 : b0,
+                acc[j >> 1] = KL_MFMA_BUILTIN(ring[(KS + j) % 3], (j & 1) ? b1 : b0,
                                                                       acc[j >> 1], 0, 0, 0);
             }
         }
@@ -769,7 +783,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 #pragma unroll
             for (int j = 0; j < N3; ++j) {
                 fetch(j + 2);
-                acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+                acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
             }
         }
     };
@@ -811,7 +825,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 // images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
 // loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
 __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
-                                                       opnd_t *Ht4, opnd_t *HTb, double *hsum, float *hs, int64_t f,
+                                                       opnd_t *Ht4, opnd_t *HTb, double *hsum, float *tcur, float *t_hs,
+                                                       const unsigned *wmax, int *op_range, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
                                                        const DevState *st, int kc, float eps_pad,
                                                        int nslab = 0, int64_t slab = 0) {
@@ -826,9 +841,10 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     }
     __shared__ double red[16];
     __shared__ double total;
+    __shared__ float rmax_s;
     const int a = blockIdx.x;
     float *row = H32 + (int64_t)a * f_pad;
-    float hs_a = 1.f;                  // a row-normalised dictionary row: sum 1, every entry <= 1
+    float t_a = kOpScaleW;             // a row-normalised dictionary row: sum 1, every entry <= 1 (hs = 1)
     if (do_update) {
         const float *nrow = num + (int64_t)a * f_pad;
         double s = 0;
@@ -845,19 +861,44 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
         const float d = (float)(kEpsNorm + total);
         for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
         __syncthreads();
+        if (t_hs && threadIdx.x == 0) t_hs[a] = t_a;
     } else {
-        // a dictionary as given (set_H: transform on a column slice, an unnormalised initial dictionary): scale the
-        // image row by the power of two at or above its sum, so that its entries use the half range as a normalised row's
+        // a dictionary as given (klnmf_set_H: transform on a column slice, an unnormalised initial dictionary): hs = the
+        // power of two at or above the row sum, so that the image's entries use the half range as a normalised row's;
+        // wmax: column maxima of the W that goes with it (bit patterns) -> the measured, balanced scale (see opnd_t)
         double s = 0;
-        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) s += (double)row[j];
+        float mx = 0.f;
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) { s += (double)row[j]; mx = fmaxf(mx, row[j]); }
         const double t = block_sum(s, red);
-        if (threadIdx.x == 0) total = t;
+        __shared__ float mred[16];
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m2 = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m2 = fmaxf(m2, mred[w]);
+            rmax_s = m2;
+            total = t;
+        }
         __syncthreads();
         int e = 0;
-        if (total > 0 && total < 1e300) { (void)frexp(total, &e); hs_a = ldexpf(1.f, e); }
+        if (total > 0 && total < 1e300) { (void)frexp(total, &e); t_a = ldexpf(kOpScaleW, e); }
+        if (t_hs && threadIdx.x == 0) t_hs[a] = t_a;
+        if (wmax) {
+            const float wm = __uint_as_float(wmax[a]), rmax = rmax_s;
+            if (wm > 0.f && wm < 3e38f && rmax > 0.f) {
+                int ew = 0, eh = 0;
+                (void)frexpf(wm, &ew);
+                (void)frexpf(rmax, &eh);
+                int et = (eh - ew) / 2;                                  // t ~ sqrt(max H / max W)
+                if (eh - et > 15) et = eh - 15;                          // H image peak <= 2^15 first (W saturates, if anything)
+                if (ew + et > 16 && threadIdx.x == 0) atomicAdd(op_range, 1);   // ... and it does: reported by the loop entry points
+                t_a = ldexpf(1.f, et);
+            }
+        }
         __syncthreads();
     }
-    const float sc = kOpScaleH / hs_a;
+    const float sc = 1.f / t_a;        // exact: t_a is a power of two
     double hsm = 0;
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
         const opnd_t v = (opnd_t)(row[j] * sc);
@@ -871,17 +912,26 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
     const double ths = block_sum(hsm, red);
     if (threadIdx.x == 0) {
         hsum[a] = ths;                 // row sum of the IMAGE (scaled): x the W image's scale it is sum_j (W.H)_ij exactly
-        hs[a] = hs_a;
+        tcur[a] = t_a;
     }
 }
 
-__global__ void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *hs) {
+// Column maxima of a W master (all entries >= 0: the bit pattern of a non-negative float orders like the integer), for the
+// measured image scales k_update_pack_H derives from them.
+__global__ void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= kp) return;
+    float m = 0.f;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) m = fmaxf(m, W32[i * kp + c]);
+    atomicMax(wmax + c, __float_as_uint(m));
+}
+__global__ void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *tcur) {
     KL_FP16_SATURATE();
     const int64_t total = n * kp;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / kp, c = e % kp;
-        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (c == kc) ? (opnd_t)kCarrierW : (opnd_t)(W32[e] * hs[c] * kOpScaleW);
+        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (c == kc) ? (opnd_t)kCarrierW : (opnd_t)(W32[e] * tcur[c]);
     }
 }
 

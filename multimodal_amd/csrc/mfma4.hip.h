@@ -138,15 +138,15 @@ __device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LD
 // wave's issue slots are the scarce resource of that schedule.  G accumulates in AGPRs ("a"), W.H in VGPRs ("v").
 template <int N>
 __device__ __forceinline__ void mfma2_w(f32x16 &acc, const opx8 &a, const opx8 &b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" KL_MFMA_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void mfma1_first_w(f32x16 &d, const opx8 &a, const opx8 &b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" KL_MFMA_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void mfma1_acc_w(f32x16 &d, const opx8 &a, const opx8 &b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" KL_MFMA_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void lds_wait(opx8 &v) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     __shared__ __attribute__((aligned(16))) unsigned char h2[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char h3[OBJ];
     __shared__ __attribute__((aligned(16))) double hsum_lds[KP];     // row sums of H, for the sum(W.H) term of the loss
-    __shared__ __attribute__((aligned(16))) float hs_lds[KP];        // per-component scale of the dictionary image (W rule)
+    __shared__ __attribute__((aligned(16))) float tc_lds[KP], tn_lds[KP];     // per-component image scales (W rule): current, next
     if (a.st->stop) return;
     KL_FP16_SATURATE();
 
@@ -332,13 +332,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             if constexpr (false)
 #endif
             if constexpr (p < N2) {
-                acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+                acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
             } else {
                 if constexpr (p == N2) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) d[e] = 0.f;
                 }
-                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % R], wf[p - N2], d, 0, 0, 0);
+                d = KL_MFMA_BUILTIN(ring[p % R], wf[p - N2], d, 0, 0, 0);
             }
         });
 #ifdef KL_STAMPS
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         if (MODE != ROW_INIT)
             for (int e = tid; e < KP; e += kThreads4) hsum_lds[e] = a.hsum[e];
         if (MODE != ROW_LOSS)
-            for (int e = tid; e < KP; e += kThreads4) hs_lds[e] = a.hs[e];
+            for (int e = tid; e < KP; e += kThreads4) { tc_lds[e] = a.tcur[e]; tn_lds[e] = a.tnext[e]; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { b0[j] = (opnd_t)0.f; b1[j] = (opnd_t)0.f; }
     }
@@ -705,14 +705,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     const int m = m0 + mm;
                     const int comp = 32 * m + 8 * g + 4 * h;
                     f32x4 w = wold[mm][g];
-                    const f32x4 hsv = *(const KL_LDS f32x4 *)(hs_lds + comp);
+                    const f32x4 tc = *(const KL_LDS f32x4 *)(tc_lds + comp), tn = *(const KL_LDS f32x4 *)(tn_lds + comp);
                     opx4 wb;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float ginv = hsv[t] * kOpScaleW;              // the accumulator saw the scaled dictionary image
-                        w[t] *= acc[m][4 * g + t] * ginv;
-                        wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW                       // eps carrier
-                                                         : (opnd_t)(w[t] * (a.fit ? kOpScaleW : ginv));
+                        w[t] *= acc[m][4 * g + t] * tc[t];                  // the accumulator saw the dictionary image H / t
+                        wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);      // eps carrier
                     }
                     *(f32x4 *)(a.W32_new + row * KP + comp) = w;
                     *(opx4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
@@ -736,7 +734,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 // image with the eps carrier column, exactly as the tail of k_rowpass4 writes them).  One thread per 4 components.
 __global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nchunk, int64_t slab, const float *W32_old,
                                                      float *W32_new, opnd_t *Wb_new, int64_t rows, int kp, int wld, int kc,
-                                                     const DevState *st, const float *hs, int fit) {
+                                                     const DevState *st, const float *tcur, const float *tnext) {
     if (st->stop) return;
     KL_FP16_SATURATE();
     const int64_t total = rows * (kp / 4);
@@ -747,13 +745,12 @@ __global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nch
         f32x4 g = *(const f32x4 *)(gpart + off);
         for (int z = 1; z < nchunk; ++z) g += *(const f32x4 *)(gpart + z * slab + off);
         f32x4 w = *(const f32x4 *)(W32_old + off);
-        const f32x4 hsv = *(const f32x4 *)(hs + comp);
+        const f32x4 tc = *(const f32x4 *)(tcur + comp), tn = *(const f32x4 *)(tnext + comp);
         opx4 wb;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float ginv = hsv[t] * kOpScaleW;
-            w[t] *= g[t] * ginv;
-            wb[t] = (comp + t == kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * (fit ? kOpScaleW : ginv));
+            w[t] *= g[t] * tc[t];
+            wb[t] = (comp + t == kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);
         }
         *(f32x4 *)(W32_new + off) = w;
         *(opx4 *)(Wb_new + row * wld + wb_col((int)(row & 31), comp)) = wb;

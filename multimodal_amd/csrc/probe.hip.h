@@ -21,7 +21,7 @@ __global__ void k_probe_mfma(const float *A, const float *B, float *D) {
     f32x16 d;
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = 0.f;
-    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, d, 0, 0, 0);
+    d = KL_MFMA_BUILTIN(a, b, d, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -67,7 +67,7 @@ __global__ void k_probe_chain(const float *A0, const float *B0, const float *A2,
     f32x16 x;
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.f;
-    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, x, 0, 0, 0);
+    x = KL_MFMA_BUILTIN(a, b, x, 0, 0, 0);
     float q[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) q[e] = x[e];
@@ -80,7 +80,7 @@ __global__ void k_probe_chain(const float *A0, const float *B0, const float *A2,
         opx8 a2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) a2[j] = (opnd_t)A2[r * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
-        y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, s == 0 ? b0 : b1, y, 0, 0, 0);
+        y = KL_MFMA_BUILTIN(a2, s == 0 ? b0 : b1, y, 0, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
