@@ -47,10 +47,12 @@ def parse_args(argv=None):
     p.add_argument('--steps', type=int, default=40)
     p.add_argument('--warmup', type=int, default=3)
     p.add_argument('--repeats', type=int, default=5, help='independent timed segments of --steps iterations (median reported)')
-    p.add_argument('--n', type=int, default=1000000)
-    p.add_argument('--f', type=int, default=4096)
-    p.add_argument('--k', type=int, default=200)
-    p.add_argument('--precision', default='bf16', choices=['bf16', 'bf16_v32', 'f32', 'f64'])
+    # (long forms: torchrun's own parser takes a bare `--n` for an abbreviation of its options)
+    p.add_argument('--n', '--rows', dest='n', type=int, default=1000000)
+    p.add_argument('--f', '--features', dest='f', type=int, default=4096)
+    p.add_argument('--k', '--components', dest='k', type=int, default=200)
+    p.add_argument('--precision', default='f16', choices=['f16', 'f16_v32', 'bf16', 'bf16_v32', 'f32', 'f64'],
+                   help="f16: fp16 MFMA operands (scaled images), fp32 accumulate; 'bf16' is the round-1 name of the same mode")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-rows', type=int, default=100000, help='rows of the same V the CPU baseline is timed on (BASELINE.md 3)')
     p.add_argument('--cpu-iters', type=int, default=3)
@@ -58,6 +60,9 @@ def parse_args(argv=None):
     p.add_argument('--data', default='blocks', choices=['blocks', 'device'],
                    help="blocks: the seeded RandomState blocks of SURVEY 8d (host-generated, identical to the CPU baseline's "
                         "data); device: a torch generator on the GPU (fast set-up for profiling runs, different values)")
+    p.add_argument('--collective', default='native', choices=['native', 'torch'],
+                   help='N > 1: native = one grouped RCCL all-reduce per iteration issued inside the C-ABI (klnmf_run_sharded); '
+                        'torch = torch.distributed all-reduces sequenced in Python around the C-ABI pieces')
     p.add_argument('--tol', type=float, default=0.0,
                    help='stop-rule tolerance of nmf.py:207,215 (relative; x n x f inside).  0 = MultimodalLearner.train')
     return p.parse_args(argv)
@@ -118,7 +123,7 @@ def measured_traffic(args, n_local):
         return None, None
     for entry in d.get('workloads', []):
         w = entry.get('workload', {})
-        if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision):
+        if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision.replace('bf16', 'f16')):
             row = col = None
             for name, v in entry.get('kernels', {}).items():
                 if 'k_rowpass' in name:
@@ -252,7 +257,15 @@ def main():
     n_local = r1 - r0
     iters_per_fit = args.warmup + args.steps
     t_setup = time.perf_counter()
-    model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision)
+    collective = args.collective if (world > 1 and not rehearsal) else 'torch'
+    try:
+        model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
+    except Exception as e:           # librccl not loadable, communicator refused, ...: say so and use the torch path
+        if collective != 'native':
+            raise
+        sys.stderr.write('bench.py: native collective path unavailable (%s); using torch.distributed\n' % e)
+        collective = 'torch'
+        model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
     if args.data == 'blocks':
         fill_shard_blocks(model, args.seed, r0, r1, n, f, k)
     else:
@@ -271,19 +284,31 @@ def main():
     for rep in range(max(1, args.repeats)):
         model.set_H(H0)
         model.init_W()
-        model.begin()
-        for _ in range(args.warmup):
-            model.iterate(fit=True, tol=args.tol)
-        model.ctx.profile_enable(True)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.iterate(fit=True, tol=args.tol)
-        fence()
-        elapsed = time.perf_counter() - t0
-        prof = model.ctx.profile_read(reset=True)
-        model.ctx.profile_enable(False)
-        errors, n_done, stopped = model.end()
+        if collective == 'native':       # each call runs its iterations, collectives included, inside the C-ABI
+            _, wd, wstop = model.run(args.warmup, fit=True, tol=args.tol) if args.warmup else ([], 0, False)
+            model.ctx.profile_enable(True)
+            fence()
+            t0 = time.perf_counter()
+            errors, n_done, stopped = model.run(args.steps, fit=True, tol=args.tol)
+            fence()
+            elapsed = time.perf_counter() - t0
+            prof = model.ctx.profile_read(reset=True)
+            model.ctx.profile_enable(False)
+            n_done, stopped = n_done + wd, stopped or wstop
+        else:
+            model.begin()
+            for _ in range(args.warmup):
+                model.iterate(fit=True, tol=args.tol)
+            model.ctx.profile_enable(True)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.iterate(fit=True, tol=args.tol)
+            fence()
+            elapsed = time.perf_counter() - t0
+            prof = model.ctx.profile_read(reset=True)
+            model.ctx.profile_enable(False)
+            errors, n_done, stopped = model.end()
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -298,8 +323,9 @@ def main():
         its = args.steps / elapsed
         row_ms = prof_tot['rowpass_ms'] / max(1, prof_tot['rowpass_launches'])
         col_ms = prof_tot['colpass_ms'] / max(1, prof_tot['colpass_launches'])
-        vbytes = 2 if args.precision == 'bf16' else 4
-        pingpong = (args.precision == 'bf16' and (k <= 224 or 256 < k <= 512)
+        fast16 = args.precision in ('f16', 'bf16')
+        vbytes = 2 if fast16 else 4
+        pingpong = (fast16 and (k <= 224 or 256 < k <= 512)
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         qbytes = _native.ratio_tile_bytes() if stored_q else 0
@@ -350,11 +376,15 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'bf16' if args.precision.startswith('bf16') else args.precision,
+            'dtype': 'f16' if args.precision in ('f16', 'f16_v32', 'bf16', 'bf16_v32') else args.precision,      # MFMA operand type (fp32 accumulate)
             'data': 'synthetic',
             'config': {'workload': 'KL-NMF fit iteration, V %dx%d (row-sharded), k=%d' % (n, f, k),
                        'n': n, 'f': f, 'k': k, 'rows_per_gpu': n_local,
                        'precision': args.precision, 'parallelism': 'rows/%d' % n_gpus,
+                       'collective': ('one grouped RCCL all-reduce of the k x f numerator + the loss per iteration, issued inside '
+                                      'the C-ABI (klnmf_run_sharded)' if collective == 'native' else
+                                      'torch.distributed all-reduce of the k x f numerator + async all-reduce of the loss')
+                                     if n_gpus > 1 else None,
                        'generator': 'seeded RandomState row blocks (SURVEY 8d), seed %d' % args.seed if args.data == 'blocks'
                                     else 'torch generator on the device, seed %d' % args.seed,
                        'timing': 'median of %d segments of %d iterations, each after a fresh init + %d warm-up iterations'

@@ -34,6 +34,7 @@ extern "C" {
 #define KLNMF_ERR_ALLOC    -2        /* device or host allocation failed  */
 #define KLNMF_ERR_HIP      -3        /* HIP runtime error                 */
 #define KLNMF_ERR_UNSUPP   -4        /* shape not supported by this mode  */
+#define KLNMF_ERR_RCCL     -5        /* an RCCL call failed, or librccl could not be opened */
 
 /* arithmetic modes */
 #define KLNMF_PREC_F64      0        /* fp64 everywhere (reference arithmetic)      */
@@ -146,11 +147,38 @@ int klnmf_iter_update_H(klnmf_ctx *ctx);
 int klnmf_iter_advance(klnmf_ctx *ctx);
 int klnmf_loop_end(klnmf_ctx *ctx, double *errors_out, int64_t *n_done,
                    int *stopped);
+/* ---- Row shards over the GPUs of one node: the native collective path -----------------------------
+ * One process (or thread) per GPU, each with its own context holding n_local rows of V and W; the dictionary is
+ * replicated.  The reference has no counterpart (it is a single process); what is exchanged per fit iteration is
+ * exactly what the algebra needs: the k x f numerator W_new^T.Q of the H rule (nmf.py:349) and the scalar loss
+ * (nmf.py:214), summed over the ranks by ONE grouped RCCL all-reduce on the context's stream (xGMI inside a node).
+ * The W rule and a transform exchange only the loss.  librccl is opened at run time on the first klnmf_comm_* call.
+ *
+ *   rank 0:  klnmf_comm_unique_id(id)  -> send the 128 bytes to every rank (any channel: MPI, a file, torch.distributed)
+ *   each:    klnmf_comm_init(ctx, id, rank, nranks)
+ *            klnmf_comm_max(ctx, &vmax) -> klnmf_set_v_max(ctx, vmax)      (the storage factor must be common)
+ *            uploads, klnmf_set_H (same H on every rank), klnmf_init_W
+ *            klnmf_run_sharded(ctx, n_total, ...)                           (errors / n_done / stopped identical on all ranks)
+ */
+#define KLNMF_COMM_ID_BYTES 128
+int klnmf_comm_unique_id(void *id_out /* KLNMF_COMM_ID_BYTES */);
+int klnmf_comm_init(klnmf_ctx *ctx, const void *id, int rank, int nranks);
+int klnmf_comm_destroy(klnmf_ctx *ctx);
+/* all-reduce(max) of one host double over the communicator (no-op without one) */
+int klnmf_comm_max(klnmf_ctx *ctx, double *value);
+/* klnmf_run over row shards: tol is the RELATIVE tolerance of nmf.py:207 (x n_total x f inside, the global shape).
+ * Without a communicator (or with one of size 1) it is klnmf_run on the local rows. */
+int klnmf_run_sharded(klnmf_ctx *ctx, int64_t n_total, int64_t max_iter, int fit, double tol,
+                      double *errors_out, int64_t *n_done, int *stopped);
+
 /* Device pointers of the two exchange buffers (what the collective sums):
  * loss: 2 doubles; numerator: *numer_count elements of fp32 (BF16 modes, F32)
  * or fp64 (F64).  The buffers are owned by the context. */
 int klnmf_exchange_buffers(klnmf_ctx *ctx, void **loss_ptr, void **numer_ptr,
                            int64_t *numer_count, int *numer_is_f64);
+/* Layout of the numerator buffer: component rows of *row_stride elements, of which the first k rows
+ * (*valid_count elements from the start) carry data -- what a collective has to move; the rest is padding. */
+int klnmf_exchange_layout(klnmf_ctx *ctx, int64_t *row_stride, int64_t *valid_count);
 /* Use caller-owned device buffers as the exchange buffers instead (e.g. torch
  * tensors handed to torch.distributed.all_reduce): loss_ptr >= 2 doubles,
  * numer_ptr >= numer_count elements.  NULL keeps the current buffer. */

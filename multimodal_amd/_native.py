@@ -22,7 +22,8 @@ PRECISIONS = {'f64': PREC_F64, 'fp64': PREC_F64, 'float64': PREC_F64,
 DT_F32, DT_F64 = 0, 1
 STREAM_DEFAULT = (1 << 64) - 1        # KLNMF_STREAM_DEFAULT: (void *)(intptr_t)-1
 
-ERR_ARG, ERR_ALLOC, ERR_HIP, ERR_UNSUPP = -1, -2, -3, -4
+ERR_ARG, ERR_ALLOC, ERR_HIP, ERR_UNSUPP, ERR_RCCL = -1, -2, -3, -4, -5
+COMM_ID_BYTES = 128
 
 _c = ctypes
 _ctx_p = _c.c_void_p
@@ -60,9 +61,16 @@ SIGNATURES = {
     'klnmf_iter_advance': (_c.c_int, [_ctx_p]),
     'klnmf_loop_end': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double), _c.POINTER(_i64),
                                   _c.POINTER(_c.c_int)]),
+    'klnmf_comm_unique_id': (_c.c_int, [_c.c_void_p]),
+    'klnmf_comm_init': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _c.c_int]),
+    'klnmf_comm_destroy': (_c.c_int, [_ctx_p]),
+    'klnmf_comm_max': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double)]),
+    'klnmf_run_sharded': (_c.c_int, [_ctx_p, _i64, _i64, _c.c_int, _c.c_double,
+                                     _c.POINTER(_c.c_double), _c.POINTER(_i64), _c.POINTER(_c.c_int)]),
     'klnmf_exchange_buffers': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_void_p),
                                           _c.POINTER(_c.c_void_p), _c.POINTER(_i64),
                                           _c.POINTER(_c.c_int)]),
+    'klnmf_exchange_layout': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_i64)]),
     'klnmf_bind_exchange': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_void_p]),
     'klnmf_error': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double)]),
     'klnmf_loss_terms': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double)]),
@@ -368,6 +376,35 @@ class Context(object):
                                    ctypes.byref(nd), ctypes.byref(stopped)))
         return [float(e) for e in errs[:nd.value]], nd.value, bool(stopped.value)
 
+    # ---- native collective path (RCCL inside the C-ABI) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        _check(load().klnmf_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def comm_init(self, uid, rank, nranks):
+        assert len(uid) == COMM_ID_BYTES
+        buf = ctypes.create_string_buffer(bytes(uid), COMM_ID_BYTES)
+        _check(self._lib.klnmf_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        _check(self._lib.klnmf_comm_destroy(self._h))
+
+    def comm_max(self, value):
+        v = ctypes.c_double(float(value))
+        _check(self._lib.klnmf_comm_max(self._h, ctypes.byref(v)))
+        return float(v.value)
+
+    def run_sharded(self, n_total, max_iter, fit, tol):
+        errs = (ctypes.c_double * max(1, int(max_iter)))()
+        n_done = _i64(0)
+        stopped = ctypes.c_int(0)
+        _check(self._lib.klnmf_run_sharded(self._h, int(n_total), int(max_iter), 1 if fit else 0, float(tol),
+                                           errs, ctypes.byref(n_done), ctypes.byref(stopped)))
+        nd = int(n_done.value)
+        return [float(errs[i]) for i in range(min(nd, int(max_iter)))], nd, bool(stopped.value)
+
     def loop_begin(self):
         _check(self._lib.klnmf_loop_begin(self._h))
 
@@ -402,6 +439,11 @@ class Context(object):
         _check(self._lib.klnmf_exchange_buffers(self._h, ctypes.byref(lp), ctypes.byref(npt),
                                                 ctypes.byref(cnt), ctypes.byref(is64)))
         return lp.value, npt.value, cnt.value, bool(is64.value)
+
+    def exchange_layout(self):
+        stride, valid = _i64(0), _i64(0)
+        _check(self._lib.klnmf_exchange_layout(self._h, ctypes.byref(stride), ctypes.byref(valid)))
+        return int(stride.value), int(valid.value)
 
     def bind_exchange(self, loss_ptr, numer_ptr):
         _check(self._lib.klnmf_bind_exchange(self._h, _c.c_void_p(loss_ptr),

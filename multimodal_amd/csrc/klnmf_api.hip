@@ -1,6 +1,8 @@
 // C-ABI of the MI355X-native KL-NMF path (see include/klnmf.h for the contract
 // and the reference interfaces each entry point replaces).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>       // types and enums only: the library itself is opened at run time (no link-time dependency)
 
 #include <algorithm>
 #include <cmath>
@@ -71,6 +73,45 @@ int grid_for(int64_t count, int block = 256, int cap = 4096) {
 struct EventPair {
     hipEvent_t a, b;
 };
+
+// RCCL entry points, resolved on first use: a process that never shards needs no librccl.
+struct RcclApi {
+    void *lib = nullptr;
+    std::string err;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) { a.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return a; }
+#define KL_RCCL_SYM(field, sym)                                                        \
+        a.field = (decltype(a.field))dlsym(a.lib, sym);                                \
+        if (!a.field && a.err.empty()) a.err = std::string("librccl lacks ") + sym;
+        KL_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") KL_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+        KL_RCCL_SYM(CommDestroy, "ncclCommDestroy") KL_RCCL_SYM(AllReduce, "ncclAllReduce")
+        KL_RCCL_SYM(GroupStart, "ncclGroupStart") KL_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        KL_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef KL_RCCL_SYM
+        return a;
+    }();
+    if (!api.err.empty()) fail(KLNMF_ERR_RCCL, api.err);
+    return api;
+}
+#define RCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) fail(KLNMF_ERR_RCCL, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
 
 }  // namespace
 
@@ -193,6 +234,11 @@ struct klnmf_ctx {
     bool profiling = false;
     std::vector<EventPair> ev_row, ev_col;
 
+    // row shards over the GPUs of a node (klnmf_comm_*, klnmf_run_sharded): this rank's RCCL communicator
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    double *comm_scratch = nullptr;       // 2 doubles on the device, owned by the communicator (not by a problem)
+
     bool is_exact() const { return prec == KLNMF_PREC_F64 || prec == KLNMF_PREC_F32; }
     // ping-pong row pass (mfma4.hip.h): fp16-stored V; 8-wave workgroups for KT <= 7, 4-wave ones for 10 <= KT <= 16 (even)
     bool pingpong() const { return prec == KLNMF_PREC_BF16 && row_gen == 4 && (KT <= 7 || KT > 8); }
@@ -233,6 +279,11 @@ namespace {
 void use(klnmf_ctx *c) {
     if (!c) fail(KLNMF_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
+}
+void comm_release(klnmf_ctx *c) {
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm_scratch) { (void)hipFree(c->comm_scratch); c->comm_scratch = nullptr; }
+    c->comm_rank = 0; c->comm_size = 1;
 }
 void need_problem(klnmf_ctx *c) {
     use(c);
@@ -960,6 +1011,9 @@ int klnmf_destroy(klnmf_ctx *c) {
         }
 #endif
         c->free_all();
+        if (c->comm || c->comm_scratch) {
+            try { comm_release(c); } catch (...) {}
+        }
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
     });
@@ -1454,6 +1508,90 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
     });
 }
 
+// ---- row shards: the native collective path (RCCL over xGMI) ------------------------------------------------------
+int klnmf_comm_unique_id(void *id) {
+    return guarded([&] {
+        if (!id) fail(KLNMF_ERR_ARG, "null id buffer");
+        static_assert(sizeof(ncclUniqueId) == KLNMF_COMM_ID_BYTES, "ncclUniqueId size");
+        RCCLCHK(rccl().GetUniqueId((ncclUniqueId *)id));
+    });
+}
+
+int klnmf_comm_init(klnmf_ctx *c, const void *id, int rank, int nranks) {
+    return guarded([&] {
+        use(c);
+        if (!id || nranks < 1 || rank < 0 || rank >= nranks) fail(KLNMF_ERR_ARG, "klnmf_comm_init: bad rank / size / id");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        comm_release(c);
+        ncclUniqueId uid;
+        std::memcpy(&uid, id, sizeof(uid));
+        RCCLCHK(rccl().CommInitRank(&c->comm, nranks, uid, rank));
+        c->comm_rank = rank;
+        c->comm_size = nranks;
+        HIPCHK(hipMalloc((void **)&c->comm_scratch, 2 * sizeof(double)));
+    });
+}
+
+int klnmf_comm_destroy(klnmf_ctx *c) {
+    return guarded([&] {
+        use(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        comm_release(c);
+    });
+}
+
+int klnmf_comm_max(klnmf_ctx *c, double *value) {
+    return guarded([&] {
+        use(c);
+        if (!value) fail(KLNMF_ERR_ARG, "null value");
+        if (!c->comm || c->comm_size == 1) return;
+        HIPCHK(hipMemcpyAsync(c->comm_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        RCCLCHK(rccl().AllReduce(c->comm_scratch, c->comm_scratch, 1, ncclDouble, ncclMax, c->comm, c->stream));
+        HIPCHK(hipMemcpyAsync(value, c->comm_scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, double tol, double *errors_out,
+                      int64_t *n_done, int *stopped) {
+    return guarded([&] {
+        need_problem(c);
+        if (max_iter < 0 || max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter out of range");
+        if (n_total < c->n) fail(KLNMF_ERR_ARG, "n_total smaller than this rank's rows");
+        if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_run_sharded: dense problems only");
+        const bool multi = c->comm != nullptr && c->comm_size > 1;
+        check_v_overflow(c);
+        reset_state(c);
+        c->loop_start_cur = c->cur;
+        const double tol_abs = tol * (double)n_total * (double)c->f;          // nmf.py:207 on the GLOBAL shape
+        // what travels: the k real rows of the numerator (the 16-bit modes lay it out [KP][f_pad], rows beyond k are
+        // padding) and the two doubles of the loss -- ONE grouped RCCL launch per iteration, on the context's stream
+        const size_t ncount = c->is_exact() ? (size_t)(c->k * c->f) : (size_t)c->k * (size_t)c->f_pad;
+        void *nbuf = c->is_exact() ? c->numer : (void *)c->numerF;
+        const ncclDataType_t ntype = c->prec == KLNMF_PREC_F64 ? ncclDouble : ncclFloat;
+        for (int64_t it = 0; it < max_iter; ++it) {
+            piece_rowpass(c, fit);                     // leaves this rank's part of the loss in loss_xchg
+            if (fit) piece_colpass(c);                 // ... and of the numerator (it does not depend on the stop decision)
+            if (multi) {
+                RCCLCHK(rccl().GroupStart());
+                if (fit) RCCLCHK(rccl().AllReduce(nbuf, nbuf, ncount, ntype, ncclSum, c->comm, c->stream));
+                RCCLCHK(rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream));
+                RCCLCHK(rccl().GroupEnd());
+            }
+            piece_decide(c, tol_abs);                  // identical inputs on every rank -> identical decisions
+            if (fit) piece_update_H(c);
+            c->cur ^= 1;
+            if (tol_abs > 0 && (it & 15) == 15) {
+                DevState hs{};
+                HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (hs.stop) break;
+            }
+        }
+        fetch_results(c, errors_out, n_done, stopped);
+    });
+}
+
 int klnmf_exchange_buffers(klnmf_ctx *c, void **loss_ptr, void **numer_ptr, int64_t *numer_count,
                            int *numer_is_f64) {
     return guarded([&] {
@@ -1468,6 +1606,15 @@ int klnmf_exchange_buffers(klnmf_ctx *c, void **loss_ptr, void **numer_ptr, int6
             if (numer_count) *numer_count = (int64_t)c->KP * c->f_pad;
             if (numer_is_f64) *numer_is_f64 = 0;
         }
+    });
+}
+
+int klnmf_exchange_layout(klnmf_ctx *c, int64_t *row_stride, int64_t *valid_count) {
+    return guarded([&] {
+        need_problem(c);
+        // numerator buffer: component rows of row_stride elements; only the first k rows (valid_count elements) carry data
+        if (row_stride) *row_stride = c->is_exact() ? c->f : c->f_pad;
+        if (valid_count) *valid_count = c->is_exact() ? c->k * c->f : c->k * c->f_pad;
     });
 }
 

@@ -25,8 +25,15 @@ import numpy as np
 
 def row_partition(n, world_size):
     """Contiguous row ranges [start, stop) per rank; sizes differ by at most 1
-    block of 32 rows (the MFMA row-tile), the last rank takes the remainder."""
+    block of 32 rows (the MFMA row-tile), the last rank takes the remainder.
+
+    Every rank needs at least one 32-row tile: with fewer tiles than ranks this raises ValueError -- on every rank,
+    before any collective (a rank with no rows would fail alone in klnmf_set_problem and leave the others waiting in
+    their first all-reduce)."""
     tiles = (n + 31) // 32
+    if world_size < 1 or tiles < world_size:
+        raise ValueError("cannot shard %d rows (%d tiles of 32) over %d ranks: use at most %d ranks"
+                         % (n, tiles, world_size, max(1, tiles)))
     base, extra = divmod(tiles, world_size)
     bounds = [0]
     for r in range(world_size):
@@ -48,8 +55,8 @@ class ShardedKLNMF(object):
                     current torch device / stream.
     """
 
-    def __init__(self, n_total, n_local, f, k, max_iter, precision='bf16',
-                 group=None, backend=None, device=None):
+    def __init__(self, n_total, n_local, f, k, max_iter, precision='f16',
+                 group=None, backend=None, device=None, collective='torch'):
         import torch
         self.torch = torch
         self.n_total, self.n_local, self.f, self.k = n_total, n_local, f, k
@@ -77,20 +84,29 @@ class ShardedKLNMF(object):
                                    device=self.tensor_device)
         self.loss_t = torch.zeros(2, dtype=torch.float64, device=self.tensor_device)
         self.ctx.bind_exchange(self.loss_t.data_ptr(), self.numer_t.data_ptr())
-        # only the k real component rows travel: the MFMA modes lay the numerator out as [KP][f_pad] with
-        # KP = k rounded up to 32, and the rows beyond k are padding (one of them carries eps)
+        # only the k real component rows travel (the 16-bit modes lay the numerator out as [KP][f_pad]; the rows beyond
+        # k are padding, one of them carries eps): the context says how many elements that is
         valid = count
-        if str(precision).startswith('bf16') and count > 0:
-            kp = 32 * ((k + 31) // 32)
-            if count % kp == 0:
-                valid = k * (count // kp)
+        if hasattr(self.ctx, 'exchange_layout'):
+            _, valid = self.ctx.exchange_layout()
         self.numer_xchg = self.numer_t[:valid]
+        # collective path: 'torch' = torch.distributed all-reduces sequenced here around the C-ABI's pieces;
+        # 'native' = klnmf_run_sharded: ONE grouped RCCL all-reduce per iteration issued inside the C-ABI
+        self.collective = collective
+        if collective == 'native' and self.dist is not None and self.world_size > 1:
+            rank = self.dist.get_rank(group)
+            box = [self.ctx.comm_unique_id() if rank == 0 else None]
+            self.dist.broadcast_object_list(box, src=0, group=group)
+            self.ctx.comm_init(box[0], rank, self.world_size)
         self.iterations_enqueued = 0
 
     # ---- data ----
     def set_v_max(self, local_max):
         """Fix the 16-bit storage factor of V from the GLOBAL maximum (all ranks
         must use the same factor because they share H); call before uploading."""
+        if self.collective == 'native':
+            self.ctx.set_v_max(self.ctx.comm_max(float(local_max)))
+            return
         t = self.torch.tensor([float(local_max)], dtype=self.torch.float64,
                               device=self.tensor_device)
         if self.dist is not None and self.world_size > 1:
@@ -158,6 +174,8 @@ class ShardedKLNMF(object):
 
     def run(self, max_iter=None, fit=True, tol=0.0):
         max_iter = self.max_iter if max_iter is None else int(max_iter)
+        if self.collective == 'native':          # the whole loop, collectives included, in one C-ABI call
+            return self.ctx.run_sharded(self.n_total, max_iter, fit, tol)
         self.begin()
         for _ in range(max_iter):
             self.iterate(fit=fit, tol=tol)
@@ -175,9 +193,16 @@ class ShardedKLNMF(object):
         W = self.get_W_local(dtype=dtype)
         if self.dist is None or self.world_size == 1:
             return W
-        parts = [None] * self.world_size
-        self.dist.all_gather_object(parts, W, group=self.group)
-        return np.vstack(parts)
+        # one all-gather of equally sized (padded) blocks instead of pickled objects
+        torch = self.torch
+        sizes = [b - a for a, b in row_partition(self.n_total, self.world_size)]
+        pad = max(sizes)
+        mine = torch.zeros((pad, W.shape[1]), dtype=torch.float64 if np.dtype(dtype) == np.float64 else torch.float32,
+                           device=self.tensor_device)
+        mine[:W.shape[0]] = torch.from_numpy(np.ascontiguousarray(W)).to(self.tensor_device)
+        parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        return np.vstack([p[:s].cpu().numpy() for p, s in zip(parts, sizes)])
 
     def close(self):
         self.ctx.close()

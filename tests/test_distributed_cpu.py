@@ -106,7 +106,8 @@ def test_row_partition():
     sizes = [b - a for a, b in parts]
     assert max(sizes) - min(sizes) <= 32 and all(s % 32 == 0 for s in sizes[:-1])
     assert row_partition(37, 2) == [(0, 32), (32, 37)]
-    assert sum(b - a for a, b in row_partition(5, 4)) == 5
+    with pytest.raises(ValueError):          # one 32-row tile cannot feed four ranks (a rank with no rows would hang the others)
+        row_partition(5, 4)
 
 
 def _free_port():
@@ -161,3 +162,33 @@ def test_sharded_equals_single_process(tmp_path, iters, tol, fit):
     np.testing.assert_array_equal(res[0]['H'], res[1]['H'])      # replicas stay bit-identical
     if tol > 0:
         assert bool(res[0]['stopped']) and len(eo) < iters
+
+
+def _tiny_worker(rank, world, port, n, out_dir):
+    """Every rank must fail the same way BEFORE any collective when there are fewer 32-row tiles than ranks."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        try:
+            row_partition(n, world)
+            msg = 'no error'
+        except ValueError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, 'r%d.txt' % rank), 'w') as fh:
+            fh.write(msg)
+        dist.barrier()                       # and nobody is left waiting in a collective
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fewer_row_tiles_than_ranks_is_refused_on_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    assert [b - a for a, b in row_partition(100, 3)] == [64, 32, 4]      # 4 tiles of 32 rows over 3 ranks, the last one ragged
+    with pytest.raises(ValueError):
+        row_partition(100, 8)                # 4 tiles of 32 rows for 8 ranks (ADVICE round 1: ranks with no rows)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_tiny_worker, args=(2, port, 20, str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
+    assert msgs[0] == msgs[1] and 'cannot shard 20 rows' in msgs[0]

@@ -213,5 +213,5 @@ def test_lean_cpu_iteration_is_the_same_iteration():
 def test_bench_defaults_follow_the_measurement_contract():
     import bench
     a = bench.parse_args([])
-    assert (a.gpus, a.n, a.f, a.k, a.precision) == (1, 1000000, 4096, 200, 'bf16')      # BASELINE.json configs[3]
+    assert (a.gpus, a.n, a.f, a.k, a.precision) == (1, 1000000, 4096, 200, 'f16')       # BASELINE.json configs[3]
     assert a.tol == 0.0 and a.repeats == 5 and a.cpu_rows == 100000 and a.data == 'blocks'
