@@ -80,6 +80,10 @@ int klnmf_set_problem(klnmf_ctx *ctx, int64_t n, int64_t f, int64_t k,
  * blocks (and all ranks: the factor must be common) before the first upload.
  * Without it c = 1 (fine for data in fp16's range).  No-op in the other modes. */
 int klnmf_set_v_max(klnmf_ctx *ctx, double vmax);
+/* Give the problem's device memory back (to the library's block cache) and keep the context -- its stream, its
+ * communicator -- for a later klnmf_set_problem.  Hosts that run many short fits in sequence (experiment.py:158-180)
+ * keep a few contexts alive this way instead of creating one per fit. */
+int klnmf_release_problem(klnmf_ctx *ctx);
 /* Forget the uploaded matrix: zero V and the sums the upload kernels accumulate (sum of V as stored, the
  * storage-rounding correction of the loss, the count of values beyond the announced maximum), so that the same
  * context can take another matrix of the same shape; klnmf_set_v_max may be called again afterwards.  (Uploading

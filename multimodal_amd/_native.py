@@ -38,6 +38,7 @@ SIGNATURES = {
     'klnmf_create': (_c.c_int, [_c.POINTER(_ctx_p), _c.c_int, _c.c_int, _c.c_void_p]),
     'klnmf_destroy': (_c.c_int, [_ctx_p]),
     'klnmf_set_problem': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64]),
+    'klnmf_release_problem': (_c.c_int, [_ctx_p]),
     'klnmf_set_v_max': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_reset_V': (_c.c_int, [_ctx_p]),
     'klnmf_upload_V': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64, _i64, _i64,
@@ -216,12 +217,28 @@ def selftest(device=0):
 class Context(object):
     """One GPU-resident KL-NMF problem (V, W, H on the device)."""
 
-    def __init__(self, precision='f64', device=0, stream=None):
+    # Handles of closed `pooled` contexts, per (precision, device): experiment.py runs hundreds of short fits and
+    # transforms in sequence (experiment.py:158-180, 235-238), each through its own KLdivNMF object; creating and
+    # destroying a native context (a HIP stream, ~25 device blocks) per call cost as much as a small transform itself.
+    # A pooled context is handed back with its problem released (klnmf_release_problem: device blocks to the block
+    # cache); the stream and the handle live on.
+    _pool = {}
+    _POOL_MAX = 4
+
+    def __init__(self, precision='f64', device=0, stream=None, pooled=False):
         self._lib = load()
         self._h = _ctx_p()
         if isinstance(precision, str):
             precision = PRECISIONS[precision]
         self.precision = precision
+        self.n = self.f = self.k = 0
+        self.cap = 0
+        self._pool_key = (precision, int(device)) if (pooled and stream is None) else None
+        if self._pool_key is not None:
+            free = Context._pool.get(self._pool_key)
+            if free:
+                self._h = free.pop()
+                return
         # stream: None -> the context creates its own stream; an integer hipStream_t handle otherwise, where
         # 0 is the device's default (null) stream -- torch's current stream unless the caller switched --
         # and is passed as KLNMF_STREAM_DEFAULT, because the C-ABI reads NULL as "no stream given".
@@ -232,13 +249,16 @@ class Context(object):
         else:
             handle = _c.c_void_p(int(stream))
         _check(self._lib.klnmf_create(ctypes.byref(self._h), device, precision, handle))
-        self.n = self.f = self.k = 0
-        self.cap = 0
 
     # -- lifetime --
     def close(self):
         if getattr(self, '_h', None) and self._h.value:
-            self._lib.klnmf_destroy(self._h)
+            key = getattr(self, '_pool_key', None)
+            free = Context._pool.setdefault(key, []) if key is not None else None
+            if free is not None and len(free) < Context._POOL_MAX and self._lib.klnmf_release_problem(self._h) == 0:
+                free.append(self._h)
+            else:
+                self._lib.klnmf_destroy(self._h)
             self._h = _ctx_p()
 
     def __del__(self):

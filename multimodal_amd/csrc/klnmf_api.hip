@@ -1035,6 +1035,8 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = false;
+        c->v_uploaded = false;
+        c->v_scale = 1.0;
         c->nnz = 0;
         c->st = (DevState *)c->dalloc(sizeof(DevState));
         c->errors = (double *)c->dalloc(sizeof(double) * (cap > 0 ? cap : 1));
@@ -1176,6 +1178,17 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
     });
 }
 
+int klnmf_release_problem(klnmf_ctx *c) {
+    return guarded([&] {
+        use(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->free_all();              // device blocks back to the per-process cache (large ones to the driver)
+        c->profiling = false;
+        c->images_measured = false;
+        c->ratio_eps = kEpsRatio;
+    });
+}
+
 int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap, int64_t nnz) {
     return guarded([&] {
         use(c);
@@ -1189,6 +1202,8 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = true;
+        c->v_uploaded = false;
+        c->v_scale = 1.0;
         c->nnz = nnz;
         const size_t es = c->esize();
         c->st = (DevState *)c->dalloc(sizeof(DevState));
@@ -1477,8 +1492,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         // iteration IS its kernel latencies: 7 launches of 4-10 us each).  Summing the column pass's slabs inside the
         // H rule as well (from_slabs) was measured and is NOT used: its k blocks walk the slabs serially, 47 -> 68 us.
         const bool fused = !c->is_exact();
-        const bool slabs = false;
-        for (int64_t it = 0; it < max_iter; ++it) {
+        auto one_iteration = [&] {
             if (fused) {
                 piece_rowpass(c, fit, &tol_abs);
             } else {
@@ -1486,23 +1500,61 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
                 piece_decide(c, tol_abs);
             }
             if (fit) {
-                if (slabs) {
-                    fast_colpass_q(c, false);
-                    fast_pack_H(c, 1, true);
-                } else {
-                    piece_colpass(c);
-                    piece_update_H(c);
-                }
+                piece_colpass(c);
+                piece_update_H(c);
             }
             c->cur ^= 1;
-            if (tol_abs > 0 && (it & 15) == 15) {
-                // the stop rule may already have fired: look, so that the remaining
-                // (no-op) iterations need not be enqueued
-                DevState hs{};
-                HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (hs.stop) break;
+        };
+        auto stopped_already = [&]() -> bool {        // the stop rule may have fired: the remaining (no-op) iterations need not be enqueued
+            DevState hs{};
+            HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return hs.stop != 0;
+        };
+        // Launch-bound problems (the reference's own data: 10^2..10^4 rows, 4-7 kernels of a few microseconds per
+        // iteration): two consecutive iterations -- both positions of the W ping-pong -- captured once into a hipGraph
+        // and replayed.  The first two iterations run eagerly (they may carry the measured image scales of W0 and the
+        // re-pack that follows them).  KLNMF_GRAPH=0 turns it off, =1 forces it for any size.
+        int64_t it = 0;
+        const char *genv = std::getenv("KLNMF_GRAPH");
+        // Measured (scripts/small_problem_timing.py, 200 x 450 .. 10 000 x 4096): 29.5 us per iteration replayed against
+        // 28.3 eager -- the iteration is the kernels' own few microseconds and their dependent boundaries, which a graph
+        // keeps (MI355X_MICROARCH.md: "dependent kernel boundary ... eager = hipGraph"), not host launch cost.  Off unless asked for.
+        const bool want_graph = c->stream != nullptr && !c->profiling && max_iter >= 12 && genv && std::atoi(genv) != 0;
+        if (want_graph) {
+            for (; it < 2; ++it) one_iteration();
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            const int cur_before = c->cur;
+            hipError_t ge = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+            if (ge == hipSuccess) {
+                try {
+                    one_iteration();
+                    one_iteration();
+                } catch (...) {
+                    (void)hipStreamEndCapture(c->stream, &graph);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    throw;
+                }
+                ge = hipStreamEndCapture(c->stream, &graph);
+                if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             }
+            c->cur = cur_before;                       // nothing has run yet: the capture only recorded the launches
+            if (ge == hipSuccess && exec) {
+                int64_t replays = 0;
+                for (; it + 2 <= max_iter; it += 2) {
+                    HIPCHK(hipGraphLaunch(exec, c->stream));
+                    if (tol_abs > 0 && (++replays & 7) == 0 && stopped_already()) { it = max_iter; break; }
+                }
+            } else {
+                (void)hipGetLastError();               // capture not available here: the eager loop below does the work
+            }
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        for (; it < max_iter; ++it) {
+            one_iteration();
+            if (tol_abs > 0 && (it & 15) == 15 && stopped_already()) break;
         }
         fetch_results(c, errors_out, n_done, stopped);
     });

@@ -23,11 +23,13 @@ class DeviceDataset(object):
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.blocks = []
         self.maxima = []
+        self.host = []           # the caller's matrices (for comparisons on the raw data, experiment.py:266: no transformation)
         for m in data_matrices:
             m = atleast2d_or_csr(m)
             check_non_negative(m, "NMF.fit")
             if hasattr(m, 'toarray'):
                 m = m.toarray()
+            self.host.append(np.asarray(m))
             t = torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(self.device)
             self.blocks.append(t)
             self.maxima.append(float(t.max().item()) if t.numel() else 0.0)
@@ -52,14 +54,21 @@ class DeviceDataset(object):
         return upload, idx.numel()
 
     # ---- what experiment.py:_perform_one_run does with the sliced copies ----
-    def train(self, learner, rows, iterations):
-        """learner.train([x[rows] for x in data], iterations) (learner.py:31-41) without the host slices."""
+    def rows_of(self, which, rows):
+        """Host rows of modality `which` as the caller gave them (what experiment.py compares raw data with)."""
+        return self.host[which][np.asarray(rows, dtype=np.int64), :]
+
+    def train(self, learner, rows, iterations, init_dictionary=None):
+        """learner.train([x[rows] for x in data], iterations) (learner.py:31-41) without the host slices.
+        `init_dictionary`: the initial dictionary instead of a draw from the global numpy stream (nmf.py:149-155)."""
         if learner.sparseness is not None:
             raise NotImplemented
         which = list(range(len(self.blocks)))
         assert [b.shape[1] for b in self.blocks] == list(learner.dim)
         upload, n = self._uploader(which, rows, list(learner.coef))
         nmf = KLdivNMF(n_components=learner.k, max_iter=iterations, tol=0)
+        if init_dictionary is not None:
+            nmf._init_dictionary = np.asarray(init_dictionary)
         nmf._fit_uploaded(n, sum(learner.dim), upload, lambda H: np.float64, _fit=True)
         learner.nmf_train = nmf
         learner.dico = nmf.components_

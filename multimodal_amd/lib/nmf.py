@@ -134,12 +134,12 @@ class KLdivNMF(object):
         prec = self.precision
         if exact and _native.PRECISIONS[prec] not in (_native.PREC_F64, _native.PREC_F32):
             prec = 'f64'
-        return _native.Context(precision=prec, device=self.device)
+        return _native.Context(precision=prec, device=self.device, pooled=True)
 
     @classmethod
     def _exact_context(cls):
         return _native.Context(precision=os.environ.get('KLNMF_STEP_PRECISION', 'f64'),
-                               device=_default_device())
+                               device=_default_device(), pooled=True)
 
     def _init_H(self, n_features):
         """Initial dictionary (reference nmf.py:149-155)."""

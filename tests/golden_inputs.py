@@ -101,3 +101,20 @@ def synthetic_problem(seed, n, f, k, block=8192):
         X[r0:r1] = Wt.dot(Ht) / k + 0.05 * rs.random_sample((r1 - r0, f))
     H0 = _normalize_rows(np.random.RandomState(seed - 1).random_sample((k, f)) + .01)
     return X, H0
+
+
+def experiment_modalities(seed, n_per_label=14, n_labels=10, dims=(48, 30)):
+    """Two dense non-negative modalities with class structure (fixture G13, tests/golden/make_golden_experiment.py):
+    a sample of label l is its label's template plus noise, histogram-like (rows of the first modality sum to 1 as the
+    motion histograms do, Appendix B of SURVEY.md).  Labels 0..9, listed in a shuffled order per modality."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for d in dims:
+        templates = rs.gamma(0.4, 1.0, (n_labels, d)) + 0.02
+        labels = np.repeat(np.arange(n_labels), n_per_label)
+        rs.shuffle(labels)
+        X = templates[labels] * (0.6 + 0.8 * rs.random_sample((labels.size, d))) + 0.05 * rs.random_sample((labels.size, d))
+        out.append((X, [int(v) for v in labels]))
+    Xa, la = out[0]
+    out[0] = (Xa / Xa.sum(axis=1, keepdims=True), la)
+    return out
