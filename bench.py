@@ -328,7 +328,7 @@ def main():
         pingpong = (fast16 and (k <= 224 or 256 < k <= 512)
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
-        qbytes = _native.ratio_tile_bytes() if stored_q else 0
+        qbytes = _native.ratio_tile_bytes(n_local, k) if stored_q else 0
         # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures
         flops_row = 4.0 * n_local * f * k
         alg_bytes_row = n_local * f * vbytes + 2 * n_local * k * 4

@@ -31,7 +31,8 @@
 namespace klnmf {
 
 __host__ __device__ constexpr int colq_w_area(int kp) { return round_up(32 * w_ld(kp) * 2, kGldsRound); }
-__host__ __device__ constexpr int colq_obj_bytes(int kp, int ksplit) { return colq_w_area(kp) + kWavesPerWG / ksplit * kQTile; }
+__host__ __device__ constexpr int colq_obj_bytes(int kp, int ksplit, int qtile = kQTile) { return colq_w_area(kp) + kWavesPerWG / ksplit * qtile; }
+constexpr int kQTile8 = 1024;                    // bytes of one 32 x 32 fp8 ratio tile (mfma4.hip.h, Q8)
 #ifndef KL_COLQ_NB
 #define KL_COLQ_NB 4
 #endif
@@ -40,9 +41,16 @@ __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
 }
 
-template <int KT, int NB, int KSPLIT = 1>
+// Q8: fp8 ratio tiles (1 KiB, row-major with the row pass's column permutation).  The tile is copied linearly (one piece
+// per wave and stage instead of two); ds_read_b64_tr_b8 hands lane l the 8 rows 16 s + 8 h .. + 7 of PHYSICAL column l & 31
+// (probed: experiments/micro/fp8_probe.hip), four v_cvt_scalef32_pk_f16_fp8 make the B operand of k-step s, the W_new
+// fragments are read in the same row order (8 h + t, 8 h + 4 + t), and the accumulator of lane l belongs to the LOGICAL
+// column 8 g + 4 h' + t of its physical column 16 h' + 4 g + t.
+template <int KT, int NB, int KSPLIT = 1, int Q8 = 0>
 __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     static_assert(kWavesPerWG == 8 && (KSPLIT == 1 || KSPLIT == 2) && KT % KSPLIT == 0, "wave decomposition");
+    static_assert(Q8 == 0 || (KSPLIT == 1 && sizeof(opnd_t) == 2), "fp8 ratio tiles: one wave per column tile");
+    constexpr int QTB = Q8 ? kQTile8 : kQTile;      // bytes of a ratio tile
     constexpr int CTW = kWavesPerWG / KSPLIT;      // column tiles per workgroup
     constexpr int KTW = KT / KSPLIT;               // accumulator blocks per wave
     constexpr int KP = 32 * KT;
@@ -50,8 +58,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     constexpr int WLDB = WLD * 2;
     constexpr int WST = 32 * WLDB;                 // bytes of W_new per 32-row stage in global memory
     constexpr int WA = colq_w_area(KP);            // copied per stage (whole rounds)
-    constexpr int OBJ = colq_obj_bytes(KP, KSPLIT);
-    constexpr int QP = 2 / KSPLIT;                 // 1 KiB pieces of its column tile's ratio tile a wave copies
+    constexpr int OBJ = colq_obj_bytes(KP, KSPLIT, QTB);
+    constexpr int QP = Q8 ? 1 : 2 / KSPLIT;        // 1 KiB pieces of its column tile's ratio tile a wave copies
     constexpr int OPS = WA / kGldsRound + QP;      // copy instructions per wave and stage
     constexpr int N3 = 2 * KTW;
     static_assert(NB >= 3 && NB <= 5 && NB * OBJ <= 160 * 1024, "LDS budget");
@@ -86,10 +94,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
 
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
     //  W_new (A operand): rows = samples 4h+tq (+8 for the second read), cols = components
-    const unsigned off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp) + 64 * KTW * kh;
-    const unsigned off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp) + 64 * KTW * kh;
+    const int ra0 = Q8 ? 8 * h + tq : 4 * h + tq, ra1 = Q8 ? 8 * h + tq + 4 : 4 * h + tq + 8;      // rows of the two A reads
+    const unsigned off_tr0 = ra0 * WLDB + 2 * wb_col(ra0, 16 * half + 4 * tp) + 64 * KTW * kh;
+    const unsigned off_tr1 = ra1 * WLDB + 2 * wb_col(ra1, 16 * half + 4 * tp) + 64 * KTW * kh;
     //  ratios (B operand): row 4h+tq (+8j), columns 16*half + 4*tp.. = slot 2*row + (tp&1), group 2*half + (tp>>1)
-    const unsigned off_q = WA + ctl * kQTile + (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8;
+    //  Q8: lane 2q + p of a 16-lane group addresses row 8h + q, physical columns 16*half + 8p .. + 7 of the row-major tile
+    const unsigned off_q = Q8 ? WA + ctl * QTB + (8 * h + (i16 >> 1)) * 32 + 16 * half + 8 * (i16 & 1)
+                              : WA + ctl * QTB + (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8;
 
     f32x16 acc[KTW];
 #pragma unroll
@@ -99,8 +110,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
 
     const unsigned char *wn = (const unsigned char *)a.Wb_new;
     // copy piece P = 64p + lane of a tile (16 bytes at LDS offset 16P): slot P>>1, operand P&1
-    const unsigned char *qt = a.Qt + (int64_t)ct * a.nrt * kQTile + (lane & 1) * 1024 +
-                              ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+    const unsigned char *qt = Q8 ? a.Qt + (int64_t)ct * a.nrt * QTB + lane * 16
+                                 : a.Qt + (int64_t)ct * a.nrt * QTB + (lane & 1) * 1024 + ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
 
     auto obj = [&](int o) -> KL_LDS unsigned char * {      // o static after unrolling
         return (KL_LDS unsigned char *)(o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o == 3 ? o3 : o4);
@@ -109,21 +120,27 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     auto stage_in = [&](int o, int sg) {
         sg = min(sg, send - 1);                    // past the end: re-copy the last stage (uniform instruction count)
         glds_copy_exact<WA, kWavesPerWG>(wn + (int64_t)sg * WST, obj(o), tid);
-        const unsigned char *qs = qt + (int64_t)sg * kQTile;
+        const unsigned char *qs = qt + (int64_t)sg * QTB;
 #pragma unroll
         for (int pp = 0; pp < QP; ++pp) {
             const int p = kh * QP + pp;            // KSPLIT = 2: the two waves of a column tile copy one piece each
             __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + p * 256),
-                                             (KL_LDS void *)(obj(o) + WA + ctl * kQTile + 1024 * p), 16, 0, 0);
+                                             (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
         }
     };
     auto compute = [&](unsigned base) {
         opx8 ring[3];
         s16x4 q0, q1, q2, q3;
-        lds_read_tr(q0, base + off_q);
-        lds_read_tr(q1, base + off_q + 8 * 64);
-        lds_read_tr(q2, base + off_q + 16 * 64);
-        lds_read_tr(q3, base + off_q + 24 * 64);
+        if constexpr (Q8 != 0) {                   // q0 / q2: the 8 fp8 values of k-step 0 / 1 (two dwords each)
+            asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(q0) : "v"(base + off_q));
+            asm volatile("ds_read_b64_tr_b8 %0, %1 offset:512" : "=v"(q2) : "v"(base + off_q));
+            q1 = q0; q3 = q2;
+        } else {
+            lds_read_tr(q0, base + off_q);
+            lds_read_tr(q1, base + off_q + 8 * 64);
+            lds_read_tr(q2, base + off_q + 16 * 64);
+            lds_read_tr(q3, base + off_q + 24 * 64);
+        }
         const unsigned t0 = base + off_tr0, t1 = base + off_tr1;
         auto fetch = [&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -133,9 +150,24 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         fetch(std::integral_constant<int, 1>{});
         // the ratio reads are older than every W_new read: they have landed when fragment 0 has
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(ring[0]));
-        // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
-        const opx8 b0 = __builtin_bit_cast(opx8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
-        const opx8 b1 = __builtin_bit_cast(opx8, __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7));
+        opx8 b0, b1;
+        if constexpr (Q8 != 0) {
+#ifndef KL_OPND_BF16
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+            const u32x2 w0 = __builtin_bit_cast(u32x2, q0), w1 = __builtin_bit_cast(u32x2, q2);
+            // rows 8h + 2j, 8h + 2j + 1 of k-step 0 (b0) and of k-step 1 (b1); the byte-pair selector must be a literal
+#define KL_Q8_PAIR(dst, src, j, sel)                                                              \
+            { const f16x2 p_ = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, 1.0f, sel); dst[2 * (j)] = p_[0]; dst[2 * (j) + 1] = p_[1]; }
+            KL_Q8_PAIR(b0, w0[0], 0, false) KL_Q8_PAIR(b0, w0[0], 1, true) KL_Q8_PAIR(b0, w0[1], 2, false) KL_Q8_PAIR(b0, w0[1], 3, true)
+            KL_Q8_PAIR(b1, w1[0], 0, false) KL_Q8_PAIR(b1, w1[0], 1, true) KL_Q8_PAIR(b1, w1[1], 2, false) KL_Q8_PAIR(b1, w1[1], 3, true)
+#undef KL_Q8_PAIR
+#endif
+        } else {
+            // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
+            b0 = __builtin_bit_cast(opx8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
+            b1 = __builtin_bit_cast(opx8, __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
         static_for<0, N3>([&](auto J) {
             constexpr int j = decltype(J)::value;
             fetch(std::integral_constant<int, j + 2>{});
@@ -166,8 +198,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS copy may outlive the workgroup
 
     if (!active) return;
-    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
-    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r (Q8: the logical column of physical column r)
+    const int rcol = Q8 ? 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3) : r;
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + rcol;
 #pragma unroll
     for (int m = 0; m < KTW; ++m)
 #pragma unroll

@@ -210,6 +210,7 @@ struct klnmf_ctx {
     void *VtA = nullptr, *VtB = nullptr;
     unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
     int col_gen = 2;
+    bool q8 = false;             // the ratio tiles are fp8 (1 B per element of V) instead of the 16-bit operands: large row counts
     float *W32[2] = {nullptr, nullptr};
     opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
@@ -240,6 +241,7 @@ struct klnmf_ctx {
     double *comm_scratch = nullptr;       // 2 doubles on the device, owned by the communicator (not by a problem)
 
     bool is_exact() const { return prec == KLNMF_PREC_F64 || prec == KLNMF_PREC_F32; }
+    static bool row_chunks_possible_q8(int64_t n) { return n >= 65536; }      // (below that the column-split update pass runs)
     // ping-pong row pass (mfma4.hip.h): fp16-stored V; 8-wave workgroups for KT <= 7, 4-wave ones for 10 <= KT <= 16 (even)
     bool pingpong() const { return prec == KLNMF_PREC_BF16 && row_gen == 4 && (KT <= 7 || KT > 8); }
     size_t esize() const { return prec == KLNMF_PREC_F64 ? 8 : 4; }
@@ -342,6 +344,18 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
                 } else {                                                                                        \
                     if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
                     else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                }                                                                                               \
+                break;                                                                                          \
+            }                                                                                                   \
+        }                                                                                                       \
+        if constexpr (MODE == ROW_UPDATE) {                                                                     \
+            if (c->q8 && a.base.Qt) {     /* fp8 ratio tiles for the column pass */                             \
+                if (ep) {                                                                                       \
+                    if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                    else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                } else {                                                                                        \
+                    if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                    else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
                 }                                                                                               \
                 break;                                                                                          \
             }                                                                                                   \
@@ -482,7 +496,8 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     if (c->profiling) ev = begin_event(c, c->ev_col);
 #define KL_COLQ_CASE(KTV)                                                                                          \
     case KTV:                                                                                                      \
-        if (c->col_gen == 3) hipLaunchKernelGGL((k_colpass_q<KTV>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        if (c->q8) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        else if (c->col_gen == 3) hipLaunchKernelGGL((k_colpass_q<KTV>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
         else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
         break;
     switch (c->KT) {
@@ -1108,9 +1123,14 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // column pass on the ratios the ping-pong row pass stores (k_colpass_q) where that row pass runs;
             // otherwise the recomputing one, which needs the second, column-tiled copy of V
             const bool stored_q = c->pingpong() && (c->col_gen >= 2 || c->KT > 8);
+            // fp8 ratio tiles: only the H numerator -- a sum over all rows -- sees their 4-bit significands; its relative
+            // error falls like 0.036 sqrt(2 / n) (5e-5 at 1M rows, 2e-4 at 65 536: below the operands' own rounding), so
+            // they are used from 65 536 rows per context on (KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
+            c->q8 = stored_q && c->KT <= 7 && c->col_gen == 2 && c->row_chunks_possible_q8(n);
+            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8 = stored_q && c->KT <= 7 && c->col_gen == 2 && std::atoi(g) == 8;
             c->VtA = c->dalloc(vbytes);
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
-            c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;
+            c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * (c->q8 ? kQTile8 : kQTile)) : nullptr;
             for (int i = 0; i < 2; ++i) {
                 c->W32[i] = (float *)c->dalloc((size_t)c->n_pad * c->KP * 4);
                 c->Wb[i] = (opnd_t *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
@@ -1157,7 +1177,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
             c->row_chunks = 1;
             c->row_ct_chunk = c->nct;
-            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8) {
+            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8 && !c->q8) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 int want = (2 * nwg <= c->cu_count) ? c->cu_count / nwg : 1;
                 if (const char *g = std::getenv("KLNMF_ROW_SPLIT")) want = std::max(1, std::atoi(g));

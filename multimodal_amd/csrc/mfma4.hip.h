@@ -157,7 +157,11 @@ __device__ __forceinline__ void lds_wait(opx8 &v) {
 // the whole 512-register file -- accumulators in AGPRs -- for 8 <= KT <= 16, i.e. k <= 512: every wave then runs the X
 // order alone on its SIMD, matrix and epilogue segments in sequence; with 2*KT + KS >= 48 matrix instructions per tile
 // the epilogue is the smaller part).
-template <int KT, int ODD, int MODE, int EP = 0, int NW = kWaves4, int SPLIT = 0>
+// Q8: the ratio tiles left for the column pass are fp8 (e4m3, saturating) instead of the 16-bit MFMA operands: 1 KiB per
+// 32 x 32 tile, row-major [row i][16 h' + 4 g + t] = column 8 g + 4 h' + t -- each lane's 16 values are 16 contiguous
+// bytes at 16 (2 i + h'), one store per lane and tile.  Only the H numerator (a sum over ALL rows) sees these 4-bit
+// significands; the W rule and the loss use the ratio as it stands in the registers (colq.hip.h).
+template <int KT, int ODD, int MODE, int EP = 0, int NW = kWaves4, int SPLIT = 0, int Q8 = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4Args aa) {
     constexpr int kWaves4 = NW, kThreads4 = 64 * NW;
     const RowPassArgs &a = aa.base;
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // SPLIT is a template parameter, not a runtime flag: the whole-row instantiation must stay the instruction stream it
     // was (a runtime branch cost 2 % at the headline shape and spilled at KT = 16)
     static_assert(SPLIT == 0 || (NW == 8 && MODE == ROW_UPDATE), "column-split pass: 8-wave update kernels only");
+    static_assert(Q8 == 0 || (NW == 8 && MODE == ROW_UPDATE && SPLIT == 0 && sizeof(opnd_t) == 2), "fp8 ratio tiles: whole-row 8-wave update kernels");
     constexpr bool split = SPLIT != 0;
     const int ct0 = split ? (int)blockIdx.y * a.ct_chunk : 0;
     const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
@@ -262,8 +267,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     };
     const unsigned char *vlane = vt + lane * 32;             // this lane's 32 bytes of a V tile
     // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
-    unsigned char *qlane = (a.Qt && active) ? a.Qt + (int64_t)rt * 2048 + lane * 16 : nullptr;
-    const int64_t qstride = (int64_t)a.nrt * 2048;
+    unsigned char *qlane = (a.Qt && active) ? (Q8 ? a.Qt + (int64_t)rt * 1024 + (2 * (lane & 31) + (lane >> 5)) * 16
+                                                  : a.Qt + (int64_t)rt * 2048 + lane * 16) : nullptr;
+    const int64_t qstride = (int64_t)a.nrt * (Q8 ? 1024 : 2048);
     f16x8 vreg[4];                                           // V tiles of even / odd column tiles (2 x 16 B each)
     // segment boundary: nothing may be scheduled across it (the MFMAs of an M segment must not sink into the
     // following E segment and vice versa -- that is the whole point of the schedule)
@@ -360,6 +366,25 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
             unsigned char *qp = qlane + (int64_t)tg * qstride;
 #endif
+            if constexpr (Q8 != 0) {
+#ifndef KL_OPND_BF16
+                // from the packed halves (the fp32 ratios are gone by the time the tile leaves): 8 conversions, 2 values each
+                typedef __attribute__((ext_vector_type(2))) short s16x2;
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+                u32x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const opx8 &src = j < 2 ? b0 : b1;
+                    const int o = 4 * (j & 1);
+                    s16x2 w = {0, 0};
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, 1.0f, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, 1.0f, true);
+                    pk[j] = __builtin_bit_cast(unsigned, w);
+                }
+                __builtin_nontemporal_store(pk, (u32x4 *)qp);
+#endif
+                return;
+            }
 #ifdef KL_ABL_QPLAIN       // experiment: ordinary stores instead of non-temporal ones
             *(opx8 *)qp = b0;
             *(opx8 *)(qp + 1024) = b1;

@@ -11,11 +11,11 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc
 scripts/bench_configs.sh $TAG/configs > $O/configs.txt 2>&1; cat $O/configs.txt
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c4 -o c4 -- python3 $R/bench.py --no-cpu-baseline > $O/kt_c4.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5s -o c5s -- python3 $R/bench.py --no-cpu-baseline --n 250000 --f 12288 --k 500 --steps 10 --warmup 2 > $O/kt_c5s.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5s -o c5s -- python3 $R/bench.py --no-cpu-baseline --data device --repeats 2 --n 250000 --f 12288 --k 500 --steps 10 --warmup 2 > $O/kt_c5s.log 2>&1
 cd $R
 rm -f $(find $O -name "*kernel_trace.csv") $(find $O -name "*agent_info.csv")
 for f in $O/kt_c4/c4_kernel_stats.csv $O/kt_c5s/c5s_kernel_stats.csv; do echo $f; grep klnmf $f | cut -c1-150 | head -8; done
 scripts/pmc_profile.sh $TAG/pmc_c4 > $O/pmc_c4.txt 2>&1
-scripts/pmc_profile.sh $TAG/pmc_c5s --n 250000 --f 12288 --k 500 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_c5s.txt 2>&1
+scripts/pmc_profile.sh $TAG/pmc_c5s --n 250000 --f 12288 --k 500 --steps 3 --warmup 1 --repeats 1 --data device --no-cpu-baseline > $O/pmc_c5s.txt 2>&1
 rm -f $(find $O -name "*kernel_trace.csv") $(find $O -name "*agent_info.csv") $(find $O -name "*counter_collection.csv")
 tail -3 $O/pmc_c4.txt; tail -3 $O/pmc_c5s.txt

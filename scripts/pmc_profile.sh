@@ -4,7 +4,7 @@
 # kernel trace), one pass per counter group; summaries land in gpurun_out/$TAG.
 TAG=${1:-pmc}
 shift
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 3 --warmup 1 --repeats 1 --data device --no-cpu-baseline}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -487,6 +487,41 @@ def test_rowpass_generations_agree_small_k(monkeypatch, n, f, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k', [(2048, 256, 40), (1000, 300, 17), (3000, 520, 200), (4096, 640, 208), (70000, 512, 200)])
+def test_fp8_ratio_tiles_agree_with_16_bit_tiles(monkeypatch, n, f, k):
+    """From 65 536 rows per context on the row pass leaves the ratios for the H rule as fp8 (1 KiB tiles: half the bytes
+    written and read); only the H numerator -- a sum over all rows -- sees their 4-bit significands.  Forced here at any
+    size (KLNMF_QTILE): same losses and factors as with the 16-bit tiles up to that rounding, which falls with sqrt(n):
+    measured H 6e-4 of its maximum at 2 100 rows, 2e-4 at 70 000; W 1e-5; losses 6e-5 / 8e-6."""
+    X = orc.synthetic_V(13, n, f, k)
+    H0 = orc.synthetic_H0(13, f, k)
+    out = {}
+    for q in ('16', '8'):
+        monkeypatch.setenv('KLNMF_QTILE', q)
+        m, W, errors, _ = fit_gpu(X, H0, k, 5, 0, precision='f16')
+        out[q] = (W, m.components_.copy(), errors)
+    assert len(out['8'][2]) == 5 and np.all(np.diff(out['8'][2]) < 0)
+    assert_allclose(out['8'][2], out['16'][2], rtol=1e-4)
+    assert _rel_to_max(out['8'][0], out['16'][0]) < 2e-3
+    assert _rel_to_max(out['8'][1], out['16'][1]) < 3e-3
+    assert_allclose(out['8'][1].sum(axis=1), 1.0, rtol=1e-5)
+
+
+def test_fp8_ratio_tiles_saturate(monkeypatch):
+    """Ratios beyond fp8's 448 (x > 0 where W.H ~ 0 in the first updates) saturate in the tile (MODE.FP16_OVFL covers the
+    fp8 conversions too: experiments/micro/fp8_probe2.hip) instead of becoming NaN: the fit stays finite and descends."""
+    n, f, k = 3000, 256, 24
+    X = orc.synthetic_V(14, n, f, k)
+    X[:, 40:44] *= 3e4                          # a few columns far above what H0 (uniform-ish rows) can explain at first
+    H0 = orc.synthetic_H0(14, f, k)
+    monkeypatch.setenv('KLNMF_QTILE', '8')
+    m, W, errors, _ = fit_gpu(X, H0, k, 6, 0, precision='f16')
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=6, tol=0)
+    assert np.isfinite(W).all() and np.isfinite(m.components_).all() and len(errors) == 6
+    assert_allclose(errors, eo, rtol=5e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n,f,k,split', [(300, 700, 24, None), (2048, 512, 96, None), (1000, 2000, 50, '3'), (4096, 1024, 200, '8'),
                                          (33, 130, 7, None)])
 def test_column_split_update_pass_agrees_with_whole_rows(monkeypatch, n, f, k, split):
@@ -549,6 +584,7 @@ def test_colpass_generations_agree(monkeypatch, n, f, k):
     X = (torch.rand(n, f, generator=g, device='cuda') * 3).cpu().numpy()
     H0 = orc.synthetic_H0(11, f, k)
     out = {}
+    monkeypatch.setenv('KLNMF_QTILE', '16')        # the three read the SAME 16-bit ratio operands (fp8 tiles: the test below)
     for gen in ('1', '2', '3'):
         monkeypatch.setenv('KLNMF_COLPASS', gen)
         m, W, errors, _ = fit_gpu(X, H0, k, 4, 0, precision='bf16')
