@@ -203,8 +203,9 @@ def all_distances(A, B, metric, device=0):
 
 
 def ratio_tile_bytes(n_local=0, k=0):
-    """Bytes per element of V of the ratio tiles the row pass leaves for the column pass (stored-ratio schedule):
-    fp8 from 65 536 rows per context on for k <= 224 (klnmf_set_problem; KLNMF_QTILE = 8 / 16 forces either)."""
+    """Bytes per element of V of the ratio tiles the row pass leaves for the column pass (stored-ratio schedule): fp8 from
+    the third iteration of a loop on, for k <= 224, from 65 536 rows per context, on data whose maximum is at most 256 x
+    its mean (klnmf_set_problem and the loop entry points decide; KLNMF_QTILE = 8 / 16 forces either)."""
     env = os.environ.get('KLNMF_QTILE')
     if env is not None:
         return 1 if (env == '8' and k <= 224) else 2

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             const u32x2 w0 = __builtin_bit_cast(u32x2, q0), w1 = __builtin_bit_cast(u32x2, q2);
             // rows 8h + 2j, 8h + 2j + 1 of k-step 0 (b0) and of k-step 1 (b1); the byte-pair selector must be a literal
 #define KL_Q8_PAIR(dst, src, j, sel)                                                              \
-            { const f16x2 p_ = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, 1.0f, sel); dst[2 * (j)] = p_[0]; dst[2 * (j) + 1] = p_[1]; }
+            { const f16x2 p_ = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, kQ8Scale, sel); dst[2 * (j)] = p_[0]; dst[2 * (j) + 1] = p_[1]; }
             KL_Q8_PAIR(b0, w0[0], 0, false) KL_Q8_PAIR(b0, w0[0], 1, true) KL_Q8_PAIR(b0, w0[1], 2, false) KL_Q8_PAIR(b0, w0[1], 3, true)
             KL_Q8_PAIR(b1, w1[0], 0, false) KL_Q8_PAIR(b1, w1[0], 1, true) KL_Q8_PAIR(b1, w1[1], 2, false) KL_Q8_PAIR(b1, w1[1], 3, true)
 #undef KL_Q8_PAIR

@@ -210,7 +210,13 @@ struct klnmf_ctx {
     void *VtA = nullptr, *VtB = nullptr;
     unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
     int col_gen = 2;
-    bool q8 = false;             // the ratio tiles are fp8 (1 B per element of V) instead of the 16-bit operands: large row counts
+    // fp8 ratio tiles (1 B per element of V instead of the 16-bit operands) for the H rule.  q8_ok: the problem's shape
+    // allows them (klnmf_set_problem); q8_loop: this loop's data do (decided at the loop's entry); they are used from the
+    // loop's third iteration on (the first updates from W0 = V.H0^T can carry ratios far beyond fp8's range).
+    bool q8_ok = false, q8_loop = false;
+    int64_t iter_in_loop = 0;
+    double v_max = 0.0;          // the maximum announced with klnmf_set_v_max (0: none)
+    bool q8() const { return q8_loop && iter_in_loop >= 2; }
     float *W32[2] = {nullptr, nullptr};
     opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
@@ -349,7 +355,7 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
             }                                                                                                   \
         }                                                                                                       \
         if constexpr (MODE == ROW_UPDATE) {                                                                     \
-            if (c->q8 && a.base.Qt) {     /* fp8 ratio tiles for the column pass */                             \
+            if (c->q8() && a.base.Qt) {     /* fp8 ratio tiles for the column pass */                             \
                 if (ep) {                                                                                       \
                     if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
                     else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
@@ -496,7 +502,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     if (c->profiling) ev = begin_event(c, c->ev_col);
 #define KL_COLQ_CASE(KTV)                                                                                          \
     case KTV:                                                                                                      \
-        if (c->q8) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        if (c->q8()) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
         else if (c->col_gen == 3) hipLaunchKernelGGL((k_colpass_q<KTV>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
         else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
         break;
@@ -1126,11 +1132,14 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // fp8 ratio tiles: only the H numerator -- a sum over all rows -- sees their 4-bit significands; its relative
             // error falls like 0.036 sqrt(2 / n) (5e-5 at 1M rows, 2e-4 at 65 536: below the operands' own rounding), so
             // they are used from 65 536 rows per context on (KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
-            c->q8 = stored_q && c->KT <= 7 && c->col_gen == 2 && c->row_chunks_possible_q8(n);
-            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8 = stored_q && c->KT <= 7 && c->col_gen == 2 && std::atoi(g) == 8;
+            c->q8_ok = stored_q && c->KT <= 7 && c->col_gen == 2 && c->row_chunks_possible_q8(n);
+            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8_ok = stored_q && c->KT <= 7 && c->col_gen == 2 && std::atoi(g) == 8;
+            c->q8_loop = false;
+            c->iter_in_loop = 0;
+            c->v_max = 0.0;
             c->VtA = c->dalloc(vbytes);
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
-            c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * (c->q8 ? kQTile8 : kQTile)) : nullptr;
+            c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
             for (int i = 0; i < 2; ++i) {
                 c->W32[i] = (float *)c->dalloc((size_t)c->n_pad * c->KP * 4);
                 c->Wb[i] = (opnd_t *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
@@ -1177,7 +1186,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
             c->row_chunks = 1;
             c->row_ct_chunk = c->nct;
-            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8 && !c->q8) {
+            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8 && !c->q8_ok) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 int want = (2 * nwg <= c->cu_count) ? c->cu_count / nwg : 1;
                 if (const char *g = std::getenv("KLNMF_ROW_SPLIT")) want = std::max(1, std::atoi(g));
@@ -1297,6 +1306,7 @@ int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
         int e = 0;
         (void)std::frexp(vmax, &e);             // vmax = m * 2^e, m in [0.5, 1)
         c->v_scale = std::ldexp(1.0, 15 - e);   // c * vmax in [2^14, 2^15)
+        c->v_max = vmax;
         if (c->kc >= 0) fast_pack_H(c, 0);      // the eps row of the dictionary images is in scaled units
     });
 }
@@ -1429,9 +1439,20 @@ int klnmf_init_W(klnmf_ctx *c) {
 // a matrix is not the fit of the caller's data, so the loop entry points refuse it (one 4-byte read per loop).
 static void check_v_overflow(klnmf_ctx *c) {
     if (c->is_exact()) return;
-    int flags[2] = {0, 0};       // v_overflow, op_range (adjacent in DevState)
-    HIPCHK(hipMemcpyAsync(flags, &c->st->v_overflow, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    DevState ds{};
+    HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const int flags[2] = {ds.v_overflow, ds.op_range};
+    // fp8 ratio tiles for this loop?  Their range ends at 3584 (saturating): data whose largest entry is more than 256 times
+    // the mean entry can hold ratios beyond that for many iterations (a spike the model has not fitted yet) -- those keep
+    // the 16-bit tiles.  KLNMF_QTILE = 8 forces the tiles on (from the third iteration), = 16 off.
+    c->q8_loop = false;
+    c->iter_in_loop = 0;
+    if (c->q8_ok) {
+        const char *g = std::getenv("KLNMF_QTILE");
+        const double mean = ds.sum_x / c->v_scale / ((double)c->n * (double)c->f);
+        c->q8_loop = g ? std::atoi(g) == 8 : (c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean);
+    }
     if (flags[1] != 0)
         fail(KLNMF_ERR_UNSUPP, "the factors exceed the fp16 operand range (max W x max H of " + std::to_string(flags[1]) +
                                    " component(s) is more than 2^15 times the largest entry of V: an initial dictionary whose rows "
@@ -1489,6 +1510,7 @@ int klnmf_iter_advance(klnmf_ctx *c) {
         need_problem(c);
         c->cur ^= 1;
         c->loop_iters += 1;
+        c->iter_in_loop += 1;
     });
 }
 
@@ -1524,6 +1546,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
                 piece_update_H(c);
             }
             c->cur ^= 1;
+            c->iter_in_loop += 1;
         };
         auto stopped_already = [&]() -> bool {        // the stop rule may have fired: the remaining (no-op) iterations need not be enqueued
             DevState hs{};
@@ -1653,6 +1676,7 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
             piece_decide(c, tol_abs);                  // identical inputs on every rank -> identical decisions
             if (fit) piece_update_H(c);
             c->cur ^= 1;
+            c->iter_in_loop += 1;
             if (tol_abs > 0 && (it & 15) == 15) {
                 DevState hs{};
                 HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));

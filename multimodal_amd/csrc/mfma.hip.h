@@ -67,7 +67,8 @@ typedef __attribute__((ext_vector_type(8))) opnd_t opx8;
 typedef __attribute__((ext_vector_type(4))) opnd_t opx4;
 constexpr float kOpScaleH = 8192.f;              // 2^13
 constexpr float kOpScaleW = 1.f / 8192.f;
-constexpr float kCarrierW = 1.f / 1024.f;        // eps carrier: W image column kc holds 2^-10, H image row kc eps * 2^10
+constexpr float kCarrierW = 1.f / 1024.f;
+constexpr float kQ8Scale = 8.f;                 // fp8 ratio tiles hold ratio / 8: e4m3 then covers 2^-6 .. 3584 (saturating), full precision from 0.125 on        // eps carrier: W image column kc holds 2^-10, H image row kc eps * 2^10
 // f32 -> f16 conversions that overflow give the largest finite half instead of infinity (MODE bit 23, FP16_OVFL; true
 // infinities stay): a ratio beyond 65504 (x > 0 where W.H ~ 0) or an operand beyond the image range then perturbs one
 // update instead of poisoning the factors with inf - inf.  Set once per kernel (the mode is per wave).

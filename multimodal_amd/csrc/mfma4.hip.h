@@ -377,8 +377,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     const opx8 &src = j < 2 ? b0 : b1;
                     const int o = 4 * (j & 1);
                     s16x2 w = {0, 0};
-                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, 1.0f, false);
-                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, 1.0f, true);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, kQ8Scale, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, kQ8Scale, true);
                     pk[j] = __builtin_bit_cast(unsigned, w);
                 }
                 __builtin_nontemporal_store(pk, (u32x4 *)qp);
