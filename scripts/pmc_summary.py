@@ -16,9 +16,20 @@ def short(name):
     m = re.search(r'k_[a-zA-Z_]+\d?', name)
     base = m.group(0) if m else name[:40]
     if 'k_rowpass' in name:
-        mm = re.search(r'k_rowpass4?ILi(\d+)ELi(\d+)ELi(\d+)', name) or re.search(r'k_rowpass4?<(\d+), (\d+), (\d+)', name)
+        mm = re.search(r'k_rowpass4?<([\d, ]+)>', name)
         if mm:
+            a = [x.strip() for x in mm.group(1).split(',')]
+            base += '<KT=%s,odd=%s,mode=%s%s>' % (a[0], a[1], a[2], ',fp8 tiles' if len(a) > 6 and a[6] == '1' else '')
+        else:
+            mm = re.search(r'k_rowpass4?ILi(\d+)ELi(\d+)ELi(\d+)', name)
+            if mm:
                 base += '<KT=%s,odd=%s,mode=%s>' % mm.groups()
+    if 'k_colpass_q2' in name:
+        mm = re.search(r'k_colpass_q2<([\d, ]+)>', name)
+        if mm:
+            a = [x.strip() for x in mm.group(1).split(',')]
+            if len(a) > 3 and a[3] == '1':
+                base += '<fp8 tiles>'
     return base
 
 
