@@ -238,7 +238,7 @@ class Context(object):
         self.precision = precision
         self.n = self.f = self.k = 0
         self.cap = 0
-        self._pool_key = (precision, int(device)) if (pooled and stream is None) else None
+        self._pool_key = (precision, int(device)) if (pooled and stream is None and os.environ.get('KLNMF_NO_POOL') != '1') else None
         if self._pool_key is not None:
             free = Context._pool.get(self._pool_key)
             if free:

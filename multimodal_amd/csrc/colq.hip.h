@@ -70,6 +70,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char o3[NB > 3 ? OBJ : 16];
     __shared__ __attribute__((aligned(16))) unsigned char o4[NB > 4 ? OBJ : 16];
     if (a.st->stop) return;
+#ifdef KL_COL_PRIO       // experiment: static priority for the second-dispatched half of the workgroup
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(KL_COL_PRIO);
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;

@@ -157,6 +157,9 @@ __device__ __forceinline__ void lds_wait(opx8 &v) {
 // the whole 512-register file -- accumulators in AGPRs -- for 8 <= KT <= 16, i.e. k <= 512: every wave then runs the X
 // order alone on its SIMD, matrix and epilogue segments in sequence; with 2*KT + KS >= 48 matrix instructions per tile
 // the epilogue is the smaller part).
+#ifndef KL_STATIC_PRIO
+#define KL_STATIC_PRIO 1
+#endif
 // Q8: the ratio tiles left for the column pass are fp8 (e4m3, saturating) instead of the 16-bit MFMA operands: 1 KiB per
 // 32 x 32 tile, row-major [row i][16 h' + 4 g + t] = column 8 g + 4 h' + t -- each lane's 16 values are 16 contiguous
 // bytes at 16 (2 i + h'), one store per lane and tile.  Only the H numerator (a sum over ALL rows) sees these 4-bit
@@ -202,6 +205,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const bool grpY = kWaves4 == 8 && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;     // wave-uniform (SGPR)
+    // Static priority for the second-dispatched half of the workgroup (the arbitration loser on every segment otherwise:
+    // MI355X_MICROARCH.md, two waves per SIMD, item 4), set once, never flipped: row pass 4.33 -> 4.13 ms at C4, same bits
+    // (profiles/r02_ab_static_priority.txt; 1, 2 and 3 measure the same; per-segment flips were no gain in round 1).
+    if (KL_STATIC_PRIO > 0 && grpY) __builtin_amdgcn_s_setprio(KL_STATIC_PRIO);
     const int rt_raw = blockIdx.x * kWaves4 + wave;
     const bool active = rt_raw < a.nrt;
     const int rt = active ? rt_raw : a.nrt - 1;

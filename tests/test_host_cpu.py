@@ -215,3 +215,16 @@ def test_bench_defaults_follow_the_measurement_contract():
     a = bench.parse_args([])
     assert (a.gpus, a.n, a.f, a.k, a.precision) == (1, 1000000, 4096, 200, 'f16')       # BASELINE.json configs[3]
     assert a.tol == 0.0 and a.repeats == 5 and a.cpu_rows == 100000 and a.data == 'blocks'
+
+
+def test_scale_inverse_scales_W_columns_and_H_rows():
+    """KLdivNMF.scale (nmf.py:314-321): W columns times (factors + eps), H rows divided by it: W.H unchanged."""
+    rs = np.random.RandomState(4)
+    W, H = rs.random_sample((6, 3)), rs.random_sample((3, 5))
+    factors = np.array([2., .5, 4.])
+    m = nmf.KLdivNMF(n_components=3)
+    sW, sH = m.scale(W, H, factors)
+    assert_array_almost_equal(sW, W * (factors + 1e-8)[None, :])
+    assert_array_almost_equal(sH, H / (factors + 1e-8)[:, None])
+    assert_array_almost_equal(sW.dot(sH), W.dot(H))
+    assert_array_almost_equal(nmf.KLdivNMF(eps=.5).scale(W, H, factors)[0], W * (factors + .5)[None, :])    # the one place self.eps is read
