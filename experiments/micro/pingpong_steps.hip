@@ -1,0 +1,265 @@
+// Microbenchmark (round 2, after pingpong_overlap.hip): the row pass's interval rebuilt from nothing, one ingredient at a
+// time, to see which of them costs the time the kernel loses against "two MFMA segments per SIMD and interval".
+//   workgroup = 8 waves (two per SIMD: X = waves 0-3, Y = waves 4-7), one workgroup per CU, each wave owns 32 rows
+//   per tile and wave:  M = 14 MFMA-2 (B = ratio operands) + 13 MFMA-1 (B = W registers), every A fragment 1 KiB from LDS
+//                       E = 16 x (rcp, mul, fma_mix, log, fma_mix) + 8 cvt_pk_f16 (+ 8 fp8 conversions with QST)
+//   order as in k_rowpass4:  X: M E | barrier      Y: M | barrier | E      (one s_barrier per tile and wave)
+// feature bits (template parameter F):
+//   1  BAR   the barrier (without it the waves free-run; Y starts with an E to be out of phase)
+//   2  DMA   every wave copies its slices of the next dictionary tile image (13 KiB per tile and workgroup, L2-resident
+//            source) into a 4-object LDS ring with global_load_lds in its E segment; the M segments read that ring
+//   4  VLD   V tiles streamed from HBM (2 x 16 B per lane and tile, issued one E segment ahead, vmcnt(0) at E's start)
+//   8  QST   fp8 ratio tile stored (16 B per lane and tile, non-temporal) one tile late, as the kernel does
+//   16 DEP   real data flow: E consumes the MFMA-1 accumulator, MFMA-2 consumes E's packed ratios (else constants)
+//   32 PRIO  s_setprio 1 for the Y waves
+//   64 TR    MFMA-1 fragments read with two ds_read_b64_tr_b16 instead of one ds_read_b128
+//   128 PLAIN  ordinary instead of non-temporal ratio stores      256 QSMALL  ratio tiles overwrite 4 slots per wave (cache-resident)
+//   1024 NOCVT the stored 16 bytes are the first half of the packed fp16 ratios (no fp8 conversions)    2048 NOSTORE conversions only
+//   4096 BATCH2 VMEM batched: V loads and dictionary copies for two tiles issued every second E segment, vmcnt(0) only there
+//   8192 VSMALL V tiles re-read from 4 slots per wave (cache hits)
+//   512 NOWAIT no s_waitcnt vmcnt(0) at the start of E (only meaningful without VLD / DMA: isolates issue cost from the wait)
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o pingpong_steps pingpong_steps.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+typedef __attribute__((ext_vector_type(2))) short s2v;
+typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(4))) unsigned u4;
+#define LDSP __attribute__((address_space(3)))
+
+constexpr int kImg = 13312;          // 32 columns x 208 components x 2 B
+constexpr int kObj = 13312;
+constexpr int kTilesL2 = 128;        // dictionary: 128 tile images = 1.7 MB
+constexpr int N2 = 14, N1 = 13, NF = 27, D = 3;
+
+template <int OFF> __device__ __forceinline__ void rd128(h8 &r, unsigned a) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void rdtr(h8 &r, unsigned a) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    h4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 512));
+    r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int N> __device__ __forceinline__ void lwait(h8 &r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N));
+}
+template <int I, int E, class Fn> __device__ __forceinline__ void sfor(Fn &&f) {
+    if constexpr (I < E) { f(std::integral_constant<int, I>{}); sfor<I + 1, E>(f); }
+}
+
+template <int F>
+__global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht, const unsigned char *vt, unsigned char *qt,
+                                            int iters, float seed) {
+    constexpr bool BAR = F & 1, DMA = F & 2, VLD = F & 4, QST = F & 8, DEP = F & 16, PRIO = F & 32, TR = F & 64;
+    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192;
+    __shared__ __attribute__((aligned(16))) unsigned char img[4 * kObj + 32768];      // ring of 4 objects (+ pad: one WG per CU)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool grpY = wave >= 4;
+    for (int i = tid; i < (4 * kObj) / 2; i += 512) ((LDSP _Float16 *)img)[i] = (_Float16)(0.0078125f * (1 + ((i * 37) & 31)));
+    __syncthreads();
+    if (PRIO && grpY) __builtin_amdgcn_s_setprio(1);
+    const int64_t wslot = ((int64_t)blockIdx.x * 8 + wave) * iters;
+    const unsigned char *vlane = vt + wslot * 2048 + lane * 32;
+    unsigned char *qlane = qt + wslot * 1024 + lane * 16;
+    f16v acc[7], d;
+    h8 wf[N1], ring[4], b0, b1, va[4], vb[4];
+    for (int m = 0; m < 7; ++m) for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    for (int e = 0; e < 16; ++e) d[e] = seed + 4.f + e;
+    for (int s = 0; s < N1; ++s) for (int j = 0; j < 8; ++j) wf[s][j] = (_Float16)(0.01f * (1 + ((lane + s + j) & 15)));
+    for (int j = 0; j < 8; ++j) { b0[j] = (_Float16)(1.f + 0.01f * j); b1[j] = (_Float16)(0.9f + 0.01f * j); va[0][j] = va[1][j] = va[2][j] = va[3][j] = (_Float16)(1.f + j); vb[0][j] = vb[1][j] = vb[2][j] = vb[3][j] = (_Float16)(2.f + j); }
+    float s1 = 0.f;
+    const float eps = 1e-8f * seed;
+    const unsigned lbase = (unsigned)(uintptr_t)img + lane * 16;
+    const unsigned tbase = (unsigned)(uintptr_t)img + lane * 8;       // transposed reads: 8 B per lane, contiguous (no bank conflicts)
+    if (VLD) { va[0] = *(const h8 *)vlane; vb[0] = *(const h8 *)(vlane + 16); }
+    if (VLD && BATCH2) { va[1] = *(const h8 *)(vlane + 2048); vb[1] = *(const h8 *)(vlane + 2048 + 16); }
+
+    auto dma = [&](int o, int tg) {
+        if (!DMA) return;
+        const unsigned char *g = ht + (int64_t)(tg & (kTilesL2 - 1)) * kImg;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int off = r * 8192 + tid * 16;
+            if (off < kImg)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned *)(g + off),
+                                                 (LDSP unsigned *)(img + o * kObj + r * 8192 + wave * 1024), 16, 0, 0);
+        }
+    };
+    auto seg_M = [&](auto TS, int it) {
+        constexpr int ts = decltype(TS)::value;
+        const unsigned ra = lbase + (DMA ? ((ts + 3) % 4) * kObj : 0);
+        const unsigned ta = (TR ? tbase : lbase) + (DMA ? (ts % 4) * kObj : 0);
+        auto issue = [&](auto P) {
+            constexpr int p = decltype(P)::value;
+            if constexpr (p < N2) rd128<(p % 13) * 1024>(ring[p % 4], ra);
+            else if constexpr (p < NF) {
+                if constexpr (TR) rdtr<((p - N2) % 13) * 1024>(ring[p % 4], ta);
+                else rd128<((p - N2) % 13) * 1024>(ring[p % 4], ta);
+            }
+        };
+        sfor<0, D>([&](auto P) { issue(P); });
+        sfor<0, NF>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            issue(std::integral_constant<int, p + D>{});
+            constexpr int last = (p + D < NF - 1) ? p + D : NF - 1;
+            constexpr int n_a = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
+            constexpr int n_b = (last - p) - n_a;
+            lwait<n_a + (TR ? 2 : 1) * n_b>(ring[p % 4]);
+            if constexpr (p < N2) acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+            else {
+                if constexpr (p == N2 && DEP) for (int e = 0; e < 16; ++e) d[e] = 0.f;
+                if constexpr (DEP) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], d, 0, 0, 0);
+                else acc[(p - N2) % 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], acc[(p - N2) % 7], 0, 0, 0);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (BAR && grpY) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    };
+    u4 qpk = {0u, 0u, 0u, 0u};
+    auto seg_E = [&](auto TS, int it) {
+        constexpr int ts = decltype(TS)::value;
+        h8 &xa = va[BATCH2 ? ts : (ts & 1)], &xb = vb[BATCH2 ? ts : (ts & 1)];
+        if (BATCH2) {
+            if ((ts & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[ts]), "+v"(vb[ts]), "+v"(va[ts + 1]), "+v"(vb[ts + 1])::"memory");
+        } else if (!NOWAIT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory");
+        if (QST && NOSTORE) asm volatile("" ::"v"(qpk));
+        else if (QST && it > 0) {
+            u4 *qp = (u4 *)(qlane + (int64_t)(QSMALL ? ((it - 1) & 3) : (it - 1)) * 1024);
+            if (PLAIN) *qp = qpk;
+            else __builtin_nontemporal_store(qpk, qp);
+        }
+        if (VLD && BATCH2) {
+            if ((ts & 1) == 0) {
+#pragma unroll
+                for (int u = 2; u < 4; ++u) {
+                    const int tn = VSMALL ? ((it + u) & 3) : min(it + u, iters - 1);
+                    const unsigned char *p = vlane + (int64_t)tn * 2048;
+                    va[(ts + u) & 3] = *(const h8 *)p;
+                    vb[(ts + u) & 3] = *(const h8 *)(p + 16);
+                }
+            }
+        } else if (VLD) {
+            const int tn = VSMALL ? ((it + 1) & 3) : min(it + 1, iters - 1);
+            const unsigned char *p = vlane + (int64_t)tn * 2048;
+            va[(ts + 1) & 1] = *(const h8 *)p;
+            vb[(ts + 1) & 1] = *(const h8 *)(p + 16);
+        }
+        if (BATCH2) {
+            if ((ts & 1) == 0) { dma((ts + 2) % 4, it + 2); dma((ts + 3) % 4, it + 3); }
+        } else dma(grpY ? (ts + 3) % 4 : (ts + 2) % 4, it + (grpY ? 3 : 2));
+        float q[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float x = (float)(e < 8 ? xa[e & 7] : xb[e & 7]);
+            const float rinv = __builtin_amdgcn_rcpf(d[e]);
+            q[e] = __builtin_fmaf(x, rinv, eps * rinv);
+            s1 = __builtin_fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
+        }
+        h8 n0, n1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { n0[j] = (_Float16)q[j]; n1[j] = (_Float16)q[8 + j]; }
+        if (DEP) { b0 = n0; b1 = n1; }
+        else { asm volatile("" ::"v"(n0), "v"(n1)); }
+        if (QST && NOCVT) qpk = __builtin_bit_cast(u4, n0);
+        else if (QST) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h8 &src = DEP ? (j < 2 ? b0 : b1) : (j < 2 ? n0 : n1);      // as the kernel: from the live MFMA operands
+                const int o = 4 * (j & 1);
+                s2v w = {0, 0};
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o], src[o + 1]}, 8.f, false);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o + 2], src[o + 3]}, 8.f, true);
+                qpk[j] = __builtin_bit_cast(unsigned, w);
+            }
+        }
+        asm volatile("" : "+v"(s1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (BAR && !grpY) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    };
+    if (!BAR && grpY) seg_E(std::integral_constant<int, 3>{}, 0);      // free-running: start the Y waves out of phase
+    for (int t4 = 0; t4 < iters; t4 += 4)
+        sfor<0, 4>([&](auto I) {
+            seg_M(I, t4 + decltype(I)::value);
+            seg_E(I, t4 + decltype(I)::value);
+        });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float r = s1 + d[3];
+    for (int m = 0; m < 7; ++m) for (int e = 0; e < 16; ++e) r += acc[m][e];
+    out[(int64_t)blockIdx.x * 512 + tid] = r;
+}
+
+__global__ void fill_h(_Float16 *p, int64_t n, float lo, float step, int mask) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = (_Float16)(lo + step * (float)((i * 29) & mask));
+}
+
+static float *g_out; static unsigned char *g_ht, *g_vt, *g_qt;
+constexpr int kGrid = 2048, kIters = 128;
+
+template <int F> void report(const char *name) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<F><<<256, 512>>>(g_out, g_ht, g_vt, g_qt, 8, 1.5f);
+    (void)hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        k<F><<<kGrid, 512>>>(g_out, g_ht, g_vt, g_qt, kIters, 1.5f);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    hipError_t err = hipGetLastError();
+    const double us = best * 1e3 / ((kGrid / 256.0) * kIters);
+    printf("F=%3d %-58s %7.3f ms  %6.3f us / interval (2 tiles per SIMD; 54 MFMAs = 0.91 us at 1.9 GHz) %s\n", F, name, best, us,
+           err == hipSuccess ? "" : hipGetErrorString(err));
+    fflush(stdout);
+}
+
+int main() {
+    const int64_t nv = (int64_t)kGrid * 8 * kIters * 1024, nq = (int64_t)kGrid * 8 * kIters * 1024;   // halves / bytes
+    (void)hipMalloc(&g_out, (size_t)kGrid * 512 * 4);
+    (void)hipMalloc(&g_ht, (size_t)kTilesL2 * kImg);
+    (void)hipMalloc(&g_vt, (size_t)nv * 2);
+    (void)hipMalloc(&g_qt, (size_t)nq);
+    fill_h<<<1024, 256>>>((_Float16 *)g_ht, (int64_t)kTilesL2 * kImg / 2, 0.0078125f, 0.0078125f, 31);
+    fill_h<<<4096, 256>>>((_Float16 *)g_vt, nv, 0.5f, 0.0625f, 63);
+    (void)hipDeviceSynchronize();
+    report<0>("free-running, constants");
+    report<16>("free-running, real data flow");
+    report<1>("barrier");
+    report<17>("barrier + data flow");
+    report<17 + 64>("barrier + data flow + transposed reads");
+    report<17 + 2>("barrier + data flow + dictionary copies");
+    report<17 + 4>("barrier + data flow + V from HBM");
+    report<17 + 8>("barrier + data flow + ratio store");
+    report<17 + 4 + 8>("barrier + data flow + V + ratio store");
+    report<17 + 2 + 4 + 8>("barrier + data flow + copies + V + store");
+    report<17 + 2 + 4 + 8 + 64>("all + transposed reads  (= the kernel's interval)");
+    report<17 + 2 + 4 + 8 + 64 + 32>("all + priority for Y");
+    report<2 + 4 + 8 + 64 + 16>("all, no barrier (copies unsynchronised: timing only)");
+    report<25 + 128>("barrier + data flow + PLAIN ratio store");
+    report<25 + 256>("barrier + data flow + nt store into 4 slots");
+    report<25 + 128 + 256>("barrier + data flow + plain store into 4 slots");
+    report<25 + 512>("barrier + data flow + nt store, never waited for");
+    report<25 + 128 + 512>("barrier + data flow + plain store, never waited for");
+    report<25 + 1024>("barrier + data flow + store without fp8 conversions");
+    report<25 + 2048>("barrier + data flow + fp8 conversions without store");
+    report<25 + 1024 + 512>("barrier + data flow + store w/o conversions, never waited");
+    report<95 + 1024>("all, store without fp8 conversions");
+    report<95 + 2048>("all, conversions without store");
+    report<95 + 4096>("all, VMEM batched per two tiles");
+    report<95 + 8192>("all, V from cache");
+    report<95 + 8192 + 256>("all, V from cache, ratio tiles into cache");
+    report<95 + 4096 + 1024>("all batched, store without conversions");
+    report<95 + 128>("all, plain stores");
+    report<95 + 256>("all, nt stores into 4 slots");
+    return 0;
+}

@@ -442,6 +442,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         if (grpY) dma((ts + 3) % 4, tg + 3);
         else dma((ts + 2) % 4, tg + 2);
         float q[16];
+#ifdef KL_NO_NUM_EPS
+        float zero_f = 0.f;
+        asm volatile("" : "+v"(zero_f));
+#endif
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float x = (float)(e < 8 ? va[e & 7] : vb[e & 7]);
@@ -457,7 +461,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
                 // adds to the matrix time of the SIMD, every instruction counts
                 const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps came in through MFMA-1
+#ifdef KL_NO_NUM_EPS
+                q[e] = fmaf(x, rinv, zero_f);
+#else
                 q[e] = fmaf(x, rinv, eps * rinv);
+#endif
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
             }
         }
