@@ -207,6 +207,15 @@ struct klnmf_ctx {
     int nrt = 0, nct = 0, nct_used = 0, nst = 0, ncb = 0, nchunks = 0, stages_per_chunk = 0;
     int row_chunks = 1, row_ct_chunk = 0;     // column-split update pass (few rows): chunks, column tiles per chunk
     float *Gpart = nullptr;                   // [row_chunks][nrt * 32][KP] partial Q.H^T
+    // hybrid update pass (many rows): the workgroups of the last partial round run column-split (tail_chunks chunks of
+    // tail_ct_chunk column tiles each) so that they fill the chip; tail_wg = 0: none.  Gpart then holds the tail's slabs.
+    int tail_wg = 0, tail_chunks = 1, tail_ct_chunk = 0;
+    int64_t loss_parts() const {               // entries of loss_part2 an update pass writes
+        if (!pingpong()) return nrt;
+        if (tail_wg > 0) return (int64_t)nrt + (int64_t)(tail_chunks - 1) * (nrt - tail_rt0());
+        return (int64_t)nrt * row_chunks;
+    }
+    int tail_rt0() const { return (((nrt + 7) / 8) - tail_wg) * 8; }
     void *VtA = nullptr, *VtB = nullptr;
     unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
     int col_gen = 2;
@@ -343,6 +352,16 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
 #define KL_ROW4_CASE(KTV)                                                                                       \
     case KTV:                                                                                                   \
         if constexpr (MODE == ROW_UPDATE) {                                                                     \
+            if (grid_y > 1 && c->q8() && a.base.Qt) {      /* column-split pass leaving fp8 ratio tiles */      \
+                if (ep) {                                                                                       \
+                    if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 1, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                    else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 1, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                } else {                                                                                        \
+                    if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0, 8, 1, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                    else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 8, 1, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                }                                                                                               \
+                break;                                                                                          \
+            }                                                                                                   \
             if (grid_y > 1) {         /* column-split pass: its own instantiations (SPLIT = 1) */               \
                 if (ep) {                                                                                       \
                     if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
@@ -458,6 +477,27 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
             hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
                                (const float *)c->Gpart, c->row_chunks, rows * c->KP, (const float *)c->W32[c->cur],
                                c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
+                               (const DevState *)c->st, a.tcur, a.tnext);
+            HIPCHK(hipGetLastError());
+            if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+            return;
+        }
+        if (mode == ROW_UPDATE && c->tail_wg > 0) {
+            // hybrid: the full rounds of workgroups take whole rows; the last partial round (tail_wg < CUs workgroups
+            // that would each run a whole row block's length on an otherwise idle chip) is split into column chunks
+            // and its W rule applied from the slabs
+            launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4 - c->tail_wg);
+            RowPass4Args t4 = a4;
+            t4.base.wg0 = grid4 - c->tail_wg;
+            t4.base.rt0 = c->tail_rt0();
+            t4.base.gpart = c->Gpart;
+            t4.base.ct_chunk = c->tail_ct_chunk;
+            launch_rowpass4_kt<ROW_UPDATE>(c, t4, c->tail_wg, c->tail_chunks);
+            const int64_t row0 = (int64_t)t4.base.rt0 * 32, rows = (int64_t)(c->nrt - t4.base.rt0) * 32;
+            hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
+                               (const float *)c->Gpart, c->tail_chunks, rows * c->KP,
+                               (const float *)c->W32[c->cur] + row0 * c->KP, c->W32[c->cur ^ 1] + row0 * c->KP,
+                               c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), c->kc,
                                (const DevState *)c->st, a.tcur, a.tnext);
             HIPCHK(hipGetLastError());
             if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
@@ -737,7 +777,7 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
         // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
         if (measured && !fit) fast_pack_H(c, 0);
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
-                           (const double2 *)c->loss_part2, (int64_t)c->nrt * (c->pingpong() ? c->row_chunks : 1),
+                           (const double2 *)c->loss_part2, c->loss_parts(),
                            (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
                            fused_tol ? *fused_tol : 0.0, c->errors, c->cap);
         HIPCHK(hipGetLastError());
@@ -1051,7 +1091,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
                                    "shard the rows or use the 16-bit mode");
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
-        c->Gpart = nullptr; c->row_chunks = 1;
+        c->Gpart = nullptr; c->row_chunks = 1; c->tail_wg = 0; c->tail_chunks = 1;
         c->Wpart = nullptr; c->wsplit = 1;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
@@ -1199,7 +1239,26 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
                 }
                 if (c->row_chunks > 1) c->Gpart = (float *)c->dalloc((size_t)c->row_chunks * slab_bytes);
             }
-            c->loss_part2 = (double2 *)c->dalloc(sizeof(double2) * c->nrt * c->row_chunks);
+            // Hybrid update pass: more workgroups than CUs, and a last partial round of at most half the CUs (one
+            // workgroup per CU: 254 registers).  Its workgroups are split into as many column chunks as fill the chip
+            // once (n = 10^6: 67 workgroups x 3 chunks; 90 000 rows: 96 x 2).  KLNMF_ROW_TAIL = 0 switches it off.
+            c->tail_wg = 0; c->tail_chunks = 1; c->tail_ct_chunk = c->nct;
+            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8 && c->row_chunks == 1) {
+                const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
+                const int rem = nwg % c->cu_count;
+                int want = (nwg > c->cu_count && rem > 0) ? c->cu_count / rem : 1;
+                if (const char *g = std::getenv("KLNMF_ROW_TAIL")) want = std::min(want, std::max(1, std::atoi(g)));
+                want = std::min(std::min(want, 4), c->nct / 4);
+                if (want > 1) {
+                    c->tail_ct_chunk = 4 * ((c->nct / 4 + want - 1) / want);
+                    c->tail_chunks = (c->nct + c->tail_ct_chunk - 1) / c->tail_ct_chunk;
+                    if (c->tail_chunks > 1) {
+                        c->tail_wg = rem;
+                        c->Gpart = (float *)c->dalloc((size_t)c->tail_chunks * (c->nrt - c->tail_rt0()) * 32 * c->KP * 4);
+                    }
+                }
+            }
+            c->loss_part2 = (double2 *)c->dalloc(sizeof(double2) * std::max<int64_t>(c->loss_parts(), (int64_t)c->nrt * c->row_chunks));
         }
         reset_state(c);
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1226,7 +1285,7 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         if (n > (1LL << 30) || f > (1LL << 30) || k > (1LL << 20)) fail(KLNMF_ERR_UNSUPP, "dimension too large");
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
-        c->Gpart = nullptr; c->row_chunks = 1;
+        c->Gpart = nullptr; c->row_chunks = 1; c->tail_wg = 0; c->tail_chunks = 1;
         c->Wpart = nullptr; c->wsplit = 1;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;

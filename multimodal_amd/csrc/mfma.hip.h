@@ -261,8 +261,13 @@ struct RowPassArgs {
     // Column-split update pass of the ping-pong kernel (few rows: one workgroup per 256 rows would leave the chip idle):
     // blockIdx.y = column chunk of ct_chunk tiles; the workgroup leaves its part of Q.H^T in gpart[chunk][row][KP] and
     // its loss terms in loss_part[chunk * nrt + rt]; k_wrule_slabs sums the chunks and applies the W rule.  null: whole rows.
+    // A launch may cover only the workgroups from wg0 on (hybrid update pass: the full rounds of workgroups run whole
+    // rows, the last partial round runs column-split so that it fills the chip: klnmf_api.hip, fast_rowpass); the split
+    // launch then addresses gpart and the chunks' extra loss parts relative to its first row tile rt0 = 8 * wg0:
+    // gpart[chunk][rt - rt0 ...], loss_part[nrt + (chunk - 1) * (nrt - rt0) + rt - rt0] for chunk >= 1.
     float *gpart;
     int ct_chunk;
+    int wg0, rt0;
 };
 
 // LDS per stage buffer: [dictionary image | V tiles of the 8 waves (16-bit V only)]

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // MI355X_MICROARCH.md, two waves per SIMD, item 4), set once, never flipped: row pass 4.33 -> 4.13 ms at C4, same bits
     // (profiles/r02_ab_static_priority.txt; 1, 2 and 3 measure the same; per-segment flips were no gain in round 1).
     if (KL_STATIC_PRIO > 0 && grpY) __builtin_amdgcn_s_setprio(KL_STATIC_PRIO);
-    const int rt_raw = blockIdx.x * kWaves4 + wave;
+    const int rt_raw = ((int)blockIdx.x + a.wg0) * kWaves4 + wave;
     const bool active = rt_raw < a.nrt;
     const int rt = active ? rt_raw : a.nrt - 1;
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // SPLIT is a template parameter, not a runtime flag: the whole-row instantiation must stay the instruction stream it
     // was (a runtime branch cost 2 % at the headline shape and spilled at KT = 16)
     static_assert(SPLIT == 0 || (NW == 8 && MODE == ROW_UPDATE), "column-split pass: 8-wave update kernels only");
-    static_assert(Q8 == 0 || (NW == 8 && MODE == ROW_UPDATE && SPLIT == 0 && sizeof(opnd_t) == 2), "fp8 ratio tiles: whole-row 8-wave update kernels");
+    static_assert(Q8 == 0 || (NW == 8 && MODE == ROW_UPDATE && sizeof(opnd_t) == 2), "fp8 ratio tiles: 8-wave update kernels");
     constexpr bool split = SPLIT != 0;
     const int ct0 = split ? (int)blockIdx.y * a.ct_chunk : 0;
     const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
@@ -684,8 +684,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         }
         const double s1w = wave_sum((double)s1);
         s2 = wave_sum(s2);
-        if (lane == 0) a.loss_part[(int64_t)blockIdx.y * a.nrt + rt] = make_double2(s1w, s2);
-        float *gp = a.gpart + ((int64_t)blockIdx.y * a.nrt * 32 + (int64_t)rt * 32 + r) * KP;
+        const int trt = a.nrt - a.rt0, lrt = rt - a.rt0;      // row tiles of this (possibly partial) launch, this wave's among them
+        if (lane == 0) a.loss_part[blockIdx.y == 0 ? (int64_t)rt : (int64_t)a.nrt + (int64_t)(blockIdx.y - 1) * trt + lrt] = make_double2(s1w, s2);
+        float *gp = a.gpart + ((int64_t)blockIdx.y * trt * 32 + (int64_t)lrt * 32 + r) * KP;
 #pragma unroll
         for (int m = 0; m < KT; ++m)
 #pragma unroll

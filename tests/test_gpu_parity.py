@@ -550,6 +550,39 @@ def test_column_split_update_pass_agrees_with_whole_rows(monkeypatch, n, f, k, s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k,iters,oracle', [(70000, 256, 200, 4, True), (66000, 512, 72, 4, False), (70001, 384, 200, 3, False)])
+def test_hybrid_update_pass_agrees_with_whole_rows(monkeypatch, n, f, k, iters, oracle):
+    """Many rows: the full rounds of workgroups take whole rows, the last partial round runs column-split with its W rule
+    from the slabs (klnmf_api.hip fast_rowpass).  Same arithmetic per element, another summation
+    order for the rows of the tail: fit (fp8 and 16-bit ratio tiles), transform and the loss record must agree with the
+    whole-row pass (KLNMF_ROW_TAIL=0) to fp32 summation noise, and with the oracle."""
+    X = orc.synthetic_V(7, n, f, min(k, 32))
+    H0 = orc.synthetic_H0(7, f, k)
+    out = {}
+    for mode in ('0', None):
+        if mode is None:
+            monkeypatch.delenv('KLNMF_ROW_TAIL', raising=False)
+        else:
+            monkeypatch.setenv('KLNMF_ROW_TAIL', mode)
+        m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+        mt = nmf.KLdivNMF(n_components=k, max_iter=2, tol=0, precision='f16')
+        mt.components_ = m.components_
+        with contextlib.redirect_stderr(io.StringIO()):
+            Wt = mt.transform(X)
+        out[mode] = (W, m.components_.copy(), np.asarray(errors), Wt)
+    a, b = out['0'], out[None]
+    assert len(a[2]) == len(b[2]) == iters
+    assert_allclose(b[2], a[2], rtol=1e-6)
+    for i in (0, 1, 3):
+        assert np.abs(b[i] - a[i]).max() <= 2e-4 * np.abs(a[i]).max()
+    assert np.abs(b[0][-300:] - a[0][-300:]).max() > 0          # the tail did take the other path
+    if oracle:
+        Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+        assert_allclose(b[2], eo, rtol=1e-4)
+        assert abs(orc.kl_error(X, b[0].astype(np.float64), b[1].astype(np.float64)) / orc.kl_error(X, Wo, Ho) - 1) < 1e-4
+
+
+@pytest.mark.gpu
 def test_rowpass_generations_agree_full_chip(monkeypatch):
     """Same comparison with enough row tiles to occupy every CU several times over
     (memory latencies under load are what exposed the ordering bugs of the counted-wait
