@@ -126,7 +126,7 @@ def measured_traffic(args, n_local):
         if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision.replace('bf16', 'f16')):
             row = col = None
             for name, v in entry.get('kernels', {}).items():
-                if 'k_rowpass' in name:
+                if 'k_rowpass' in name and 'column-split' not in name:      # the whole-row launch (the roofline entry)
                     row = v['hbm_bytes_per_launch']
                 elif 'k_colpass' in name:
                     col = v['hbm_bytes_per_launch']
@@ -280,7 +280,9 @@ def main():
         torch.cuda.synchronize()
 
     segments, fits = [], []
-    prof_tot = {'rowpass_ms': 0.0, 'rowpass_launches': 0, 'colpass_ms': 0.0, 'colpass_launches': 0}
+    prof_tot = {'rowpass_ms': 0.0, 'rowpass_launches': 0, 'colpass_ms': 0.0, 'colpass_launches': 0, 'tail_ms': 0.0,
+                'tail_launches': 0}
+    tail_rows = 0
     for rep in range(max(1, args.repeats)):
         model.set_H(H0)
         model.init_W()
@@ -316,6 +318,7 @@ def main():
         fits.append((list(errors), int(n_done), bool(stopped)))
         for key in prof_tot:
             prof_tot[key] += prof[key]
+        tail_rows = prof.get('tail_rows', 0)
 
     if rank == 0:
         elapsed = statistics.median(segments)
@@ -329,10 +332,22 @@ def main():
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         qbytes = _native.ratio_tile_bytes(n_local, k) if stored_q else 0
-        # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures
-        flops_row = 4.0 * n_local * f * k
-        alg_bytes_row = n_local * f * vbytes + 2 * n_local * k * 4
-        sched_bytes_row = alg_bytes_row + 2 * n_local * k * 2 + n_local * f * qbytes      # + 16-bit W images in/out + ratio tiles out
+        # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures.
+        # Hybrid update pass: the dominant kernel is the whole-row k_rowpass4 over the full rounds of
+        # workgroups (n_row rows); the column-split last partial round + its slab W rule are reported beside it.
+        section_ms = row_ms
+        hybrid = prof_tot['tail_launches'] > 0 and prof_tot['tail_launches'] == prof_tot['rowpass_launches']
+        n_row = n_local
+        tail_ms = 0.0
+        if hybrid:
+            n_pad = (n_local + 63) // 64 * 64
+            n_row = n_pad - tail_rows                       # all of them valid rows: the padding sits in the tail
+            tail_ms = prof_tot['tail_ms'] / prof_tot['tail_launches']
+            row_ms = section_ms - tail_ms
+        flops_row = 4.0 * n_row * f * k
+        alg_bytes_row = n_row * f * vbytes + 2 * n_row * k * 4
+        sched_bytes_row = alg_bytes_row + 2 * n_row * k * 2 + n_row * f * qbytes      # + 16-bit W images in/out + ratio tiles out
+        sched_bytes_section = sched_bytes_row * n_local / n_row
         flops_col = 2.0 * n_local * f * k
         sched_bytes_col = (n_local * f * qbytes + n_local * k * 2) if stored_q else (n_local * f * vbytes + 2 * n_local * k * 2)
         t_mfma = flops_row / (PEAK_BF16_TFLOPS * 1e12)
@@ -352,7 +367,7 @@ def main():
             'frac': ((row_tflops / PEAK_BF16_TFLOPS) if mfma_bound else (row_gbs / PEAK_HBM_GBS)) if row_s > 0 else None,
             'traffic': traffic_row,
             'traffic_source': PMC_TRAFFIC_FILE if traffic_row else None,
-            'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'],
+            'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'], 'rows_per_launch': n_row,
             'algorithmic_flops_per_launch': flops_row,
             'algorithmic_bytes_per_launch': alg_bytes_row,
             'schedule_bytes_per_launch': sched_bytes_row,
@@ -403,6 +418,14 @@ def main():
             'device': info,
             'roofline': roofline,
             'kernels': {
+                'row_pass_section': {
+                    'what': ('whole-row k_rowpass4 over %d rows (the roofline entry) + column-split k_rowpass4 over the last %d '
+                             'rows + k_wrule_slabs on those rows' % (n_row, n_local - n_row)) if hybrid
+                            else 'one launch (the roofline entry)',
+                    'avg_ms': section_ms, 'tail_avg_ms': tail_ms if hybrid else None,
+                    'tail_rows': n_local - n_row if hybrid else 0,
+                    'algorithmic_tflops': 4.0 * n_local * f * k / (section_ms * 1e-3) / 1e12 if section_ms > 0 else None,
+                    'frac_of_bf16_peak': 4.0 * n_local * f * k / (section_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if section_ms > 0 else None},
                 ('k_colpass_q2' if stored_q else 'k_colpass'): {
                     'avg_launch_ms': col_ms, 'launches': prof_tot['colpass_launches'],
                     'algorithmic_tflops': flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
@@ -411,7 +434,7 @@ def main():
                     'schedule_hbm_gbs': sched_bytes_col / (col_ms * 1e-3) / 1e9 if col_ms > 0 else None,
                     'traffic': traffic_col},
                 'iteration_algorithmic_bytes': n * f * vbytes + 2 * n * k * 4 + 3 * k * f * 4,
-                'iteration_schedule_bytes': (sched_bytes_row + sched_bytes_col) * n_gpus,
+                'iteration_schedule_bytes': (sched_bytes_section + sched_bytes_col) * n_gpus,
                 'iteration_algorithmic_tflops': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12,
                 'iteration_frac_of_bf16_peak': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
             },

@@ -225,6 +225,10 @@ int klnmf_profile_enable(klnmf_ctx *ctx, int on);
 int klnmf_profile_read(klnmf_ctx *ctx, int64_t *rowpass_launches,
                        double *rowpass_ms, int64_t *colpass_launches,
                        double *colpass_ms, int reset);
+/* The part of the row-pass time klnmf_profile_read reports that the column-split last partial round of workgroups and its
+ * slab W rule took (hybrid update pass: DESIGN.md section 4.1), the launches it was measured over and the (padded) rows
+ * that part covers; 0 launches when the context runs whole rows everywhere. */
+int klnmf_profile_read_tail(klnmf_ctx *ctx, int64_t *tail_n, double *tail_ms, int64_t *tail_rows, int reset);
 int klnmf_synchronize(klnmf_ctx *ctx);
 
 /* ---- CSR input (next-row N3): the reference's sparse branch ----------------------------------- */

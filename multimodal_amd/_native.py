@@ -88,6 +88,7 @@ SIGNATURES = {
     'klnmf_profile_enable': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_profile_read': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double),
                                       _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.c_int]),
+    'klnmf_profile_read_tail': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.POINTER(_i64), _c.c_int]),
     'klnmf_synchronize': (_c.c_int, [_ctx_p]),
     'klnmf_set_problem_sparse': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64, _i64]),
     'klnmf_upload_csr': (_c.c_int, [_ctx_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
@@ -536,8 +537,12 @@ class Context(object):
         _check(self._lib.klnmf_profile_read(self._h, ctypes.byref(rn), ctypes.byref(rms),
                                             ctypes.byref(cn), ctypes.byref(cms),
                                             1 if reset else 0))
+        tn, tr, tms = _i64(0), _i64(0), _c.c_double(0)
+        _check(self._lib.klnmf_profile_read_tail(self._h, ctypes.byref(tn), ctypes.byref(tms), ctypes.byref(tr),
+                                                 1 if reset else 0))
         return {'rowpass_launches': rn.value, 'rowpass_ms': rms.value,
-                'colpass_launches': cn.value, 'colpass_ms': cms.value}
+                'colpass_launches': cn.value, 'colpass_ms': cms.value,
+                'tail_launches': tn.value, 'tail_ms': tms.value, 'tail_rows': tr.value}
 
     def synchronize(self):
         _check(self._lib.klnmf_synchronize(self._h))

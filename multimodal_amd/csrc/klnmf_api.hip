@@ -248,7 +248,7 @@ struct klnmf_ctx {
     bool v_uploaded = false;
 
     bool profiling = false;
-    std::vector<EventPair> ev_row, ev_col;
+    std::vector<EventPair> ev_row, ev_col, ev_tail;      // ev_tail: the column-split tail + slabs part of a hybrid row pass
 
     // row shards over the GPUs of a node (klnmf_comm_*, klnmf_run_sharded): this rank's RCCL communicator
     ncclComm_t comm = nullptr;
@@ -285,6 +285,8 @@ struct klnmf_ctx {
         allocs.clear();
         for (auto &e : ev_row) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : ev_col) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto &e : ev_tail) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        ev_tail.clear();
         ev_row.clear();
         ev_col.clear();
         have_problem = false;
@@ -487,6 +489,8 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
             // that would each run a whole row block's length on an otherwise idle chip) is split into column chunks
             // and its W rule applied from the slabs
             launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4 - c->tail_wg);
+            EventPair evt{};
+            if (c->profiling) evt = begin_event(c, c->ev_tail);
             RowPass4Args t4 = a4;
             t4.base.wg0 = grid4 - c->tail_wg;
             t4.base.rt0 = c->tail_rt0();
@@ -500,7 +504,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                                c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), c->kc,
                                (const DevState *)c->st, a.tcur, a.tnext);
             HIPCHK(hipGetLastError());
-            if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+            if (c->profiling) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
             return;
         }
         switch (mode) {
@@ -1978,6 +1982,26 @@ int klnmf_profile_read(klnmf_ctx *c, int64_t *row_n, double *row_ms, int64_t *co
         };
         total(c->ev_row, row_n, row_ms);
         total(c->ev_col, col_n, col_ms);
+    });
+}
+
+int klnmf_profile_read_tail(klnmf_ctx *c, int64_t *tail_n, double *tail_ms, int64_t *tail_rows, int reset) {
+    return guarded([&] {
+        use(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        double s = 0;
+        for (auto &e : c->ev_tail) {
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+            s += t;
+        }
+        if (tail_n) *tail_n = (int64_t)c->ev_tail.size();
+        if (tail_ms) *tail_ms = s;
+        if (tail_rows) *tail_rows = c->tail_wg > 0 ? (int64_t)(c->nrt - c->tail_rt0()) * 32 : 0;
+        if (reset) {
+            for (auto &e : c->ev_tail) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+            c->ev_tail.clear();
+        }
     });
 }
 

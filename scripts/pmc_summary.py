@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V')
+pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs')
 
 
 def short(name):
@@ -19,7 +19,8 @@ def short(name):
         mm = re.search(r'k_rowpass4?<([\d, ]+)>', name)
         if mm:
             a = [x.strip() for x in mm.group(1).split(',')]
-            base += '<KT=%s,odd=%s,mode=%s%s>' % (a[0], a[1], a[2], ',fp8 tiles' if len(a) > 6 and a[6] == '1' else '')
+            base += '<KT=%s,odd=%s,mode=%s%s%s>' % (a[0], a[1], a[2], ',fp8 tiles' if len(a) > 6 and a[6] == '1' else '',
+                                                     ',column-split' if len(a) > 5 and a[5] == '1' else '')
         else:
             mm = re.search(r'k_rowpass4?ILi(\d+)ELi(\d+)ELi(\d+)', name)
             if mm:
@@ -62,7 +63,7 @@ for k in sorted(vals):
 import json
 traffic = {}
 for kname in vals:
-    if 'k_rowpass' in kname and 'mode=0' in kname or kname.startswith('k_colpass'):
+    if 'k_rowpass' in kname and 'mode=0' in kname or kname.startswith('k_colpass') or kname.startswith('k_wrule_slabs'):
         fs = vals[kname].get('FETCH_SIZE'); ws = vals[kname].get('WRITE_SIZE')
         if fs and ws:
             traffic[kname] = {'fetch_bytes_corrected': 2 * 1024 * sum(fs) / len(fs),
