@@ -1066,6 +1066,10 @@ int klnmf_destroy(klnmf_ctx *c) {
                 double pro = 0, epi = 0;
                 for (int i = 0; i < c->nrt; ++i) { pro += (double)(hs[(size_t)i * 8 + 7] >> 32); epi += (double)(hs[(size_t)i * 8 + 7] & 0xffffffffull); }
                 std::fprintf(stderr, "[stamps4] per wave: prologue %.0f cycles, epilogue %.0f cycles\n", pro / c->nrt, epi / c->nrt);
+#ifdef KL_STAMPS2
+                std::fprintf(stderr, "[stamps4] epilogue: loss sums %.0f | old W loads landed %.0f | W rule, stores, drain %.0f\n",
+                             sum[2] / c->nrt, sum[5] / c->nrt, epi / c->nrt - sum[2] / c->nrt - sum[5] / c->nrt);
+#endif
                 std::fprintf(stderr, "[stamps4] per tile per wave (cycles): M segment %.0f | E segment %.0f | V wait %.0f | copy wait %.0f | barrier after M %.0f | barrier after E %.0f || kernel %.0f cycles, %d tiles\n",
                              sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[5] / c->nrt / tiles,
                              sum[3] / c->nrt / tiles, sum[4] / c->nrt / tiles, sum[6] / c->nrt, c->nct);

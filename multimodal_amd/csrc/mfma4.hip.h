@@ -193,10 +193,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     constexpr int IMG = KP * kRow4B;          // bytes of one dictionary tile image
     static_assert(IMG <= kObj4 && IMG % 16 == 0, "dictionary tile image size");
     constexpr int OBJ = IMG;
-    __shared__ __attribute__((aligned(16))) unsigned char h0[OBJ];
-    __shared__ __attribute__((aligned(16))) unsigned char h1[OBJ];
-    __shared__ __attribute__((aligned(16))) unsigned char h2[OBJ];
-    __shared__ __attribute__((aligned(16))) unsigned char h3[OBJ];
+    // one arena: the four dictionary tile objects of the main loop; after it, the waves' 32 x 32 fp32 transposition
+    // buffers of the W rule (kTLD dwords per row: conflict-free 16-byte writes of the accumulator layout)
+    constexpr int kTLD = 36;
+#ifdef KL_TAIL_SCATTERED
+    constexpr int TBUF = 0;
+#else
+    constexpr int TBUF = (MODE != ROW_LOSS && SPLIT == 0) ? NW * 32 * kTLD * 4 : 0;
+#endif
+    constexpr int ARENA = 4 * OBJ > TBUF ? 4 * OBJ : TBUF;
+    __shared__ __attribute__((aligned(16))) unsigned char arena[ARENA];
+    KL_LDS unsigned char *const h0 = (KL_LDS unsigned char *)arena, *const h1 = h0 + OBJ, *const h2 = h0 + 2 * OBJ, *const h3 = h0 + 3 * OBJ;
     __shared__ __attribute__((aligned(16))) double hsum_lds[KP];     // row sums of H, for the sum(W.H) term of the loss
     __shared__ __attribute__((aligned(16))) float tc_lds[KP], tn_lds[KP];     // per-component image scales (W rule): current, next
     if (a.st->stop) return;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
 
     auto Hobj = [&](int o) -> KL_LDS unsigned char * {      // o in 0..3 (static after unrolling)
-        return (KL_LDS unsigned char *)(o == 0 ? h0 : (o == 1 ? h1 : (o == 2 ? h2 : h3)));
+        return o == 0 ? h0 : (o == 1 ? h1 : (o == 2 ? h2 : h3));
     };
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
     // copy of dictionary tile `tg` (global index, clamped) into object o: this thread's slices
@@ -671,6 +678,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #ifdef KL_STAMPS
     unsigned long long tkL; KL_STAMP(tkL);
 #endif
+#ifndef KL_TAIL_SCATTERED
+    if (TBUF > 0) barrier();      // the W rule's transposition buffers overlay the tile objects the other waves' last M segment reads
+#endif
 
     if (!active) return;
     if (split) {
@@ -706,14 +716,87 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // rounding step of the running sum in the SAME way for every row -- sum_a colsum(W)_a (hsum_a - 1) was
         // lost or kept as a whole, +-2e-7 of sum(V) per evaluation, 1e-4 of the loss at 250000 x 12288, k = 500
         // (scripts/loss_terms_check.py; this, not operand rounding, is what tripped tol = 0 in round 1).
+        {
+            double c2[4] = {0.0, 0.0, 0.0, 0.0};      // four chains: 8 KS dependent fp64 fmas in one were 1.5 % of the kernel
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s2 = fma((double)(float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
+                for (int j = 0; j < 8; ++j) c2[j & 3] = fma((double)(float)wf[s][j], hsum_lds[16 * s + 8 * h + j], c2[j & 3]);
+            s2 += (c2[0] + c2[1]) + (c2[2] + c2[3]);
+        }
         const double s1w = wave_sum((double)s1);
         s2 = wave_sum(s2);
         if (lane == 0) a.loss_part[rt] = make_double2(s1w, s2);
     }
+#ifdef KL_STAMPS2      // experiment: where the kernel's tail goes (loss sums | W loads landed | the rest incl. the store drain)
+    unsigned long long tkA; KL_STAMP(tkA);
+#endif
+#ifndef KL_TAIL_SCATTERED
+    if (MODE != ROW_LOSS) {
+        // W rule.  The accumulators hold Q.H^T as (row r = lane & 31; components 32 m + 8 g + 4 h + t): taken as they stand,
+        // every load / store of the masters would touch 32 rows x 32 bytes (64 scattered 16-byte pieces per instruction:
+        // 20 000 + 21 000 cycles per workgroup for the old master's loads and the new one's stores, 9 % of the kernel at C4,
+        // -DKL_STAMPS2).  So each 32 x 32 block goes through the wave's own LDS buffer and comes back row-major --
+        // lane l: row 8 j + (l >> 3), components 4 (l & 7) .. + 3 -- and every global instruction moves 8 whole 128-byte
+        // lines.  All loads of the old master are issued before the first use (the operand fragments, ring and V
+        // registers of the main loop are dead here, so KT*16 registers are free): one memory round trip per wave.
+        // (For KT > 8 in blocks of 8 component tiles: the accumulators alone fill half the register file.)
+        KL_LDS float *tb = (KL_LDS float *)arena + wave * (32 * kTLD);
+        const int c4 = (lane & 7) * 4, rj = lane >> 3;
+        const int64_t row0 = (int64_t)rt * 32;
+        constexpr int MB = KT <= 8 ? KT : 8;
+#pragma unroll
+        for (int m0 = 0; m0 < KT; m0 += MB) {
+            f32x4 wold[MB][4];
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == ROW_UPDATE && m0 + mm < KT) {
+                        wold[mm][j] = *(const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) wold[mm][j][t] = 1.f;
+                    }
+                }
+            if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
+#ifdef KL_STAMPS2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            { unsigned long long tkB; KL_STAMP(tkB); ph[2] = tkA - tkL; ph[5] = tkB - tkA; }
+#endif
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm) {
+                if (m0 + mm >= KT) continue;
+                const int m = m0 + mm;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = acc[m][4 * g + t];
+                    *(KL_LDS f32x4 *)(tb + r * kTLD + 8 * g + 4 * h) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own writes, read back by other lanes
+                const f32x4 tc = *(const KL_LDS f32x4 *)(tc_lds + 32 * m + c4), tn = *(const KL_LDS f32x4 *)(tn_lds + 32 * m + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rl = 8 * j + rj, comp = 32 * m + c4;
+                    const f32x4 gq = *(const KL_LDS f32x4 *)(tb + rl * kTLD + c4);
+                    f32x4 w = wold[mm][j];
+                    opx4 wb;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        w[t] *= gq[t] * tc[t];                              // the accumulator saw the dictionary image H / t
+                        wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);      // eps carrier
+                    }
+                    *(f32x4 *)(a.W32_new + (row0 + rl) * KP + comp) = w;
+                    *(opx4 *)(a.Wb_new + (row0 + rl) * WLD + wb_col(rl, comp)) = wb;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // block m read before block m + 1 overwrites it
+            }
+            if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
     if (MODE != ROW_LOSS) {
         // W rule.  All loads of the old fp32 master are issued before the first use (the operand fragments,
         // ring and V registers of the main loop are dead here, so KT*16 registers are free): one memory round
@@ -738,6 +821,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     }
                 }
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
+#ifdef KL_STAMPS2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            { unsigned long long tkB; KL_STAMP(tkB); ph[2] = tkA - tkL; ph[5] = tkB - tkA; }
+#endif
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
@@ -759,6 +846,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
         }
     }
+#endif
 #ifdef KL_STAMPS
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
