@@ -160,6 +160,9 @@ __device__ __forceinline__ void lds_wait(opx8 &v) {
 #ifndef KL_STATIC_PRIO
 #define KL_STATIC_PRIO 1
 #endif
+#ifndef KL_TAIL_EARLY
+#define KL_TAIL_EARLY 3      // component blocks of the old master requested before the loss sums (k_rowpass4's tail)
+#endif
 // Q8: the ratio tiles left for the column pass are fp8 (e4m3, saturating) instead of the 16-bit MFMA operands: 1 KiB per
 // 32 x 32 tile, row-major [row i][16 h' + 4 g + t] = column 8 g + 4 h' + t -- each lane's 16 values are 16 contiguous
 // bytes at 16 (2 i + h'), one store per lane and tile.  Only the H numerator (a sum over ALL rows) sees these 4-bit
@@ -708,6 +711,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             }
         return;
     }
+    // W rule, first loads: the old master's rows for the first MB1 component blocks are requested BEFORE the loss sums
+    // (6 800 cycles of fp64 arithmetic and lane reductions that touch no memory), the rest after them -- the register file
+    // holds the accumulators (16 KT), these (16 MB1) and the W fragments the loss sums still read (4 KS).
+#if defined(KL_TAIL_SCATTERED) || defined(KL_TAIL_LATE_LOADS)
+    constexpr int MB1 = 0;
+#else
+    constexpr int MB1 = (MODE == ROW_UPDATE && KT <= 8) ? (KT < KL_TAIL_EARLY ? KT : KL_TAIL_EARLY) : 0;
+#endif
+    f32x4 wold_e[MB1 > 0 ? MB1 : 1][4];
+    if constexpr (MB1 > 0) {
+        const int c4e = (lane & 7) * 4, rje = lane >> 3;
+#pragma unroll
+        for (int mm = 0; mm < MB1; ++mm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wold_e[mm][j] = *(const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (MODE != ROW_INIT) {
         // sum over this wave's rows of (W.H) = sum_c W[row][c] * hsum[c]; hsum from LDS (staged in the prologue:
         // read from global memory here it was KS dependent round trips on the kernel's tail).  In DOUBLE: the rows
@@ -716,14 +737,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // rounding step of the running sum in the SAME way for every row -- sum_a colsum(W)_a (hsum_a - 1) was
         // lost or kept as a whole, +-2e-7 of sum(V) per evaluation, 1e-4 of the loss at 250000 x 12288, k = 500
         // (scripts/loss_terms_check.py; this, not operand rounding, is what tripped tol = 0 in round 1).
-        {
-            double c2[4] = {0.0, 0.0, 0.0, 0.0};      // four chains: 8 KS dependent fp64 fmas in one were 1.5 % of the kernel
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) c2[j & 3] = fma((double)(float)wf[s][j], hsum_lds[16 * s + 8 * h + j], c2[j & 3]);
-            s2 += (c2[0] + c2[1]) + (c2[2] + c2[3]);
-        }
+            for (int j = 0; j < 8; ++j) s2 = fma((double)(float)wf[s][j], hsum_lds[16 * s + 8 * h + j], s2);
         const double s1w = wave_sum((double)s1);
         s2 = wave_sum(s2);
         if (lane == 0) a.loss_part[rt] = make_double2(s1w, s2);
@@ -752,7 +769,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (MODE == ROW_UPDATE && m0 + mm < KT) {
+                    if (MODE == ROW_UPDATE && m0 + mm < MB1) {
+                        wold[mm][j] = wold_e[mm][j];                 // requested before the loss sums
+                    } else if (MODE == ROW_UPDATE && m0 + mm < KT) {
                         wold[mm][j] = *(const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4);
                     } else {
 #pragma unroll
