@@ -36,6 +36,12 @@ constexpr int kQTile8 = 1024;                    // bytes of one 32 x 32 fp8 rat
 #ifndef KL_COLQ_NB
 #define KL_COLQ_NB 4
 #endif
+#ifndef KL_COLQ8_PAIR       // fp8 ratio tiles (24 KiB objects at KT = 7): stages per fence and objects
+#define KL_COLQ8_PAIR 1
+#endif
+#ifndef KL_COLQ8_NB
+#define KL_COLQ8_NB (KL_COLQ8_PAIR == 2 ? 6 : 4)
+#endif
 
 __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
@@ -46,7 +52,10 @@ __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
 // (probed: experiments/micro/fp8_probe.hip), four v_cvt_scalef32_pk_f16_fp8 make the B operand of k-step s, the W_new
 // fragments are read in the same row order (8 h + t, 8 h + 4 + t), and the accumulator of lane l belongs to the LOGICAL
 // column 8 g + 4 h' + t of its physical column 16 h' + 4 g + t.
-template <int KT, int NB, int KSPLIT = 1, int Q8 = 0>
+// PAIR = 2: two 32-row stages per fence (copies of the next PAIR stages issued, PAIR stages computed, then ONE counted wait +
+// barrier): half the workgroup barriers per row; NB (even) objects hold NB / 2 such pairs, one pair in flight behind the
+// pair being computed.
+template <int KT, int NB, int KSPLIT = 1, int Q8 = 0, int PAIR = 1>
 __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     static_assert(kWavesPerWG == 8 && (KSPLIT == 1 || KSPLIT == 2) && KT % KSPLIT == 0, "wave decomposition");
     static_assert(Q8 == 0 || (KSPLIT == 1 && sizeof(opnd_t) == 2), "fp8 ratio tiles: one wave per column tile");
@@ -62,13 +71,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     constexpr int QP = Q8 ? 1 : 2 / KSPLIT;        // 1 KiB pieces of its column tile's ratio tile a wave copies
     constexpr int OPS = WA / kGldsRound + QP;      // copy instructions per wave and stage
     constexpr int N3 = 2 * KTW;
-    static_assert(NB >= 3 && NB <= 5 && NB * OBJ <= 160 * 1024, "LDS budget");
+    static_assert(NB >= 3 && NB <= 6 && NB * OBJ <= 160 * 1024, "LDS budget");
     static_assert((NB - 2) * OPS <= 63, "vmcnt range");
+    static_assert(PAIR == 1 || (PAIR == 2 && NB % 2 == 0 && NB >= 4), "stage pairs");
     __shared__ __attribute__((aligned(16))) unsigned char o0[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char o1[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char o2[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char o3[NB > 3 ? OBJ : 16];
     __shared__ __attribute__((aligned(16))) unsigned char o4[NB > 4 ? OBJ : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char o5[NB > 5 ? OBJ : 16];
     if (a.st->stop) return;
 #ifdef KL_COL_PRIO       // experiment: static priority for the second-dispatched half of the workgroup
     if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(KL_COL_PRIO);
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
                                  : a.Qt + (int64_t)ct * a.nrt * QTB + (lane & 1) * 1024 + ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
 
     auto obj = [&](int o) -> KL_LDS unsigned char * {      // o static after unrolling
-        return (KL_LDS unsigned char *)(o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o == 3 ? o3 : o4);
+        return (KL_LDS unsigned char *)(o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o == 3 ? o3 : o == 4 ? o4 : o5);
     };
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
     auto stage_in = [&](int o, int sg) {
@@ -179,21 +190,27 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
         });
     };
-    auto fence = [&]() {          // my copies of the next stage have landed; then everybody's
+    auto fence = [&]() {          // my copies of the next stage (pair of stages) have landed; then everybody's
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * OPS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2 * PAIR) * OPS) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // prologue: stages sbeg .. sbeg+NB-2 in flight, the first one awaited
-    static_for<0, NB - 1>([&](auto I) { stage_in(decltype(I)::value, sbeg + decltype(I)::value); });
+    // prologue: stages sbeg .. sbeg+NB-PAIR-1 in flight, the first one (pair) awaited
+    static_for<0, NB - PAIR>([&](auto I) { stage_in(decltype(I)::value, sbeg + decltype(I)::value); });
     fence();
     for (int s0 = sbeg; s0 < send; s0 += NB) {
-        static_for<0, NB>([&](auto I) {
-            constexpr int i = decltype(I)::value;
+        static_for<0, NB / PAIR>([&](auto I) {
+            constexpr int i = PAIR * decltype(I)::value;
             if (s0 + i < send) {                                   // uniform
-                stage_in((i + NB - 1) % NB, s0 + i + NB - 1);
+                static_for<0, PAIR>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    stage_in((i + NB - PAIR + u) % NB, s0 + i + NB - PAIR + u);
+                });
                 compute(lds_addr(obj(i)));
+                if constexpr (PAIR == 2) {
+                    if (s0 + i + 1 < send) compute(lds_addr(obj((i + 1) % NB)));
+                }
                 fence();
             }
         });

@@ -546,7 +546,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     if (c->profiling) ev = begin_event(c, c->ev_col);
 #define KL_COLQ_CASE(KTV)                                                                                          \
     case KTV:                                                                                                      \
-        if (c->q8()) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        if (c->q8()) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ8_NB, 1, 1, KL_COLQ8_PAIR>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
         else if (c->col_gen == 3) hipLaunchKernelGGL((k_colpass_q<KTV>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
         else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
         break;

@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
-CASES = [(3000, 520, 200, 4), (70000, 256, 200, 3), (2100, 4096, 500, 3), (520, 1030, 200, 5)]
+CASES = [(3000, 520, 200, 4), (70000, 256, 200, 5), (2100, 4096, 500, 3), (520, 1030, 200, 5)]
 
 
 def main():
