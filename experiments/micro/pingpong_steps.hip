@@ -17,6 +17,8 @@
 //   1024 NOCVT the stored 16 bytes are the first half of the packed fp16 ratios (no fp8 conversions)    2048 NOSTORE conversions only
 //   4096 BATCH2 VMEM batched: V loads and dictionary copies for two tiles issued every second E segment, vmcnt(0) only there
 //   8192 VSMALL V tiles re-read from 4 slots per wave (cache hits)
+//   16384 SPREAD the E segment's memory instructions issued between quarters of its arithmetic instead of ahead of it
+//   32768 MVM  memory instructions + fp8 conversions in the M segment (between its MFMAs), vmcnt(0) at its start; E arithmetic only
 //   512 NOWAIT no s_waitcnt vmcnt(0) at the start of E (only meaningful without VLD / DMA: isolates issue cost from the wait)
 // build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o pingpong_steps pingpong_steps.hip
 #include <hip/hip_runtime.h>
@@ -58,7 +60,7 @@ template <int F>
 __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht, const unsigned char *vt, unsigned char *qt,
                                             int iters, float seed) {
     constexpr bool BAR = F & 1, DMA = F & 2, VLD = F & 4, QST = F & 8, DEP = F & 16, PRIO = F & 32, TR = F & 64;
-    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192;
+    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192, SPREAD = F & 16384, MVM = F & 32768;
     __shared__ __attribute__((aligned(16))) unsigned char img[4 * kObj + 32768];      // ring of 4 objects (+ pad: one WG per CU)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,8 +95,31 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
                                                  (LDSP unsigned *)(img + o * kObj + r * 8192 + wave * 1024), 16, 0, 0);
         }
     };
+    u4 qpk = {0u, 0u, 0u, 0u};
+    // MVM: the wave's memory instructions and the fp8 conversions of the previous tile's ratios live in the M segment
+    // (vmcnt(0) at its start covers what the previous M segment issued, a whole interval ago); E is arithmetic only
+    auto m_cvt_store = [&](int it) {
+        if (!QST) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const h8 &src = j < 2 ? b0 : b1;
+            const int o = 4 * (j & 1);
+            s2v w = {0, 0};
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o], src[o + 1]}, 8.f, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o + 2], src[o + 3]}, 8.f, true);
+            qpk[j] = __builtin_bit_cast(unsigned, w);
+        }
+        if (it > 0) __builtin_nontemporal_store(qpk, (u4 *)(qlane + (int64_t)(it - 1) * 1024));
+    };
+    auto m_vload = [&](int slot, int it) {
+        if (!VLD) return;
+        const unsigned char *p = vlane + (int64_t)min(it + 1, iters - 1) * 2048;
+        va[slot] = *(const h8 *)p;
+        vb[slot] = *(const h8 *)(p + 16);
+    };
     auto seg_M = [&](auto TS, int it) {
         constexpr int ts = decltype(TS)::value;
+        if (MVM) asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[ts & 1]), "+v"(vb[ts & 1])::"memory");
         const unsigned ra = lbase + (DMA ? ((ts + 3) % 4) * kObj : 0);
         const unsigned ta = (TR ? tbase : lbase) + (DMA ? (ts % 4) * kObj : 0);
         auto issue = [&](auto P) {
@@ -119,42 +144,55 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
                 if constexpr (DEP) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], d, 0, 0, 0);
                 else acc[(p - N2) % 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], acc[(p - N2) % 7], 0, 0, 0);
             }
+            if constexpr (MVM && (p == 3 || p == 9 || p == 16)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (p == 3) m_cvt_store(it);
+                if constexpr (p == 9) m_vload((ts + 1) & 1, it);
+                if constexpr (p == 16) dma((ts + 2) % 4, it + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
         __builtin_amdgcn_sched_barrier(0);
         if (BAR && grpY) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     };
-    u4 qpk = {0u, 0u, 0u, 0u};
     auto seg_E = [&](auto TS, int it) {
         constexpr int ts = decltype(TS)::value;
         h8 &xa = va[BATCH2 ? ts : (ts & 1)], &xb = vb[BATCH2 ? ts : (ts & 1)];
         if (BATCH2) {
             if ((ts & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[ts]), "+v"(vb[ts]), "+v"(va[ts + 1]), "+v"(vb[ts + 1])::"memory");
-        } else if (!NOWAIT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory");
+        } else if (!NOWAIT && !MVM) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa), "+v"(xb)::"memory");
+        auto vm_store = [&]() {
         if (QST && NOSTORE) asm volatile("" ::"v"(qpk));
-        else if (QST && it > 0) {
-            u4 *qp = (u4 *)(qlane + (int64_t)(QSMALL ? ((it - 1) & 3) : (it - 1)) * 1024);
-            if (PLAIN) *qp = qpk;
-            else __builtin_nontemporal_store(qpk, qp);
-        }
-        if (VLD && BATCH2) {
-            if ((ts & 1) == 0) {
-#pragma unroll
-                for (int u = 2; u < 4; ++u) {
-                    const int tn = VSMALL ? ((it + u) & 3) : min(it + u, iters - 1);
-                    const unsigned char *p = vlane + (int64_t)tn * 2048;
-                    va[(ts + u) & 3] = *(const h8 *)p;
-                    vb[(ts + u) & 3] = *(const h8 *)(p + 16);
-                }
+            else if (QST && it > 0) {
+                u4 *qp = (u4 *)(qlane + (int64_t)(QSMALL ? ((it - 1) & 3) : (it - 1)) * 1024);
+                if (PLAIN) *qp = qpk;
+                else __builtin_nontemporal_store(qpk, qp);
             }
-        } else if (VLD) {
-            const int tn = VSMALL ? ((it + 1) & 3) : min(it + 1, iters - 1);
-            const unsigned char *p = vlane + (int64_t)tn * 2048;
-            va[(ts + 1) & 1] = *(const h8 *)p;
-            vb[(ts + 1) & 1] = *(const h8 *)(p + 16);
-        }
+        };
+        auto vm_vload = [&]() {
+        if (VLD && BATCH2) {
+                if ((ts & 1) == 0) {
+#pragma unroll
+                    for (int u = 2; u < 4; ++u) {
+                        const int tn = VSMALL ? ((it + u) & 3) : min(it + u, iters - 1);
+                        const unsigned char *p = vlane + (int64_t)tn * 2048;
+                        va[(ts + u) & 3] = *(const h8 *)p;
+                        vb[(ts + u) & 3] = *(const h8 *)(p + 16);
+                    }
+                }
+            } else if (VLD) {
+                const int tn = VSMALL ? ((it + 1) & 3) : min(it + 1, iters - 1);
+                const unsigned char *p = vlane + (int64_t)tn * 2048;
+                va[(ts + 1) & 1] = *(const h8 *)p;
+                vb[(ts + 1) & 1] = *(const h8 *)(p + 16);
+            }
+        };
+        auto vm_dma = [&]() {
         if (BATCH2) {
-            if ((ts & 1) == 0) { dma((ts + 2) % 4, it + 2); dma((ts + 3) % 4, it + 3); }
-        } else dma(grpY ? (ts + 3) % 4 : (ts + 2) % 4, it + (grpY ? 3 : 2));
+                if ((ts & 1) == 0) { dma((ts + 2) % 4, it + 2); dma((ts + 3) % 4, it + 3); }
+            } else dma(grpY ? (ts + 3) % 4 : (ts + 2) % 4, it + (grpY ? 3 : 2));
+        };
+        if (!SPREAD && !MVM) { vm_store(); vm_vload(); vm_dma(); }
         float q[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -162,21 +200,34 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
             const float rinv = __builtin_amdgcn_rcpf(d[e]);
             q[e] = __builtin_fmaf(x, rinv, eps * rinv);
             s1 = __builtin_fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
+            if (SPREAD && (e & 3) == 3) {        // the memory instructions spread over the arithmetic instead of ahead of it
+                asm volatile("" : "+v"(s1));
+                __builtin_amdgcn_sched_barrier(0);
+                if (e == 3) vm_store();
+                if (e == 7) vm_vload();
+                if (e == 11) vm_dma();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        h8 n0, n1;
+        // packed as the kernel's compiler output has it: one v_cvt_pk_f16_f32 per pair, the fp8 conversions from those registers
+        u4 p0, p1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { n0[j] = (_Float16)q[j]; n1[j] = (_Float16)q[8 + j]; }
+        for (int j = 0; j < 4; ++j) {
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0[j]) : "v"(q[2 * j]), "v"(q[2 * j + 1]));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1[j]) : "v"(q[8 + 2 * j]), "v"(q[8 + 2 * j + 1]));
+        }
+        const h8 n0 = __builtin_bit_cast(h8, p0), n1 = __builtin_bit_cast(h8, p1);
         if (DEP) { b0 = n0; b1 = n1; }
         else { asm volatile("" ::"v"(n0), "v"(n1)); }
-        if (QST && NOCVT) qpk = __builtin_bit_cast(u4, n0);
-        else if (QST) {
+        if (QST && NOCVT) qpk = p0;
+        else if (QST && !MVM) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const h8 &src = DEP ? (j < 2 ? b0 : b1) : (j < 2 ? n0 : n1);      // as the kernel: from the live MFMA operands
-                const int o = 4 * (j & 1);
+                const u4 &src = j < 2 ? p0 : p1;
+                const int o = 2 * (j & 1);
                 s2v w = {0, 0};
-                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o], src[o + 1]}, 8.f, false);
-                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o + 2], src[o + 3]}, 8.f, true);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, __builtin_bit_cast(h2, src[o]), 8.f, false);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, __builtin_bit_cast(h2, src[o + 1]), 8.f, true);
                 qpk[j] = __builtin_bit_cast(unsigned, w);
             }
         }
@@ -259,6 +310,9 @@ int main() {
     report<95 + 8192>("all, V from cache");
     report<95 + 8192 + 256>("all, V from cache, ratio tiles into cache");
     report<95 + 4096 + 1024>("all batched, store without conversions");
+    report<95 + 16384>("all, memory instructions spread over E");
+    report<95 + 32768>("all, memory instructions and conversions in M");
+    report<95 + 32768 + 32>("all, memory instructions in M, priority for Y");
     report<95 + 128>("all, plain stores");
     report<95 + 256>("all, nt stores into 4 slots");
     return 0;
