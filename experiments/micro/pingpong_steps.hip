@@ -18,6 +18,7 @@
 //   4096 BATCH2 VMEM batched: V loads and dictionary copies for two tiles issued every second E segment, vmcnt(0) only there
 //   8192 VSMALL V tiles re-read from 4 slots per wave (cache hits)
 //   16384 SPREAD the E segment's memory instructions issued between quarters of its arithmetic instead of ahead of it
+//   65536 MCV  only the fp8 conversions of the previous tile's ratios in M (E stores the result)
 //   32768 MVM  memory instructions + fp8 conversions in the M segment (between its MFMAs), vmcnt(0) at its start; E arithmetic only
 //   512 NOWAIT no s_waitcnt vmcnt(0) at the start of E (only meaningful without VLD / DMA: isolates issue cost from the wait)
 // build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o pingpong_steps pingpong_steps.hip
@@ -60,7 +61,7 @@ template <int F>
 __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht, const unsigned char *vt, unsigned char *qt,
                                             int iters, float seed) {
     constexpr bool BAR = F & 1, DMA = F & 2, VLD = F & 4, QST = F & 8, DEP = F & 16, PRIO = F & 32, TR = F & 64;
-    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192, SPREAD = F & 16384, MVM = F & 32768;
+    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192, SPREAD = F & 16384, MVM = F & 32768, MCV = F & 65536;
     __shared__ __attribute__((aligned(16))) unsigned char img[4 * kObj + 32768];      // ring of 4 objects (+ pad: one WG per CU)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,6 +112,18 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
         }
         if (it > 0) __builtin_nontemporal_store(qpk, (u4 *)(qlane + (int64_t)(it - 1) * 1024));
     };
+    auto m_cvt = [&]() {          // MCV: only the conversions move into M (the store of the result stays at the start of E)
+        if (!QST) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const h8 &src = j < 2 ? b0 : b1;
+            const int o = 4 * (j & 1);
+            s2v w = {0, 0};
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o], src[o + 1]}, 8.f, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, h2{src[o + 2], src[o + 3]}, 8.f, true);
+            qpk[j] = __builtin_bit_cast(unsigned, w);
+        }
+    };
     auto m_vload = [&](int slot, int it) {
         if (!VLD) return;
         const unsigned char *p = vlane + (int64_t)min(it + 1, iters - 1) * 2048;
@@ -143,6 +156,11 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
                 if constexpr (p == N2 && DEP) for (int e = 0; e < 16; ++e) d[e] = 0.f;
                 if constexpr (DEP) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], d, 0, 0, 0);
                 else acc[(p - N2) % 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], acc[(p - N2) % 7], 0, 0, 0);
+            }
+            if constexpr (MCV && p == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                m_cvt();
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (MVM && (p == 3 || p == 9 || p == 16)) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
         if (DEP) { b0 = n0; b1 = n1; }
         else { asm volatile("" ::"v"(n0), "v"(n1)); }
         if (QST && NOCVT) qpk = p0;
-        else if (QST && !MVM) {
+        else if (QST && !MVM && !MCV) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const u4 &src = j < 2 ? p0 : p1;
@@ -311,6 +329,7 @@ int main() {
     report<95 + 8192 + 256>("all, V from cache, ratio tiles into cache");
     report<95 + 4096 + 1024>("all batched, store without conversions");
     report<95 + 16384>("all, memory instructions spread over E");
+    report<95 + 65536>("all, only the fp8 conversions in M");
     report<95 + 32768>("all, memory instructions and conversions in M");
     report<95 + 32768 + 32>("all, memory instructions in M, priority for Y");
     report<95 + 128>("all, plain stores");
