@@ -142,7 +142,23 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
                                              (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
         }
     };
-    auto compute = [&](unsigned base) {
+    // one copy instruction of stage sg into object o (the order stage_in issues them in: W_new rounds, then ratio pieces)
+    constexpr int WR = WA / kGldsRound;
+    static_assert(WR + QP == OPS, "copy instructions per wave and stage");
+    auto piece = [&](int o, int sg, auto I) {
+        constexpr int i = decltype(I)::value;
+        sg = min(sg, send - 1);
+        if constexpr (i < WR) {
+            __builtin_amdgcn_global_load_lds((const KL_GLB void *)(wn + (int64_t)sg * WST + i * kGldsRound + tid * 16),
+                                             (KL_LDS void *)(obj(o) + i * kGldsRound + (tid & ~63) * 16), 16, 0, 0);
+        } else {
+            const int p = kh * QP + (i - WR);
+            __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qt + (int64_t)sg * QTB + p * 256),
+                                             (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
+        }
+    };
+    // o_next >= 0: the copies of stage sg_next into object o_next are issued BETWEEN this stage's MFMAs (KL_COLQ_INTERLEAVE)
+    auto compute = [&](unsigned base, int o_next = -1, int sg_next = 0) {
         opx8 ring[3];
         s16x4 q0, q1, q2, q3;
         if constexpr (Q8 != 0) {                   // q0 / q2: the 8 fp8 values of k-step 0 / 1 (two dwords each)
@@ -188,6 +204,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             constexpr int younger = (j + 2 < N3 ? 2 : N3 - 1 - j);      // fragments issued after fragment j
             lds_wait<2 * younger>(ring[j % 3]);
             acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+#ifdef KL_COLQ_INTERLEAVE
+            static_for<0, OPS>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int pos = (i * N3) / OPS < N3 - 1 ? (i * N3) / OPS : N3 - 1;
+                if constexpr (pos == j) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (o_next >= 0) piece(o_next, sg_next, I);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+#endif
         });
     };
     auto fence = [&]() {          // my copies of the next stage (pair of stages) have landed; then everybody's
@@ -203,11 +230,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         static_for<0, NB / PAIR>([&](auto I) {
             constexpr int i = PAIR * decltype(I)::value;
             if (s0 + i < send) {                                   // uniform
+#ifdef KL_COLQ_INTERLEAVE
+                if constexpr (PAIR == 1) compute(lds_addr(obj(i)), (i + NB - 1) % NB, s0 + i + NB - 1);
+                else
+#endif
+                {
                 static_for<0, PAIR>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     stage_in((i + NB - PAIR + u) % NB, s0 + i + NB - PAIR + u);
                 });
                 compute(lds_addr(obj(i)));
+                }
                 if constexpr (PAIR == 2) {
                     if (s0 + i + 1 < send) compute(lds_addr(obj((i + 1) % NB)));
                 }
