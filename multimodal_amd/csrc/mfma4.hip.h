@@ -235,7 +235,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     if (MODE != ROW_INIT) {
         const opnd_t *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
 #pragma unroll
+#ifdef KL_ABL_WFLIN       // ablation build: the wave's W fragments read linearly (whole lines; wrong lanes, finite data; timing only)
+        for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(a.Wb_old + (int64_t)rt * 32 * WLD + (s * 64 + lane) * 8);
+#else
         for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(wrow + wb_col(r, 16 * s + 8 * h));
+#endif
     }
     f32x16 acc[KT];
 #pragma unroll
