@@ -107,22 +107,25 @@ __device__ __forceinline__ void lds_read_tr_pair(opx8 &dst, unsigned addr0, unsi
 // waits are only valid among operations of one kind -- global_load_lds copies (L2 hits) overtake older
 // VGPR loads (HBM), so "all but the newest N" does not mean the older V load has landed.  The row pass
 // therefore waits vmcnt(0) once per E segment and lets the compiler place the waits of these loads.
-__device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p) {
-    a = *(const f16x8 *)p;
-    b = *(const f16x8 *)(p + 16);
+// p: wave-uniform (scalar) address of the tile, off: this lane's byte offset -- the form the compiler turns into
+// `global_load_dwordx4 v, v_off, s[base]` (no 64-bit VALU address arithmetic in the epilogue segment)
+__device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p, unsigned off) {
+    a = *(const f16x8 *)(p + off);
+    b = *(const f16x8 *)(p + off + 16);
 }
 // global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
 template <int BYTES, int NW = kWaves4>
 __device__ __forceinline__ void glds_copy_exact(const unsigned char *gsrc, KL_LDS unsigned char *ldst, int tid) {
     constexpr int kRound4 = NW * 1024;       // bytes one round of the NW-wave workgroup moves
     constexpr int FULL = BYTES / kRound4, REM = BYTES % kRound4;
-    const int wave_base = (tid & ~63) * 16;
+    const unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 1024u;      // scalar: M0 without a VALU detour
+    const unsigned t16 = (unsigned)tid * 16u;                                                    // zero-extended lane offset: saddr form
 #pragma unroll
     for (int r = 0; r < FULL; ++r)
-        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kRound4 + tid * 16),
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kRound4 + t16),
                                          (KL_LDS void *)(ldst + r * kRound4 + wave_base), 16, 0, 0);
     if (REM > 0 && tid * 16 < REM)
-        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + FULL * kRound4 + tid * 16),
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + FULL * kRound4 + t16),
                                          (KL_LDS void *)(ldst + FULL * kRound4 + wave_base), 16, 0, 0);
 }
 
@@ -159,6 +162,13 @@ __device__ __forceinline__ void lds_wait(opx8 &v) {
 // the epilogue is the smaller part).
 #ifndef KL_STATIC_PRIO
 #define KL_STATIC_PRIO 1
+#endif
+#ifndef KL_SADDR
+#ifdef KL_NO_SADDR
+#define KL_SADDR 0
+#else
+#define KL_SADDR 5     // bit 0: dictionary copies, bit 2: fp8 ratio store -- as asm statements with scalar base + lane offset
+#endif
 #endif
 #ifndef KL_TAIL_EARLY
 #define KL_TAIL_EARLY 3      // component blocks of the old master requested before the loss sums (k_rowpass4's tail)
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     if (a.st->stop) return;
     KL_FP16_SATURATE();
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar
     const int r = lane & 31, h = lane >> 5;
     const bool grpY = kWaves4 == 8 && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;     // wave-uniform (SGPR)
     // Static priority for the second-dispatched half of the workgroup (the arbitration loser on every segment otherwise:
@@ -270,7 +280,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         if (tg > 4) tg = 4;
 #endif
         tg = min(tg, a.nct - 1);
+#if !(KL_SADDR & 1)
         glds_copy_exact<IMG, NW>(ht + (int64_t)tg * IMG, Hobj(o), tid);
+#else
+        // scalar base + this lane's 32-bit offset, LDS destination (M0) from scalars: no VALU address arithmetic in the
+        // epilogue segment (hipcc makes a 64-bit per-lane pointer of the builtin's operand: v_mad_i64_i32 + v_readfirstlane)
+        constexpr int kRound4 = NW * 1024, FULL = IMG / kRound4, REM = IMG % kRound4;
+        const unsigned char *gbase = ht + (int64_t)tg * IMG;
+        const unsigned m0b = lds_addr(Hobj(o)) + (unsigned)wave * 1024u, t16 = (unsigned)tid * 16u;
+#pragma unroll
+        for (int rr = 0; rr < FULL; ++rr)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0b + rr * kRound4), "v"(t16), "s"(gbase + rr * kRound4) : "memory");
+        if (REM > 0 && wave * 1024 < REM)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0b + FULL * kRound4), "v"(t16), "s"(gbase + FULL * kRound4) : "memory");
+#endif
     };
     // one round (this thread's 16 bytes of every NW KiB) of the copy of dictionary tile tg into object o: the FUSED
     // order issues the rounds one per MFMA instead of back to back (a lone wave's VMEM issue is not covered by a partner)
@@ -286,10 +309,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         unsigned t16 = tid * 16;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(t16), "s"(gbase) : "memory");
     };
-    const unsigned char *vlane = vt + lane * 32;             // this lane's 32 bytes of a V tile
+    const unsigned vl32 = (unsigned)lane * 32u;              // this lane's 32 bytes of a V tile (vt is wave-uniform)
     // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
-    unsigned char *qlane = (a.Qt && active) ? (Q8 ? a.Qt + (int64_t)rt * 1024 + (2 * (lane & 31) + (lane >> 5)) * 16
-                                                  : a.Qt + (int64_t)rt * 2048 + lane * 16) : nullptr;
+    // ratio tiles: wave-uniform base (tiles of one column tile are consecutive in rt) + this lane's 16-byte piece(s)
+    const bool qon = a.Qt != nullptr && active;                                      // scalar
+    unsigned char *const qbase = a.Qt + (int64_t)rt * (Q8 ? 1024 : 2048);
+    const unsigned ql32 = Q8 ? (unsigned)(2 * (lane & 31) + (lane >> 5)) * 16u : (unsigned)lane * 16u;
     const int64_t qstride = (int64_t)a.nrt * (Q8 ? 1024 : 2048);
     f16x8 vreg[4];                                           // V tiles of even / odd column tiles (2 x 16 B each)
     // segment boundary: nothing may be scheduled across it (the MFMAs of an M segment must not sink into the
@@ -381,12 +406,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // the ratios of tile tg as packed in b0 / b1, for the column pass (k_colpass_q2): written once, read once by
     // another kernel -> non-temporal
     auto store_q2 = [&](int tg, const opx8 &b0, const opx8 &b1) {
-        if (MODE == ROW_UPDATE && qlane) {
+        if (MODE == ROW_UPDATE && qon) {
 #ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
-            unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
+            unsigned char *qp = qbase + (int64_t)(tg & 3) * qstride + ql32;
 #else
-            unsigned char *qp = qlane + (int64_t)tg * qstride;
+            unsigned char *qp = qbase + (int64_t)tg * qstride + ql32;
 #endif
+            unsigned char *const qp_s = qbase + (int64_t)tg * qstride;      // the wave-uniform part (saddr form of the store)
+            (void)qp; (void)qp_s;
             if constexpr (Q8 != 0) {
 #ifndef KL_OPND_BF16
                 // from the packed halves (the fp32 ratios are gone by the time the tile leaves): 8 conversions, 2 values each
@@ -402,7 +429,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, kQ8Scale, true);
                     pk[j] = __builtin_bit_cast(unsigned, w);
                 }
+#if !(KL_SADDR & 4)
                 __builtin_nontemporal_store(pk, (u32x4 *)qp);
+#else
+                // (a VALU write of the data registers of a store wider than 8 bytes needs a wait state after its issue:
+                // hipcc pads its own stores, nobody pads an asm statement -- cf. DESIGN.md section 8, h4 and h9 vii)
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp_s) : "memory");
+#endif
 #endif
                 return;
             }
@@ -417,11 +450,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     };
     auto store_q = [&](int tg) { store_q2(tg, b0, b1); };
     auto store_q_half = [&](int tg, const opx8 &b, int off) {
-        if (MODE == ROW_UPDATE && qlane) {
+        if (MODE == ROW_UPDATE && qon) {
 #ifdef KL_ABL_QSMALL
-            unsigned char *qp = qlane + (int64_t)(tg & 3) * qstride;
+            unsigned char *qp = qbase + (int64_t)(tg & 3) * qstride + ql32;
 #else
-            unsigned char *qp = qlane + (int64_t)tg * qstride;
+            unsigned char *qp = qbase + (int64_t)tg * qstride + ql32;
 #endif
             __builtin_nontemporal_store(b, (opx8 *)(qp + off));
         }
@@ -449,9 +482,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         if (tg > ct0) store_q(tg - 1);
 #endif
 #ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
-        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)((tg + 1) & 3) * TB);
+        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)((tg + 1) & 3) * TB, vl32);
 #else
-        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vlane + (int64_t)min(tg + 1, a.nct - 1) * TB);
+        // (these stay compiler loads: as asm statements with register outputs -- scalar base + lane offset, one VALU
+        // instruction less per tile -- they gave wrong results at 70 000 rows: nothing keeps the compiler from touching an
+        // asm output before the data lands; and a pointer passed through an asm statement comes back as a FLAT one)
+        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)min(tg + 1, a.nct - 1) * TB, vl32);
 #endif
         if (grpY) dma((ts + 3) % 4, tg + 3);
         else dma((ts + 2) % 4, tg + 2);
@@ -600,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             constexpr int n_rd = D - n_tr;                                             // younger row reads of the next interval
             if constexpr (sI == 0) mfma1_first_w<2 * n_tr + n_rd>(d, ring[(N2 + sI) % R], wf[0]);
             else mfma1_acc_w<2 * n_tr + n_rd>(d, ring[(N2 + sI) % R], wf[sI]);
-            if constexpr (sI == 1) v_tile_load(va, vb, vlane + (int64_t)min(tg + 2, a.nct - 1) * TB);
+            if constexpr (sI == 1) v_tile_load(va, vb, vt + (int64_t)min(tg + 2, a.nct - 1) * TB, vl32);
             if constexpr (sI >= 3 && (sI - 3) % 3 == 0 && (sI - 3) / 3 < kRounds)
                 dma_round((ts + 2) % 4, tg + 2, std::integral_constant<int, (sI - 3) / 3>{});
             if constexpr (sI == N1 - 4) store_q_half(tg, c0, 0);
@@ -618,8 +654,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // ---- prologue: dictionary tiles 0 and 1 and V tile 0 in flight; the object of "tile -1" zero-filled
     dma(0, ct0);
     dma(1, ct0 + 1);
-    v_tile_load(vreg[0], vreg[1], vlane + (int64_t)ct0 * TB);
-    if constexpr (FUSED) v_tile_load(vreg[2], vreg[3], vlane + (int64_t)min(1, a.nct - 1) * TB);
+    v_tile_load(vreg[0], vreg[1], vt + (int64_t)ct0 * TB, vl32);
+    if constexpr (FUSED) v_tile_load(vreg[2], vreg[3], vt + (int64_t)min(1, a.nct - 1) * TB, vl32);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int e = tid; e < IMG / 16; e += kThreads4) ((KL_LDS u32x4 *)h3)[e] = z;
