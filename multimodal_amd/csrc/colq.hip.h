@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(KL_COL_PRIO);
 #endif
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar
     const int r = lane & 31, h = lane >> 5;
     const int G = gridDim.x;                       // XCD-aware block -> (row chunk, column block)
     int lin = blockIdx.x;
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
 
     const unsigned char *wn = (const unsigned char *)a.Wb_new;
     // copy piece P = 64p + lane of a tile (16 bytes at LDS offset 16P): slot P>>1, operand P&1
-    const unsigned char *qt = Q8 ? a.Qt + (int64_t)ct * a.nrt * QTB + lane * 16
-                                 : a.Qt + (int64_t)ct * a.nrt * QTB + (lane & 1) * 1024 + ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+    const unsigned char *const qt_s = a.Qt + (int64_t)ct * a.nrt * QTB;       // wave-uniform part
+    const unsigned ql32 = Q8 ? (unsigned)lane * 16u : (unsigned)((lane & 1) * 1024 + ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16);
+    const unsigned char *qt = qt_s + ql32;
 
     auto obj = [&](int o) -> KL_LDS unsigned char * {      // o static after unrolling
         return (KL_LDS unsigned char *)(o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o == 3 ? o3 : o == 4 ? o4 : o5);
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
     auto stage_in = [&](int o, int sg) {
         sg = min(sg, send - 1);                    // past the end: re-copy the last stage (uniform instruction count)
+#if !(KL_SADDR & 1)
         glds_copy_exact<WA, kWavesPerWG>(wn + (int64_t)sg * WST, obj(o), tid);
         const unsigned char *qs = qt + (int64_t)sg * QTB;
 #pragma unroll
@@ -141,6 +143,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + p * 256),
                                              (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
         }
+#else
+        // scalar base + this lane's 32-bit offset, M0 from scalars (mfma4.hip.h `dma`)
+        const unsigned char *wbase = wn + (int64_t)sg * WST;
+        const unsigned t16 = (unsigned)tid * 16u, m0w = lds_addr(obj(o)) + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int rr = 0; rr < WA / kGldsRound; ++rr)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w + rr * kGldsRound), "v"(t16), "s"(wbase + rr * kGldsRound) : "memory");
+        const unsigned char *qbase = qt_s + (int64_t)sg * QTB;
+#pragma unroll
+        for (int pp = 0; pp < QP; ++pp) {
+            const int p = kh * QP + pp;            // KSPLIT = 2: the two waves of a column tile copy one piece each
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + ctl * QTB + 1024 * p), "v"(ql32), "s"(qbase + p * 256) : "memory");
+        }
+#endif
     };
     // one copy instruction of stage sg into object o (the order stage_in issues them in: W_new rounds, then ratio pieces)
     constexpr int WR = WA / kGldsRound;
@@ -164,7 +180,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         if constexpr (Q8 != 0) {                   // q0 / q2: the 8 fp8 values of k-step 0 / 1 (two dwords each)
             asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(q0) : "v"(base + off_q));
             asm volatile("ds_read_b64_tr_b8 %0, %1 offset:512" : "=v"(q2) : "v"(base + off_q));
-            q1 = q0; q3 = q2;
         } else {
             lds_read_tr(q0, base + off_q);
             lds_read_tr(q1, base + off_q + 8 * 64);
@@ -179,7 +194,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         fetch(std::integral_constant<int, 0>{});
         fetch(std::integral_constant<int, 1>{});
         // the ratio reads are older than every W_new read: they have landed when fragment 0 has
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(ring[0]));
+        if constexpr (Q8 != 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q2), "+v"(ring[0]));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(ring[0]));
         opx8 b0, b1;
         if constexpr (Q8 != 0) {
 #ifndef KL_OPND_BF16
