@@ -340,6 +340,25 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = 0.f;
 
+    u32x4 pk8 = {0u, 0u, 0u, 0u};          // KL_CVT8_IN_M: the fp8 form of b0 / b1, converted at the head of the M segment
+    auto cvt8_of = [&](const opx8 &b0, const opx8 &b1) {
+        typedef __attribute__((ext_vector_type(2))) short s16x2;
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+        u32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const opx8 &src = j < 2 ? b0 : b1;
+            const int o = 4 * (j & 1);
+            s16x2 w;                          // both halves are written below: no zero-fill instruction for the tied operand
+            asm volatile("" : "=v"(w));
+#ifndef KL_OPND_BF16
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, kQ8Scale, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, kQ8Scale, true);
+#endif
+            pk[j] = __builtin_bit_cast(unsigned, w);
+        }
+        return pk;
+    };
     // Fragment P of the M segment of tile slot TS: [0,N2) MFMA-2 of the previous tile (row reads of ITS image),
     // [N2,NF) MFMA-1 of this tile (transposed reads).  ra / ta: per-lane base addresses in the two objects.
     auto issue = [&](auto P, unsigned robj, unsigned tobj) {     // robj / tobj: LDS addresses of the two tile images
@@ -369,6 +388,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #endif
         const unsigned ra = lds_addr(Hobj((ts + 3) % 4));
         const unsigned ta = lds_addr(Hobj(ts % 4));
+#ifdef KL_CVT8_IN_M       // experiment: the previous tile's fp8 conversions here, beside the packing hipcc sinks to this point
+        if constexpr (Q8 != 0) { pk8 = cvt8_of(b0, b1); asm volatile("" : "+v"(pk8)); }
+#endif
         static_for<DP, D>([&](auto P) { issue(P, ra, ta); });      // the part of the lead the E segment could not issue
         static_for<0, NF>([&](auto P) {
             constexpr int p = decltype(P)::value;
@@ -418,19 +440,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             if constexpr (Q8 != 0) {
 #ifndef KL_OPND_BF16
                 // from the packed halves (the fp32 ratios are gone by the time the tile leaves): 8 conversions, 2 values each
-                typedef __attribute__((ext_vector_type(2))) short s16x2;
-                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-                u32x4 pk;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const opx8 &src = j < 2 ? b0 : b1;
-                    const int o = 4 * (j & 1);
-                    s16x2 w;                          // both halves are written below: no zero-fill instruction for the tied operand
-                    asm volatile("" : "=v"(w));
-                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, kQ8Scale, false);
-                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, kQ8Scale, true);
-                    pk[j] = __builtin_bit_cast(unsigned, w);
-                }
+#ifdef KL_CVT8_IN_M
+                const u32x4 pk = pk8;
+#else
+                const u32x4 pk = cvt8_of(b0, b1);
+#endif
 #if !(KL_SADDR & 4)
                 __builtin_nontemporal_store(pk, (u32x4 *)qp);
 #else
@@ -527,6 +541,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         store_q(tg);          // includes stores issued half a tile interval ago: row pass 4.16 instead of 4.10 ms at C4)
 #endif
         asm volatile("" : "+v"(s1));                        // keep the loss terms inside this segment
+#ifdef KL_PACK_IN_E       // experiment: the packing conversions pinned here (hipcc otherwise sinks them to the head of the M segment)
+        asm volatile("" : "+v"(b0), "+v"(b1));
+#endif
         if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
             const unsigned ra = lds_addr(Hobj(ts % 4));
             static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
