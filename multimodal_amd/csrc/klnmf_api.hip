@@ -1732,7 +1732,9 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         void *nbuf = c->is_exact() ? c->numer : (void *)c->numerF;
         const ncclDataType_t ntype = c->prec == KLNMF_PREC_F64 ? ncclDouble : ncclFloat;
         for (int64_t it = 0; it < max_iter; ++it) {
-            piece_rowpass(c, fit);                     // leaves this rank's part of the loss in loss_xchg
+            // one rank: the stop decision rides in the loss kernel, as in klnmf_run (one launch less per iteration)
+            if (multi || c->is_exact()) piece_rowpass(c, fit);      // leaves this rank's part of the loss in loss_xchg
+            else piece_rowpass(c, fit, &tol_abs);
             if (fit) piece_colpass(c);                 // ... and of the numerator (it does not depend on the stop decision)
             if (multi) {
                 RCCLCHK(rccl().GroupStart());
@@ -1740,7 +1742,7 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
                 RCCLCHK(rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream));
                 RCCLCHK(rccl().GroupEnd());
             }
-            piece_decide(c, tol_abs);                  // identical inputs on every rank -> identical decisions
+            if (multi || c->is_exact()) piece_decide(c, tol_abs);      // identical inputs on every rank -> identical decisions
             if (fit) piece_update_H(c);
             c->cur ^= 1;
             c->iter_in_loop += 1;
