@@ -458,9 +458,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #ifdef KL_ABL_QPLAIN       // experiment: ordinary stores instead of non-temporal ones
             *(opx8 *)qp = b0;
             *(opx8 *)(qp + 1024) = b1;
-#else
+#elif !(KL_SADDR & 4)
             __builtin_nontemporal_store(b0, (opx8 *)qp);
             __builtin_nontemporal_store(b1, (opx8 *)(qp + 1024));
+#else
+            // b0 / b1 are the live MFMA-2 operands: nothing writes them before the next E segment packs the next tile
+            asm volatile("global_store_dwordx4 %0, %1, %3 nt\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 nt\n\ts_nop 1"
+                         ::"v"(ql32), "v"(b0), "v"(b1), "s"(qp_s) : "memory");
 #endif
         }
     };
@@ -472,7 +476,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
             unsigned char *qp = qbase + (int64_t)tg * qstride + ql32;
 #endif
+#if !(KL_SADDR & 4) || defined(KL_ABL_QSMALL)
             __builtin_nontemporal_store(b, (opx8 *)(qp + off));
+#else
+            (void)qp;
+            unsigned char *const qp_s = qbase + (int64_t)tg * qstride + off;      // wave-uniform
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(b), "s"(qp_s) : "memory");
+#endif
         }
     };
     // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
