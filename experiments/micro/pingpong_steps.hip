@@ -18,6 +18,7 @@
 //   4096 BATCH2 VMEM batched: V loads and dictionary copies for two tiles issued every second E segment, vmcnt(0) only there
 //   8192 VSMALL V tiles re-read from 4 slots per wave (cache hits)
 //   16384 SPREAD the E segment's memory instructions issued between quarters of its arithmetic instead of ahead of it
+//   131072 BAR2 the barrier only behind every second tile (timing only: the copies' ring would need twice the objects)
 //   65536 MCV  only the fp8 conversions of the previous tile's ratios in M (E stores the result)
 //   32768 MVM  memory instructions + fp8 conversions in the M segment (between its MFMAs), vmcnt(0) at its start; E arithmetic only
 //   512 NOWAIT no s_waitcnt vmcnt(0) at the start of E (only meaningful without VLD / DMA: isolates issue cost from the wait)
@@ -61,7 +62,7 @@ template <int F>
 __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht, const unsigned char *vt, unsigned char *qt,
                                             int iters, float seed) {
     constexpr bool BAR = F & 1, DMA = F & 2, VLD = F & 4, QST = F & 8, DEP = F & 16, PRIO = F & 32, TR = F & 64;
-    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192, SPREAD = F & 16384, MVM = F & 32768, MCV = F & 65536;
+    constexpr bool PLAIN = F & 128, QSMALL = F & 256, NOWAIT = F & 512, NOCVT = F & 1024, NOSTORE = F & 2048, BATCH2 = F & 4096, VSMALL = F & 8192, SPREAD = F & 16384, MVM = F & 32768, MCV = F & 65536, BAR2 = F & 131072;
     __shared__ __attribute__((aligned(16))) unsigned char img[4 * kObj + 32768];      // ring of 4 objects (+ pad: one WG per CU)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
             }
         });
         __builtin_amdgcn_sched_barrier(0);
-        if (BAR && grpY) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        if (BAR && grpY && (!BAR2 || (ts & 1))) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     };
     auto seg_E = [&](auto TS, int it) {
         constexpr int ts = decltype(TS)::value;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
         }
         asm volatile("" : "+v"(s1));
         __builtin_amdgcn_sched_barrier(0);
-        if (BAR && !grpY) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        if (BAR && !grpY && (!BAR2 || (ts & 1))) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     };
     if (!BAR && grpY) seg_E(std::integral_constant<int, 3>{}, 0);      // free-running: start the Y waves out of phase
     for (int t4 = 0; t4 < iters; t4 += 4)
@@ -329,6 +330,7 @@ int main() {
     report<95 + 8192 + 256>("all, V from cache, ratio tiles into cache");
     report<95 + 4096 + 1024>("all batched, store without conversions");
     report<95 + 16384>("all, memory instructions spread over E");
+    report<95 + 131072>("all, barrier behind every second tile only");
     report<95 + 65536>("all, only the fp8 conversions in M");
     report<95 + 32768>("all, memory instructions and conversions in M");
     report<95 + 32768 + 32>("all, memory instructions in M, priority for Y");
