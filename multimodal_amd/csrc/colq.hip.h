@@ -219,6 +219,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             fetch(std::integral_constant<int, j + 2>{});
             constexpr int younger = (j + 2 < N3 ? 2 : N3 - 1 - j);      // fragments issued after fragment j
             lds_wait<2 * younger>(ring[j % 3]);
+#ifdef KL_EMU_W8          // precision experiment: the W_new operand rounded to fp8 (e4m3, image / 256, saturating) as an fp8 column pass would see it
+            {
+                typedef __attribute__((ext_vector_type(2))) short s16x2_;
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+                opx8 &fr = ring[j % 3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s16x2_ w8 = {0, 0};
+                    w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, f16x2_{fr[2 * u], fr[2 * u + 1]}, 256.f, false);
+                    const f16x2_ back = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(unsigned, w8), 256.f, false);
+                    fr[2 * u] = back[0]; fr[2 * u + 1] = back[1];
+                }
+            }
+#endif
             acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
 #ifdef KL_COLQ_INTERLEAVE
             static_for<0, OPS>([&](auto I) {
