@@ -1,0 +1,247 @@
+// The column pass with fp8 on BOTH sides (KLNMF_COL8=0 switches it off).
+//
+//   numer[a][j] = sum_i W_new[i][a] * Q[i][j]      with W_new as an e4m3 image (f16 image / 256, saturating) and the fp8 ratio
+//                                                  tiles of the row pass, on v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales)
+//
+// Stage = 64 rows.  Object = [W8 rows: 64 x KP bytes, copied linearly | the 8 waves' two ratio tiles].  Per wave and stage:
+// 2 + 2 copy pieces, 4 + 4 KT transposed 8-byte LDS reads, KT MFMAs of K = 64 (64 cycles each: half the matrix time of the
+// f16 form), no conversions.  ds_read_b64_tr_b8 gives lane l (component or column l & 31 of the block, half h = l >> 5) the
+// 8 rows of its byte column; four of them are the 32 k-values 32 h .. 32 h + 31 of the A / B operand -- the hardware pairs
+// byte j of lane half h of A with byte j of lane half h of B, so any k order used for both is right.
+// The e4m3 image comes from a conversion kernel behind the row pass (k_w8_from_wb) with a measured power of two per component
+// (k_w8_scales: the previous iteration's column maxima); writing it from the W rule itself would save its 0.2 ms.
+#pragma once
+#include "colq.hip.h"
+
+namespace klnmf {
+
+// f16 W image (swizzled rows of w_ld(KP) halves) -> e4m3 image [rows][KP bytes] = image / w8s[component] (saturating), and
+// the column maxima of the f16 image for the NEXT iteration's scales (W moves slowly from one update to the next; the
+// scale leaves one binade of headroom and the conversion saturates).  Block = 8 rows x (KP / 8) threads: a thread keeps its
+// 8 components over all its rows.
+__global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
+                                                    const float *w8s, unsigned *w8max, const DevState *st) {
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    if (st->stop) return;
+    KL_FP16_SATURATE();
+    __shared__ float red[8][256 / 8 * 8];
+    const int groups = kp / 8;                       // threads per row
+    const int c8 = threadIdx.x % groups, rl = threadIdx.x / groups;
+    const int rows_per_block = blockDim.x / groups;
+    const int comp = 8 * c8;
+    f16x2 inv[4];
+    float mx[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) inv[u] = f16x2{(_Float16)(1.f / w8s[comp + 2 * u]), (_Float16)(1.f / w8s[comp + 2 * u + 1])};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx[e] = 0.f;
+    if (rl < rows_per_block) {
+        const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+        constexpr int U = 4;                          // rows in flight per thread (one dependent load per trip was latency-bound)
+        for (int64_t row0 = (int64_t)blockIdx.x * rows_per_block + rl; row0 < rows; row0 += U * stride) {
+            opx8 v[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int64_t row = row0 + q * stride;
+                if (row < rows) v[q] = *(const opx8 *)(Wb + row * wld + wb_col((int)(row & 31), comp));
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int64_t row = row0 + q * stride;
+                if (row >= rows) break;
+                unsigned out[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    s16x2 w = {0, 0};
+#ifndef KL_OPND_BF16
+                    const f16x2 p0 = f16x2{v[q][4 * u], v[q][4 * u + 1]} * inv[2 * u], p1 = f16x2{v[q][4 * u + 2], v[q][4 * u + 3]} * inv[2 * u + 1];
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p0, 1.f, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p1, 1.f, true);
+#endif
+                    out[u] = __builtin_bit_cast(unsigned, w);
+                }
+                *(uint2 *)(W8 + row * kp + comp) = make_uint2(out[0], out[1]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)v[q][e]);
+            }
+        }
+    }
+    // block maximum per component (positive floats order like their bit patterns)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[e][threadIdx.x] = mx[e];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float m = red[e][c8];
+            for (int q = 1; q < rows_per_block; ++q) m = fmaxf(m, red[e][q * groups + c8]);
+            w8max[(int64_t)blockIdx.x * kp + comp + e] = __float_as_uint(m);      // [block][component]: no atomics, reduced by k_w8_scales
+        }
+    }
+}
+
+// scales of the e4m3 image from the maxima the previous conversion measured: a power of two with image / scale <= 224
+// (e4m3 reaches 448)
+__global__ __launch_bounds__(64) void k_w8_scales(const unsigned *w8max, int nblocks, float *w8s, int kp, const DevState *st) {
+    if (st->stop) return;
+    const int c = blockIdx.x;                         // one wave per component
+    unsigned mb = 0u;
+    for (int b = threadIdx.x; b < nblocks; b += 64) mb = max(mb, w8max[(int64_t)b * kp + c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_down((int)mb, o, 64));
+    if (threadIdx.x != 0) return;
+    const float m = __uint_as_float(mb);
+    float s = 1.f;
+    if (m > 0.f) {
+        int e;
+        (void)frexpf(m / 224.f, &e);                 // m / 224 = f * 2^e, f in [0.5, 1)  ->  scale 2^e >= m / 224
+        e = e < -14 ? -14 : (e > 15 ? 15 : e);         // its reciprocal and the scaled values stay f16 numbers
+        s = ldexpf(1.f, e);
+    }
+    w8s[c] = s;
+}
+
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr8(i32x2_t &dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+struct ColPass8Args {
+    ColPassQArgs q;
+    const unsigned char *W8;      // [rows][KP] e4m3 = f16 image / w8s[component]
+    const float *w8s;             // [KP]
+};
+
+template <int KT, int NB>
+__global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
+    const ColPassQArgs &a = aa.q;
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    typedef i32x2_t i32x2;
+    constexpr int KP = 32 * KT;
+    constexpr int WST = 64 * KP;                              // bytes of W8 per 64-row stage
+    constexpr int WA = round_up(WST, kGldsRound);             // copied per stage (whole rounds)
+    constexpr int WR = WA / kGldsRound;
+    constexpr int QA = kWavesPerWG * 2 * kQTile8;             // the waves' two ratio tiles
+    constexpr int OBJ = WA + QA;
+    constexpr int OPS = WR + 2;
+    static_assert(NB >= 3 && NB <= 5 && NB * OBJ <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char o0[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char o1[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char o2[OBJ];
+    __shared__ __attribute__((aligned(16))) unsigned char o3[NB > 3 ? OBJ : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char o4[NB > 4 ? OBJ : 16];
+    if (a.st->stop) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;
+    int lin = blockIdx.x;
+    if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = lin / a.ncb, cb = lin % a.ncb;
+    const int ct_raw = cb * kWavesPerWG + wave;
+    const bool active = ct_raw < a.nct;
+    const int ct = active ? ct_raw : a.nct - 1;
+    // stages of 64 rows (the host's chunk decomposition counts 64-row stages)
+    const int sbeg = chunk * a.stages_per_chunk;
+    const int send = min(a.nrt / 2, sbeg + a.stages_per_chunk);
+    if (sbeg >= send) {
+        if (active) {
+            float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+            for (int c = h; c < KP; c += 2) np[(int64_t)c * a.f_pad] = 0.f;
+        }
+        return;
+    }
+    const int i16 = lane & 15, half = (lane >> 4) & 1;
+    // A (W8): rows 32 h + 8 u + (i16 >> 1), byte column 32 m + 16 half + 8 (i16 & 1)
+    const unsigned off_a = (32 * h + (i16 >> 1)) * KP + 16 * half + 8 * (i16 & 1);
+    // B (ratio tiles of stage rows 0..31 for h = 0, 32..63 for h = 1): row 8 u + (i16 >> 1) of tile h
+    const unsigned off_b = WA + (2 * wave + h) * kQTile8 + (i16 >> 1) * 32 + 16 * half + 8 * (i16 & 1);
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    const unsigned char *const qt_s = a.Qt + (int64_t)ct * a.nrt * kQTile8;
+    const unsigned t16 = (unsigned)tid * 16u, l16 = (unsigned)lane * 16u;
+    auto obj = [&](int o) -> KL_LDS unsigned char * {
+        return (KL_LDS unsigned char *)(o == 0 ? o0 : o == 1 ? o1 : o == 2 ? o2 : o == 3 ? o3 : o4);
+    };
+    auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
+    auto stage_in = [&](int o, int sg) {
+        sg = min(sg, send - 1);
+        const unsigned char *wbase = aa.W8 + (int64_t)sg * WST;
+        const unsigned m0w = lds_addr(obj(o)) + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int rr = 0; rr < WR; ++rr)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w + rr * kGldsRound), "v"(t16), "s"(wbase + rr * kGldsRound) : "memory");
+        const unsigned char *qbase = qt_s + (int64_t)(2 * sg) * kQTile8;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + (2 * wave + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
+    };
+    auto compute = [&](unsigned base) {
+        i32x2 bq[4];
+        static_for<0, 4>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            lds_read_tr8<u * 8 * 32>(bq[u], base + off_b);
+        });
+        i32x2 ring[2][4];
+        auto fetch = [&](auto M) {
+            constexpr int m = decltype(M)::value;
+            if constexpr (m < KT) {
+                static_for<0, 4>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    lds_read_tr8<u * 8 * KP + 32 * m>(ring[m & 1][u], base + off_a);
+                });
+            }
+        };
+        fetch(std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+        const i32x8 bo = {bq[0][0], bq[0][1], bq[1][0], bq[1][1], bq[2][0], bq[2][1], bq[3][0], bq[3][1]};
+        static_for<0, KT>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            fetch(std::integral_constant<int, m + 1>{});
+            if constexpr (m + 1 < KT) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
+            const i32x8 ao = {ring[m & 1][0][0], ring[m & 1][0][1], ring[m & 1][1][0], ring[m & 1][1][1],
+                              ring[m & 1][2][0], ring[m & 1][2][1], ring[m & 1][3][0], ring[m & 1][3][1]};
+            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[m], 0, 0, 0, 127, 0, 127);
+        });
+    };
+    auto fence = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * OPS) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    static_for<0, NB - 1>([&](auto I) { stage_in(decltype(I)::value, sbeg + decltype(I)::value); });
+    fence();
+    for (int s0 = sbeg; s0 < send; s0 += NB) {
+        static_for<0, NB>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (s0 + i < send) {
+                stage_in((i + NB - 1) % NB, s0 + i + NB - 1);
+                compute(lds_addr(obj(i)));
+                fence();
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!active) return;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t; lane's column: the LOGICAL column of physical column r (colq.hip.h);
+    // the operands were W image / w8s[component] and ratio / 8
+    const int rcol = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + rcol;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            np[(int64_t)comp * a.f_pad] = acc[m][e] * (kQ8Scale * aa.w8s[comp]);
+        }
+}
+
+}  // namespace klnmf

@@ -23,6 +23,7 @@
 #include "mfma.hip.h"
 #include "mfma4.hip.h"
 #include "colq.hip.h"
+#include "colq8x.hip.h"
 #include "probe.hip.h"
 
 using namespace klnmf;
@@ -69,6 +70,8 @@ int grid_for(int64_t count, int block = 256, int cap = 4096) {
     if (g > cap) g = cap;
     return (int)g;
 }
+
+constexpr int kW8Blocks = 1024;             // conversion kernel's grid: per-block column maxima [kW8Blocks][KP]
 
 struct EventPair {
     hipEvent_t a, b;
@@ -210,6 +213,11 @@ struct klnmf_ctx {
     // hybrid update pass (many rows): the workgroups of the last partial round run column-split (tail_chunks chunks of
     // tail_ct_chunk column tiles each) so that they fill the chip; tail_wg = 0: none.  Gpart then holds the tail's slabs.
     int tail_wg = 0, tail_chunks = 1, tail_ct_chunk = 0;
+    unsigned char *W8 = nullptr;              // e4m3 image of W_new for the fp8 x fp8 column pass (colq8x.hip.h; KLNMF_COL8=0: off)
+    unsigned *w8max = nullptr;                // [KP] column maxima of the f16 W image, measured by the conversion kernel
+    float *w8s = nullptr;                     // [KP] power-of-two scales of the e4m3 image
+    bool w8_meas = false;                     // w8max holds a measurement of this loop
+    int w8_blocks = 0;                        // blocks of the last conversion launch (rows of w8max)
     int64_t loss_parts() const {               // entries of loss_part2 an update pass writes
         if (!pingpong()) return nrt;
         if (tail_wg > 0) return (int64_t)nrt + (int64_t)(tail_chunks - 1) * (nrt - tail_rt0());
@@ -543,6 +551,51 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     a.f_pad = c->f_pad;
     const int grid = c->ncb * c->nchunks;
     EventPair ev{};
+    if (c->W8 && c->q8()) {
+        // fp8 x fp8 column pass (colq8x.hip.h).  The e4m3 image of W_new is converted behind the row pass with the scales
+        // the PREVIOUS conversion's column maxima give; a loop's first fp8 iteration only measures and runs the f16 form.
+        const bool use8 = c->w8_meas;
+        if (use8) {
+            hipLaunchKernelGGL(k_w8_scales, dim3(c->KP), dim3(64), 0, c->stream, (const unsigned *)c->w8max, c->w8_blocks,
+                               c->w8s, c->KP, (const DevState *)c->st);
+        }           // (else: w8s holds 256 from klnmf_set_problem or the last loop's scales; this image is not used)
+        {
+            const int groups = c->KP / 8, rpb = 256 / groups;
+            const int64_t rows = c->n_pad;
+            const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
+            c->w8_blocks = blocks;
+            hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
+                               c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st);
+            HIPCHK(hipGetLastError());
+        }
+        c->w8_meas = true;
+        if (use8) {
+        if (c->profiling) ev = begin_event(c, c->ev_col);
+        ColPass8Args a8{a, c->W8, c->w8s};
+        switch (c->KT) {
+#ifdef KL_DEV_BUILD
+            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+#else
+            case 1: hipLaunchKernelGGL((k_colpass_q8x<1, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 2: hipLaunchKernelGGL((k_colpass_q8x<2, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 3: hipLaunchKernelGGL((k_colpass_q8x<3, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 4: hipLaunchKernelGGL((k_colpass_q8x<4, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 5: hipLaunchKernelGGL((k_colpass_q8x<5, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 6: hipLaunchKernelGGL((k_colpass_q8x<6, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+#endif
+            default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass prototype: k <= 224");
+        }
+        HIPCHK(hipGetLastError());
+        if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+        if (!sum_slabs) return;
+        const int64_t count8 = (int64_t)c->KP * c->f_pad;
+        hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count8 / 4)), dim3(256), 0, c->stream,
+                           (const float *)c->NpartF, c->numerF, count8 / 4, c->nchunks, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        return;
+        }
+    }
     if (c->profiling) ev = begin_event(c, c->ev_col);
 #define KL_COLQ_CASE(KTV)                                                                                          \
     case KTV:                                                                                                      \
@@ -1188,6 +1241,15 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->VtA = c->dalloc(vbytes);
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
+            c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8_meas = false;
+            if (c->q8_ok && c->KT <= 7 && !(std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 0)) {
+                c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * c->KP + 32768);
+                c->w8max = (unsigned *)c->dalloc((size_t)kW8Blocks * c->KP * 4);
+                c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
+                const std::vector<float> unit8((size_t)c->KP, 256.f);
+                HIPCHK(hipMemcpyAsync(c->w8s, unit8.data(), unit8.size() * 4, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+            }
             for (int i = 0; i < 2; ++i) {
                 c->W32[i] = (float *)c->dalloc((size_t)c->n_pad * c->KP * 4);
                 c->Wb[i] = (opnd_t *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
@@ -1515,6 +1577,7 @@ static void check_v_overflow(klnmf_ctx *c) {
     // the 16-bit tiles.  KLNMF_QTILE = 8 forces the tiles on (from the third iteration), = 16 off.
     c->q8_loop = false;
     c->iter_in_loop = 0;
+    c->w8_meas = false;
     if (c->q8_ok) {
         const char *g = std::getenv("KLNMF_QTILE");
         const double mean = ds.sum_x / c->v_scale / ((double)c->n * (double)c->f);
