@@ -332,6 +332,7 @@ def main():
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         qbytes = _native.ratio_tile_bytes(n_local, k) if stored_q else 0
+        col8 = stored_q and qbytes == 1 and k <= 224 and os.environ.get('KLNMF_COL8', '1') != '0'      # fp8 x fp8 column pass (colq8x.hip.h)
         # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures.
         # Hybrid update pass: the dominant kernel is the whole-row k_rowpass4 over the full rounds of
         # workgroups (n_row rows); the column-split last partial round + its slab W rule are reported beside it.
@@ -349,7 +350,7 @@ def main():
         sched_bytes_row = alg_bytes_row + 2 * n_row * k * 2 + n_row * f * qbytes      # + 16-bit W images in/out + ratio tiles out
         sched_bytes_section = sched_bytes_row * n_local / n_row
         flops_col = 2.0 * n_local * f * k
-        sched_bytes_col = (n_local * f * qbytes + n_local * k * 2) if stored_q else (n_local * f * vbytes + 2 * n_local * k * 2)
+        sched_bytes_col = (n_local * f * qbytes + n_local * k * (1 if col8 else 2)) if stored_q else (n_local * f * vbytes + 2 * n_local * k * 2)
         t_mfma = flops_row / (PEAK_BF16_TFLOPS * 1e12)
         t_hbm = alg_bytes_row / (PEAK_HBM_GBS * 1e9)
         mfma_bound = t_mfma >= t_hbm
@@ -426,7 +427,7 @@ def main():
                     'tail_rows': n_local - n_row if hybrid else 0,
                     'algorithmic_tflops': 4.0 * n_local * f * k / (section_ms * 1e-3) / 1e12 if section_ms > 0 else None,
                     'frac_of_bf16_peak': 4.0 * n_local * f * k / (section_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if section_ms > 0 else None},
-                ('k_colpass_q2' if stored_q else 'k_colpass'): {
+                (('k_colpass_q8x' if col8 else 'k_colpass_q2') if stored_q else 'k_colpass'): {
                     'avg_launch_ms': col_ms, 'launches': prof_tot['colpass_launches'],
                     'algorithmic_tflops': flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
                     'frac_of_bf16_peak': flops_col / (col_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if col_ms > 0 else None,

@@ -34,8 +34,12 @@ if os.path.exists(os.path.join(G, 'pmc_c4', 'traffic.json')):
     main = 'k_rowpass4<KT=7,odd=1,mode=0,fp8 tiles>'
     split = 'k_rowpass4<KT=7,odd=1,mode=0,fp8 tiles,column-split>'
     slabs = [k for k in t4 if k.startswith('k_wrule_slabs')]
-    col = 'k_colpass_q2<fp8 tiles>'
+    col8 = [k for k in t4 if k.startswith('k_colpass_q8')]
+    col = col8[0] if col8 else 'k_colpass_q2<fp8 tiles>'
     kern = {main: t4[main], col: t4[col]}
+    conv = [k for k in t4 if k.startswith('k_w8')]
+    if conv:
+        kern['k_w8_from_wb'] = t4[conv[0]]
     if split in t4:
         kern[split] = t4[split]
     if slabs:
@@ -52,7 +56,7 @@ if os.path.exists(os.path.join(G, 'pmc_c4', 'traffic.json')):
                      'rows over the workgroups of the full rounds (%d rows: the roofline entry of bench.py), the column-split last '
                      'partial round and its slab W rule' % n_row,
              'kernels': kern,
-             'first_two_iterations_16_bit_tiles': {k: v for k, v in t4.items() if 'fp8' not in k and not k.startswith('k_wrule')},
+             'first_iterations_other_kernels': {k: v for k, v in t4.items() if k not in kern and not k.startswith('k_wrule')},
              'algorithmic_bytes_per_rowpass_launch': n_row * 4096 * 2 + 2 * n_row * 200 * 4,
              'iteration_hbm_bytes': sum(v['hbm_bytes_per_launch'] for v in kern.values())},
             {'workload': {'n_local': 250000, 'f': 12288, 'k': 500, 'precision': 'f16'},

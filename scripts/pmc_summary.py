@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs')
+pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs|k_w8_from_wb')
 
 
 def short(name):
@@ -63,7 +63,7 @@ for k in sorted(vals):
 import json
 traffic = {}
 for kname in vals:
-    if 'k_rowpass' in kname and 'mode=0' in kname or kname.startswith('k_colpass') or kname.startswith('k_wrule_slabs'):
+    if 'k_rowpass' in kname and 'mode=0' in kname or kname.startswith('k_colpass') or kname.startswith('k_wrule_slabs') or kname.startswith('k_w8'):
         fs = vals[kname].get('FETCH_SIZE'); ws = vals[kname].get('WRITE_SIZE')
         if fs and ws:
             traffic[kname] = {'fetch_bytes_corrected': 2 * 1024 * sum(fs) / len(fs),
