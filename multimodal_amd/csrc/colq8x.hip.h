@@ -83,15 +83,22 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
 
 // scales of the e4m3 image from the maxima the previous conversion measured: a power of two with image / scale <= 224
 // (e4m3 reaches 448)
-__global__ __launch_bounds__(64) void k_w8_scales(const unsigned *w8max, int nblocks, float *w8s, int kp, const DevState *st) {
+// column maxima of a slice of the [entries][KP] table (one thread per component: coalesced), combined by atomics
+__global__ void k_w8_reduce(const unsigned *w8max, int64_t entries, int per_block, unsigned *final_max, int kp, const DevState *st) {
     if (st->stop) return;
-    const int c = blockIdx.x;                         // one wave per component
+    const int c = threadIdx.x;
+    if (c >= kp) return;
+    const int64_t e0 = (int64_t)blockIdx.x * per_block, e1 = min(entries, e0 + per_block);
     unsigned mb = 0u;
-    for (int b = threadIdx.x; b < nblocks; b += 64) mb = max(mb, w8max[(int64_t)b * kp + c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_down((int)mb, o, 64));
-    if (threadIdx.x != 0) return;
-    const float m = __uint_as_float(mb);
+    for (int64_t e = e0; e < e1; ++e) mb = max(mb, w8max[e * kp + c]);
+    atomicMax(final_max + c, mb);
+}
+__global__ void k_w8_scales(unsigned *final_max, float *w8s, int kp, const DevState *st) {
+    if (st->stop) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= kp) return;
+    const float m = __uint_as_float(final_max[c]);
+    final_max[c] = 0u;
     float s = 1.f;
     if (m > 0.f) {
         int e;

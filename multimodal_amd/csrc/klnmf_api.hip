@@ -216,8 +216,13 @@ struct klnmf_ctx {
     unsigned char *W8 = nullptr;              // e4m3 image of W_new for the fp8 x fp8 column pass (colq8x.hip.h; KLNMF_COL8=0: off)
     unsigned *w8max = nullptr;                // [KP] column maxima of the f16 W image, measured by the conversion kernel
     float *w8s = nullptr;                     // [KP] power-of-two scales of the e4m3 image
+    unsigned *w8fin = nullptr;                // [KP] reduced maxima (zero between uses)
     bool w8_meas = false;                     // w8max holds a measurement of this loop
     int w8_blocks = 0;                        // blocks of the last conversion launch (rows of w8max)
+    bool w8_tail = false;                     // KLNMF_COL8=2: the W rule writes the e4m3 image itself (whole-row launch); the conversion
+                                              // kernel then only covers the rows of the column-split last partial round
+    bool w8_use = false;                      // this iteration's image was written with measured scales: the fp8 x fp8 pass may run
+    int64_t w8_entries = 0;                   // rows of w8max that hold this iteration's maxima
     int64_t loss_parts() const {               // entries of loss_part2 an update pass writes
         if (!pingpong()) return nrt;
         if (tail_wg > 0) return (int64_t)nrt + (int64_t)(tail_chunks - 1) * (nrt - tail_rt0());
@@ -450,6 +455,14 @@ void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
     HIPCHK(hipGetLastError());
 }
 
+void w8_make_scales(klnmf_ctx *c, int64_t entries) {
+    const int per_block = 128;
+    hipLaunchKernelGGL(k_w8_reduce, dim3((unsigned)((entries + per_block - 1) / per_block)), dim3(256), 0, c->stream,
+                       (const unsigned *)c->w8max, entries, per_block, c->w8fin, c->KP, (const DevState *)c->st);
+    hipLaunchKernelGGL(k_w8_scales, dim3(1), dim3(256), 0, c->stream, c->w8fin, c->w8s, c->KP, (const DevState *)c->st);
+    HIPCHK(hipGetLastError());
+}
+
 void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     RowPassArgs a{};
     a.VtA = c->VtA;
@@ -471,6 +484,18 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.nct = c->nct;
     a.nst = c->nst;
     a.eps = (float)(kEpsRatio * c->v_scale);
+    // fp8 x fp8 column pass with the image written by the W rule (KLNMF_COL8=2): this iteration's scales from the previous
+    // iteration's maxima first, then the row pass writes image and maxima
+    const bool w8_here = c->w8_tail && c->W8 && store_q && mode == ROW_UPDATE && c->q8() && c->pingpong() && c->row_chunks == 1;
+    if (w8_here) {
+        c->w8_use = c->w8_meas;
+        if (c->w8_meas) {
+            w8_make_scales(c, c->w8_entries);
+        }
+        a.W8 = c->W8;
+        a.w8s = c->w8s;
+        a.w8max = c->w8max;
+    }
     const int grid = (c->nrt + kWavesPerWG - 1) / kWavesPerWG;
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
@@ -512,9 +537,20 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                                c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), c->kc,
                                (const DevState *)c->st, a.tcur, a.tnext);
             HIPCHK(hipGetLastError());
+            if (w8_here) {         // the rows of the split tail: image and maxima by the conversion kernel (a few thousand rows)
+                const int groups = c->KP / 8, rpb = 256 / groups;
+                const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
+                hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
+                                   c->W8 + row0 * c->KP, rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
+                                   c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st);
+                HIPCHK(hipGetLastError());
+                c->w8_entries = t4.base.rt0 + blocks;
+                c->w8_meas = true;
+            }
             if (c->profiling) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
             return;
         }
+        if (w8_here) { c->w8_entries = c->nrt; c->w8_meas = true; }
         switch (mode) {
             case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
             case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
@@ -554,12 +590,13 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     if (c->W8 && c->q8()) {
         // fp8 x fp8 column pass (colq8x.hip.h).  The e4m3 image of W_new is converted behind the row pass with the scales
         // the PREVIOUS conversion's column maxima give; a loop's first fp8 iteration only measures and runs the f16 form.
-        const bool use8 = c->w8_meas;
-        if (use8) {
-            hipLaunchKernelGGL(k_w8_scales, dim3(c->KP), dim3(64), 0, c->stream, (const unsigned *)c->w8max, c->w8_blocks,
-                               c->w8s, c->KP, (const DevState *)c->st);
+        const bool use8 = c->w8_tail ? c->w8_use : c->w8_meas;
+        if (c->w8_tail) {
+            // (image, maxima and scales were handled around the row pass)
+        } else if (use8) {
+            w8_make_scales(c, c->w8_blocks);
         }           // (else: w8s holds 256 from klnmf_set_problem or the last loop's scales; this image is not used)
-        {
+        if (!c->w8_tail) {
             const int groups = c->KP / 8, rpb = 256 / groups;
             const int64_t rows = c->n_pad;
             const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
@@ -568,7 +605,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
                                c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st);
             HIPCHK(hipGetLastError());
         }
-        c->w8_meas = true;
+        if (!c->w8_tail) c->w8_meas = true;
         if (use8) {
         if (c->profiling) ev = begin_event(c, c->ev_col);
         ColPass8Args a8{a, c->W8, c->w8s};
@@ -1241,11 +1278,13 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->VtA = c->dalloc(vbytes);
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
-            c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8_meas = false;
+            c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8fin = nullptr; c->w8_meas = false;
             if (c->q8_ok && c->KT <= 7 && !(std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 0)) {
                 c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * c->KP + 32768);
-                c->w8max = (unsigned *)c->dalloc((size_t)kW8Blocks * c->KP * 4);
+                c->w8max = (unsigned *)c->dalloc(((size_t)c->nrt + kW8Blocks) * c->KP * 4);
+                c->w8_tail = std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
                 c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
+                c->w8fin = (unsigned *)c->dalloc((size_t)c->KP * 4);      // (dalloc hands out zero-filled blocks)
                 const std::vector<float> unit8((size_t)c->KP, 256.f);
                 HIPCHK(hipMemcpyAsync(c->w8s, unit8.data(), unit8.size() * 4, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
@@ -1578,6 +1617,7 @@ static void check_v_overflow(klnmf_ctx *c) {
     c->q8_loop = false;
     c->iter_in_loop = 0;
     c->w8_meas = false;
+    c->w8_use = false;
     if (c->q8_ok) {
         const char *g = std::getenv("KLNMF_QTILE");
         const double mean = ds.sum_x / c->v_scale / ((double)c->n * (double)c->f);

@@ -268,6 +268,11 @@ struct RowPassArgs {
     float *gpart;
     int ct_chunk;
     int wg0, rt0;
+    // fp8 x fp8 column pass (colq8x.hip.h): the W rule also leaves the e4m3 image of W_new (f16 image / w8s[component],
+    // exactly as k_w8_from_wb converts it) and this wave's column maxima of the f16 image; null: not written
+    unsigned char *W8;
+    const float *w8s;         // [KP]
+    unsigned *w8max;          // [nrt][KP] float bit patterns
 };
 
 // LDS per stage buffer: [dictionary image | V tiles of the 8 waves (16-bit V only)]

@@ -785,7 +785,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #if defined(KL_TAIL_SCATTERED) || defined(KL_TAIL_LATE_LOADS)
     constexpr int MB1 = 0;
 #else
-    constexpr int MB1 = (MODE == ROW_UPDATE && KT <= 8) ? (KT < KL_TAIL_EARLY ? KT : KL_TAIL_EARLY) : 0;
+    constexpr int kEarly = KL_TAIL_EARLY - (Q8 != 0 ? 1 : 0);      // (the fp8 kernels' W rule also carries the e4m3 image's maxima)
+    constexpr int MB1 = (MODE == ROW_UPDATE && KT <= 8) ? (KT < kEarly ? KT : kEarly) : 0;
 #endif
     f32x4 wold_e[MB1 > 0 ? MB1 : 1][4];
     if constexpr (MB1 > 0) {
@@ -827,6 +828,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // registers of the main loop are dead here, so KT*16 registers are free): one memory round trip per wave.
         // (For KT > 8 in blocks of 8 component tiles: the accumulators alone fill half the register file.)
         KL_LDS float *tb = (KL_LDS float *)arena + wave * (32 * kTLD);
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2w;
+        typedef __attribute__((ext_vector_type(2))) short s16x2w;
+        const bool w8on = MODE == ROW_UPDATE && KT <= 8 && a.W8 != nullptr;      // scalar
+        f16x2w mx8[KT <= 8 ? KT : 1][2];                                         // running column maxima of the f16 image (packed)
+        if (w8on) {
+#pragma unroll
+            for (int m = 0; m < (KT <= 8 ? KT : 1); ++m) { mx8[m][0] = f16x2w{(_Float16)0.f, (_Float16)0.f}; mx8[m][1] = mx8[m][0]; }
+        }
         const int c4 = (lane & 7) * 4, rj = lane >> 3;
         const int64_t row0 = (int64_t)rt * 32;
         constexpr int MB = KT <= 8 ? KT : 8;
@@ -864,6 +873,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own writes, read back by other lanes
                 const f32x4 tc = *(const KL_LDS f32x4 *)(tc_lds + 32 * m + c4), tn = *(const KL_LDS f32x4 *)(tn_lds + 32 * m + c4);
+                f16x2w inv8[2];
+                if (w8on) {
+                    const f32x4 s8 = *(const f32x4 *)(a.w8s + 32 * m + c4);      // powers of two: the reciprocals are exact
+                    inv8[0] = f16x2w{(_Float16)__builtin_amdgcn_rcpf(s8[0]), (_Float16)__builtin_amdgcn_rcpf(s8[1])};
+                    inv8[1] = f16x2w{(_Float16)__builtin_amdgcn_rcpf(s8[2]), (_Float16)__builtin_amdgcn_rcpf(s8[3])};
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int rl = 8 * j + rj, comp = 32 * m + c4;
@@ -877,10 +892,46 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     }
                     *(f32x4 *)(a.W32_new + (row0 + rl) * KP + comp) = w;
                     *(opx4 *)(a.Wb_new + (row0 + rl) * WLD + wb_col(rl, comp)) = wb;
+#ifndef KL_OPND_BF16
+                    if (w8on) {                                             // the e4m3 image, the operations of k_w8_from_wb
+                        const f16x2w lo = f16x2w{wb[0], wb[1]}, hi = f16x2w{wb[2], wb[3]};
+                        mx8[mm][0] = __builtin_elementwise_max(mx8[mm][0], lo);
+                        mx8[mm][1] = __builtin_elementwise_max(mx8[mm][1], hi);
+                        s16x2w w8;
+                        asm volatile("" : "=v"(w8));
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, lo * inv8[0], 1.f, false);
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, hi * inv8[1], 1.f, true);
+                        *(unsigned *)(a.W8 + (row0 + rl) * KP + comp) = __builtin_bit_cast(unsigned, w8);
+                    }
+#endif
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // block m read before block m + 1 overwrites it
             }
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (w8on) {
+            // maxima over the wave's 32 rows: the eight lanes with the same components differ in lane bits 3..5
+#pragma unroll
+            for (int m = 0; m < (KT <= 8 ? KT : 1); ++m)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    unsigned v = __builtin_bit_cast(unsigned, mx8[m][q]);
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        const unsigned other = (unsigned)__shfl_xor((int)v, o, 64);
+                        v = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2w, v), __builtin_bit_cast(f16x2w, other)));
+                    }
+                    mx8[m][q] = __builtin_bit_cast(f16x2w, v);
+                }
+            if (lane < 8) {
+#pragma unroll
+                for (int m = 0; m < (KT <= 8 ? KT : 1); ++m) {
+                    u32x4 o;
+                    o[0] = __float_as_uint((float)mx8[m][0][0]); o[1] = __float_as_uint((float)mx8[m][0][1]);
+                    o[2] = __float_as_uint((float)mx8[m][1][0]); o[3] = __float_as_uint((float)mx8[m][1][1]);
+                    *(u32x4 *)(a.w8max + (int64_t)rt * KP + 32 * m + c4) = o;
+                }
+            }
         }
     }
 #else
