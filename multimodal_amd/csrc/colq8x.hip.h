@@ -13,6 +13,10 @@
 #pragma once
 #include "colq.hip.h"
 
+#ifndef KL_COL8_NB
+#define KL_COL8_NB 4      // LDS objects of the fp8 x fp8 column pass (3 and 5 measured: profiles/r02_ab_fp8_fp8_colpass.txt)
+#endif
+
 namespace klnmf {
 
 // f16 W image (swizzled rows of w_ld(KP) halves) -> e4m3 image [rows][KP bytes] = image / w8s[component] (saturating), and

@@ -611,15 +611,15 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         ColPass8Args a8{a, c->W8, c->w8s};
         switch (c->KT) {
 #ifdef KL_DEV_BUILD
-            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
 #else
-            case 1: hipLaunchKernelGGL((k_colpass_q8x<1, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 2: hipLaunchKernelGGL((k_colpass_q8x<2, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 3: hipLaunchKernelGGL((k_colpass_q8x<3, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 4: hipLaunchKernelGGL((k_colpass_q8x<4, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 5: hipLaunchKernelGGL((k_colpass_q8x<5, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 6: hipLaunchKernelGGL((k_colpass_q8x<6, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, 4>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 1: hipLaunchKernelGGL((k_colpass_q8x<1, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 2: hipLaunchKernelGGL((k_colpass_q8x<2, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 3: hipLaunchKernelGGL((k_colpass_q8x<3, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 4: hipLaunchKernelGGL((k_colpass_q8x<4, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 5: hipLaunchKernelGGL((k_colpass_q8x<5, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 6: hipLaunchKernelGGL((k_colpass_q8x<6, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
 #endif
             default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass prototype: k <= 224");
         }
