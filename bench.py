@@ -332,7 +332,7 @@ def main():
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         qbytes = _native.ratio_tile_bytes(n_local, k) if stored_q else 0
-        col8 = stored_q and qbytes == 1 and k <= 224 and os.environ.get('KLNMF_COL8', '1') != '0'      # fp8 x fp8 column pass (colq8x.hip.h)
+        col8 = stored_q and qbytes == 1 and os.environ.get('KLNMF_COL8', '1') != '0'      # fp8 x fp8 column pass (colq8x.hip.h)
         # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures.
         # Hybrid update pass: the dominant kernel is the whole-row k_rowpass4 over the full rounds of
         # workgroups (n_row rows); the column-split last partial round + its slab W rule are reported beside it.

@@ -205,12 +205,13 @@ def all_distances(A, B, metric, device=0):
 
 def ratio_tile_bytes(n_local=0, k=0):
     """Bytes per element of V of the ratio tiles the row pass leaves for the column pass (stored-ratio schedule): fp8 from
-    the third iteration of a loop on, for k <= 224, from 65 536 rows per context, on data whose maximum is at most 256 x
+    the third iteration of a loop on, for k <= 224 and 256 < k <= 512, from 65 536 rows per context, on data whose maximum is at most 256 x
     its mean (klnmf_set_problem and the loop entry points decide; KLNMF_QTILE = 8 / 16 forces either)."""
     env = os.environ.get('KLNMF_QTILE')
+    k_ok = k <= 224 or (256 < k <= 512 and os.environ.get('KLNMF_COL8', '1') != '0')      # (k > 256: with the fp8 x fp8 column pass only)
     if env is not None:
-        return 1 if (env == '8' and k <= 224) else 2
-    return 1 if (n_local >= 65536 and k <= 224) else 2
+        return 1 if (env == '8' and k_ok) else 2
+    return 1 if (n_local >= 65536 and k_ok) else 2
 
 
 def selftest(device=0):

@@ -19,12 +19,17 @@
 
 namespace klnmf {
 
+// row stride (bytes) of the e4m3 image: KP, padded so that the 8 rows a transposed 8-byte LDS read touches fall into distinct
+// groups of 8 banks (stride in dwords = 8 x odd mod 64) -- the rule of w_ld for the f16 image
+__host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 0 ? 32 : 0); }
+
 // f16 W image (swizzled rows of w_ld(KP) halves) -> e4m3 image [rows][KP bytes] = image / w8s[component] (saturating), and
 // the column maxima of the f16 image for the NEXT iteration's scales (W moves slowly from one update to the next; the
 // scale leaves one binade of headroom and the conversion saturates).  Block = 8 rows x (KP / 8) threads: a thread keeps its
 // 8 components over all its rows.
 __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
                                                     const float *w8s, unsigned *w8max, const DevState *st) {
+    const int ld8 = w8_ld(kp);
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
     if (st->stop) return;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
 #endif
                     out[u] = __builtin_bit_cast(unsigned, w);
                 }
-                *(uint2 *)(W8 + row * kp + comp) = make_uint2(out[0], out[1]);
+                *(uint2 *)(W8 + row * ld8 + comp) = make_uint2(out[0], out[1]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)v[q][e]);
             }
@@ -125,18 +130,25 @@ struct ColPass8Args {
     const float *w8s;             // [KP]
 };
 
-template <int KT, int NB>
+// KSPLIT = 2 (KT > 8, k <= 512): the 8 waves are 4 column tiles x 2 halves of the component range (the accumulators of a
+// half fit two waves per SIMD); the two waves of a column tile read the same two ratio tiles and copy one each.
+template <int KT, int NB, int KSPLIT = 1>
 __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     const ColPassQArgs &a = aa.q;
     typedef __attribute__((ext_vector_type(8))) int i32x8;
     typedef i32x2_t i32x2;
+    static_assert((KSPLIT == 1 || KSPLIT == 2) && KT % KSPLIT == 0, "wave decomposition");
+    constexpr int CTW = kWavesPerWG / KSPLIT;                 // column tiles per workgroup
+    constexpr int KTW = KT / KSPLIT;                          // accumulator blocks per wave
     constexpr int KP = 32 * KT;
-    constexpr int WST = 64 * KP;                              // bytes of W8 per 64-row stage
+    constexpr int LD8 = w8_ld(KP);                            // row stride of the e4m3 image
+    constexpr int WST = 64 * LD8;                             // bytes of W8 per 64-row stage
     constexpr int WA = round_up(WST, kGldsRound);             // copied per stage (whole rounds)
     constexpr int WR = WA / kGldsRound;
-    constexpr int QA = kWavesPerWG * 2 * kQTile8;             // the waves' two ratio tiles
+    constexpr int QA = CTW * 2 * kQTile8;                     // the column tiles' two ratio tiles
     constexpr int OBJ = WA + QA;
-    constexpr int OPS = WR + 2;
+    constexpr int QPW = 2 / KSPLIT;                           // ratio tile pieces a wave copies
+    constexpr int OPS = WR + QPW;
     static_assert(NB >= 3 && NB <= 5 && NB * OBJ <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char o0[OBJ];
     __shared__ __attribute__((aligned(16))) unsigned char o1[OBJ];
@@ -151,7 +163,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     int lin = blockIdx.x;
     if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int chunk = lin / a.ncb, cb = lin % a.ncb;
-    const int ct_raw = cb * kWavesPerWG + wave;
+    const int ctl = wave % CTW, kh = wave / CTW;              // column tile inside the workgroup, half of the component range
+    const int ct_raw = cb * CTW + ctl;
     const bool active = ct_raw < a.nct;
     const int ct = active ? ct_raw : a.nct - 1;
     // stages of 64 rows (the host's chunk decomposition counts 64-row stages)
@@ -160,19 +173,19 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     if (sbeg >= send) {
         if (active) {
             float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
-            for (int c = h; c < KP; c += 2) np[(int64_t)c * a.f_pad] = 0.f;
+            for (int c = 32 * KTW * kh + h; c < 32 * KTW * (kh + 1); c += 2) np[(int64_t)c * a.f_pad] = 0.f;
         }
         return;
     }
     const int i16 = lane & 15, half = (lane >> 4) & 1;
     // A (W8): rows 32 h + 8 u + (i16 >> 1), byte column 32 m + 16 half + 8 (i16 & 1)
-    const unsigned off_a = (32 * h + (i16 >> 1)) * KP + 16 * half + 8 * (i16 & 1);
+    const unsigned off_a = (32 * h + (i16 >> 1)) * LD8 + 16 * half + 8 * (i16 & 1) + 32 * KTW * kh;
     // B (ratio tiles of stage rows 0..31 for h = 0, 32..63 for h = 1): row 8 u + (i16 >> 1) of tile h
-    const unsigned off_b = WA + (2 * wave + h) * kQTile8 + (i16 >> 1) * 32 + 16 * half + 8 * (i16 & 1);
+    const unsigned off_b = WA + (2 * ctl + h) * kQTile8 + (i16 >> 1) * 32 + 16 * half + 8 * (i16 & 1);
 
-    f32x16 acc[KT];
+    f32x16 acc[KTW];
 #pragma unroll
-    for (int m = 0; m < KT; ++m)
+    for (int m = 0; m < KTW; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
@@ -191,8 +204,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w + rr * kGldsRound), "v"(t16), "s"(wbase + rr * kGldsRound) : "memory");
         const unsigned char *qbase = qt_s + (int64_t)(2 * sg) * kQTile8;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + (2 * wave + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
+        for (int pp = 0; pp < QPW; ++pp) {
+            const int p = kh * QPW + pp;               // KSPLIT = 2: the two waves of a column tile copy one tile each
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + (2 * ctl + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
+        }
     };
     auto compute = [&](unsigned base) {
         i32x2 bq[4];
@@ -203,20 +218,20 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
         i32x2 ring[2][4];
         auto fetch = [&](auto M) {
             constexpr int m = decltype(M)::value;
-            if constexpr (m < KT) {
+            if constexpr (m < KTW) {
                 static_for<0, 4>([&](auto U) {
                     constexpr int u = decltype(U)::value;
-                    lds_read_tr8<u * 8 * KP + 32 * m>(ring[m & 1][u], base + off_a);
+                    lds_read_tr8<u * 8 * LD8 + 32 * m>(ring[m & 1][u], base + off_a);
                 });
             }
         };
         fetch(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
         const i32x8 bo = {bq[0][0], bq[0][1], bq[1][0], bq[1][1], bq[2][0], bq[2][1], bq[3][0], bq[3][1]};
-        static_for<0, KT>([&](auto M) {
+        static_for<0, KTW>([&](auto M) {
             constexpr int m = decltype(M)::value;
             fetch(std::integral_constant<int, m + 1>{});
-            if constexpr (m + 1 < KT) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
+            if constexpr (m + 1 < KTW) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
             const i32x8 ao = {ring[m & 1][0][0], ring[m & 1][0][1], ring[m & 1][1][0], ring[m & 1][1][1],
                               ring[m & 1][2][0], ring[m & 1][2][1], ring[m & 1][3][0], ring[m & 1][3][1]};
@@ -247,10 +262,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     const int rcol = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);
     float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + rcol;
 #pragma unroll
-    for (int m = 0; m < KT; ++m)
+    for (int m = 0; m < KTW; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            const int comp = 32 * (KTW * kh + m) + 8 * (e >> 2) + 4 * h + (e & 3);
             np[(int64_t)comp * a.f_pad] = acc[m][e] * (kQ8Scale * aa.w8s[comp]);
         }
 }

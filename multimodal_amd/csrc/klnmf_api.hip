@@ -238,7 +238,9 @@ struct klnmf_ctx {
     bool q8_ok = false, q8_loop = false;
     int64_t iter_in_loop = 0;
     double v_max = 0.0;          // the maximum announced with klnmf_set_v_max (0: none)
-    bool q8() const { return q8_loop && iter_in_loop >= 2; }
+    // fp8 ratio tiles in this iteration?  k > 256 (FUSED row pass, KSPLIT = 2 column pass) has only the fp8 x fp8 column pass
+    // for them: there the W image's scales must have been measured (the loop's second iteration does that)
+    bool q8() const { return q8_loop && iter_in_loop >= 2 && (KT <= 7 || (W8 != nullptr && w8_meas)); }
     float *W32[2] = {nullptr, nullptr};
     opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
@@ -410,6 +412,13 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
         break;
 #define KL_ROW4_BIG(KTV)                                                                                        \
     case KTV:                                                                                                   \
+        if constexpr (MODE == ROW_UPDATE) {                                                                     \
+            if (c->q8() && a.base.Qt) {     /* FUSED order leaving fp8 ratio tiles */                           \
+                if (ep) hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 4, 0, 1>), grid, dim3(256), 0, c->stream, a);   \
+                else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4, 0, 1>), grid, dim3(256), 0, c->stream, a);      \
+                break;                                                                                          \
+            }                                                                                                   \
+        }                                                                                                       \
         if (ep) hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 4>), grid, dim3(256), 0, c->stream, a);   \
         else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4>), grid, dim3(256), 0, c->stream, a);      \
         break;
@@ -457,9 +466,9 @@ void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
 
 void w8_make_scales(klnmf_ctx *c, int64_t entries) {
     const int per_block = 128;
-    hipLaunchKernelGGL(k_w8_reduce, dim3((unsigned)((entries + per_block - 1) / per_block)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_w8_reduce, dim3((unsigned)((entries + per_block - 1) / per_block)), dim3(512), 0, c->stream,
                        (const unsigned *)c->w8max, entries, per_block, c->w8fin, c->KP, (const DevState *)c->st);
-    hipLaunchKernelGGL(k_w8_scales, dim3(1), dim3(256), 0, c->stream, c->w8fin, c->w8s, c->KP, (const DevState *)c->st);
+    hipLaunchKernelGGL(k_w8_scales, dim3(2), dim3(256), 0, c->stream, c->w8fin, c->w8s, c->KP, (const DevState *)c->st);
     HIPCHK(hipGetLastError());
 }
 
@@ -541,7 +550,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                 const int groups = c->KP / 8, rpb = 256 / groups;
                 const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
                 hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
-                                   c->W8 + row0 * c->KP, rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
+                                   c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
                                    c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st);
                 HIPCHK(hipGetLastError());
                 c->w8_entries = t4.base.rt0 + blocks;
@@ -587,24 +596,30 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     a.f_pad = c->f_pad;
     const int grid = c->ncb * c->nchunks;
     EventPair ev{};
-    if (c->W8 && c->q8()) {
+    auto w8_convert = [&]() {          // e4m3 image of W_new with the current scales + this image's column maxima
+        const int groups = c->KP / 8, rpb = std::max(1, 256 / groups);
+        const int64_t rows = c->n_pad;
+        const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
+        c->w8_blocks = blocks;
+        hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
+                           c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+    };
+    if (c->W8 && c->q8_loop && !c->w8_tail && c->iter_in_loop == 1 && !c->w8_meas) {
+        // the loop's second iteration (16-bit tiles still): measure the W image's column maxima for the third one's scales
+        w8_convert();
+        c->w8_meas = true;
+    } else if (c->W8 && c->q8()) {
         // fp8 x fp8 column pass (colq8x.hip.h).  The e4m3 image of W_new is converted behind the row pass with the scales
-        // the PREVIOUS conversion's column maxima give; a loop's first fp8 iteration only measures and runs the f16 form.
+        // the PREVIOUS conversion's column maxima give; without a measurement (k <= 224 only) this iteration measures and
+        // runs the f16-operand form.
         const bool use8 = c->w8_tail ? c->w8_use : c->w8_meas;
         if (c->w8_tail) {
             // (image, maxima and scales were handled around the row pass)
         } else if (use8) {
             w8_make_scales(c, c->w8_blocks);
         }           // (else: w8s holds 256 from klnmf_set_problem or the last loop's scales; this image is not used)
-        if (!c->w8_tail) {
-            const int groups = c->KP / 8, rpb = 256 / groups;
-            const int64_t rows = c->n_pad;
-            const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
-            c->w8_blocks = blocks;
-            hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
-                               c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st);
-            HIPCHK(hipGetLastError());
-        }
+        if (!c->w8_tail) w8_convert();
         if (!c->w8_tail) c->w8_meas = true;
         if (use8) {
         if (c->profiling) ev = begin_event(c, c->ev_col);
@@ -612,6 +627,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         switch (c->KT) {
 #ifdef KL_DEV_BUILD
             case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 16: hipLaunchKernelGGL((k_colpass_q8x<16, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
 #else
             case 1: hipLaunchKernelGGL((k_colpass_q8x<1, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 2: hipLaunchKernelGGL((k_colpass_q8x<2, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
@@ -620,8 +636,12 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
             case 5: hipLaunchKernelGGL((k_colpass_q8x<5, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 6: hipLaunchKernelGGL((k_colpass_q8x<6, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 10: hipLaunchKernelGGL((k_colpass_q8x<10, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 12: hipLaunchKernelGGL((k_colpass_q8x<12, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 14: hipLaunchKernelGGL((k_colpass_q8x<14, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 16: hipLaunchKernelGGL((k_colpass_q8x<16, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
 #endif
-            default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass prototype: k <= 224");
+            default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: k <= 224 or 256 < k <= 512");
         }
         HIPCHK(hipGetLastError());
         if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
@@ -1270,8 +1290,10 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // fp8 ratio tiles: only the H numerator -- a sum over all rows -- sees their 4-bit significands; its relative
             // error falls like 0.036 sqrt(2 / n) (5e-5 at 1M rows, 2e-4 at 65 536: below the operands' own rounding), so
             // they are used from 65 536 rows per context on (KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
-            c->q8_ok = stored_q && c->KT <= 7 && c->col_gen == 2 && c->row_chunks_possible_q8(n);
-            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8_ok = stored_q && c->KT <= 7 && c->col_gen == 2 && std::atoi(g) == 8;
+            const bool col8_off = std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 0;
+            const bool q8_kt = c->KT <= 7 || (c->KT > 8 && !col8_off);      // (k > 256: fp8 tiles only with the fp8 x fp8 column pass)
+            c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->KT > 8) && c->row_chunks_possible_q8(n);
+            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->KT > 8) && std::atoi(g) == 8;
             c->q8_loop = false;
             c->iter_in_loop = 0;
             c->v_max = 0.0;
@@ -1279,10 +1301,10 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
             c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8fin = nullptr; c->w8_meas = false;
-            if (c->q8_ok && c->KT <= 7 && !(std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 0)) {
-                c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * c->KP + 32768);
+            if (c->q8_ok && !col8_off) {
+                c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * w8_ld(c->KP) + 65536);
                 c->w8max = (unsigned *)c->dalloc(((size_t)c->nrt + kW8Blocks) * c->KP * 4);
-                c->w8_tail = std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
+                c->w8_tail = c->KT <= 7 && std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
                 c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
                 c->w8fin = (unsigned *)c->dalloc((size_t)c->KP * 4);      // (dalloc hands out zero-filled blocks)
                 const std::vector<float> unit8((size_t)c->KP, 256.f);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // SPLIT is a template parameter, not a runtime flag: the whole-row instantiation must stay the instruction stream it
     // was (a runtime branch cost 2 % at the headline shape and spilled at KT = 16)
     static_assert(SPLIT == 0 || (NW == 8 && MODE == ROW_UPDATE), "column-split pass: 8-wave update kernels only");
-    static_assert(Q8 == 0 || (NW == 8 && MODE == ROW_UPDATE && sizeof(opnd_t) == 2), "fp8 ratio tiles: 8-wave update kernels");
+    static_assert(Q8 == 0 || (MODE == ROW_UPDATE && sizeof(opnd_t) == 2), "fp8 ratio tiles: update kernels");
     constexpr bool split = SPLIT != 0;
     const int ct0 = split ? (int)blockIdx.y * a.ct_chunk : 0;
     const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
@@ -476,6 +476,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
             unsigned char *qp = qbase + (int64_t)tg * qstride + ql32;
 #endif
+            if constexpr (Q8 != 0) {       // FUSED order: this half of the lane's 16 bytes of the fp8 tile (off = 0 / 1024 -> + 0 / 8)
+#ifndef KL_OPND_BF16
+                typedef __attribute__((ext_vector_type(2))) short s16x2h;
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2h;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2h;
+                u32x2h pk;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    s16x2h w;
+                    asm volatile("" : "=v"(w));
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j], b[4 * j + 1]}, kQ8Scale, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j + 2], b[4 * j + 3]}, kQ8Scale, true);
+                    pk[j] = __builtin_bit_cast(unsigned, w);
+                }
+                (void)qp;
+                unsigned char *const qp8 = qbase + (int64_t)tg * qstride + (off ? 8 : 0);      // wave-uniform
+                asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp8) : "memory");
+#endif
+                return;
+            }
 #if !(KL_SADDR & 4) || defined(KL_ABL_QSMALL)
             __builtin_nontemporal_store(b, (opx8 *)(qp + off));
 #else
@@ -901,7 +921,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                         asm volatile("" : "=v"(w8));
                         w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, lo * inv8[0], 1.f, false);
                         w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, hi * inv8[1], 1.f, true);
-                        *(unsigned *)(a.W8 + (row0 + rl) * KP + comp) = __builtin_bit_cast(unsigned, w8);
+                        *(unsigned *)(a.W8 + (row0 + rl) * (KP + ((KP / 32) % 2 == 0 ? 32 : 0)) + comp) = __builtin_bit_cast(unsigned, w8);      // row stride: w8_ld(KP), colq8x.hip.h
                     }
 #endif
                 }

@@ -583,9 +583,9 @@ def test_hybrid_update_pass_agrees_with_whole_rows(monkeypatch, n, f, k, iters, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,f,k,iters', [(70000, 512, 200, 8), (66000, 384, 72, 7), (70001, 256, 24, 6)])
+@pytest.mark.parametrize('n,f,k,iters', [(70000, 512, 200, 8), (66000, 384, 72, 7), (70001, 256, 24, 6), (66000, 256, 500, 6), (70000, 384, 300, 6)])
 def test_fp8_column_pass_agrees_with_f16_operands_and_oracle(monkeypatch, n, f, k, iters):
-    """From a loop's fourth iteration on (65 536 rows and more, k <= 224) the column pass multiplies an e4m3 image of
+    """From a loop's third iteration on (65 536 rows and more; k <= 224 and 256 < k <= 512) the column pass multiplies an e4m3 image of
     W_new (power-of-two scales per component from the previous iteration's column maxima, colq8x.hip.h) with the fp8
     ratio tiles on the block-scaled fp8 MFMA.  Only the H numerator -- a sum over ALL rows -- sees the 4-bit
     significands: against the f16-operand column pass (KLNMF_COL8=0) the loss record must agree to 1e-5, the factors to
@@ -594,16 +594,16 @@ def test_fp8_column_pass_agrees_with_f16_operands_and_oracle(monkeypatch, n, f, 
     H0 = orc.synthetic_H0(5, f, k)
     out = {}
     for mode in ('0', None):
-        if mode is None:
-            monkeypatch.delenv('KLNMF_COL8', raising=False)
-        else:
-            monkeypatch.setenv('KLNMF_COL8', mode)
+        monkeypatch.delenv('KLNMF_COL8', raising=False)
+        monkeypatch.delenv('KLNMF_QTILE', raising=False)
+        if mode == '0':       # the f16-operand reference: KLNMF_COL8=0; for k > 256 that also means 16-bit ratio tiles
+            monkeypatch.setenv('KLNMF_COL8', '0')
         m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
         out[mode] = (W, m.components_.copy(), np.asarray(errors))
     a, b = out['0'], out[None]
     assert len(a[2]) == len(b[2]) == iters
     assert_allclose(b[2], a[2], rtol=1e-5)
-    assert np.abs(b[2][4:] - a[2][4:]).max() > 0                   # the other path did run (from the fourth iteration's H on)
+    assert np.abs(b[2][3:] - a[2][3:]).max() > 0                   # the other path did run (from the third iteration's H on)
     for i in (0, 1):
         assert np.abs(b[i] - a[i]).max() <= 2e-3 * np.abs(a[i]).max()
     Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
@@ -622,6 +622,7 @@ def test_rowpass_generations_agree_full_chip(monkeypatch):
     X = (torch.rand(n, f, generator=g, device='cuda') * 3).cpu().numpy()
     H0 = orc.synthetic_H0(7, f, k)
     out = {}
+    monkeypatch.setenv('KLNMF_QTILE', '16')      # the generations of the ROW pass are compared: 16-bit ratio tiles, f16 column pass on both
     for gen in ('1', '4'):
         monkeypatch.setenv('KLNMF_ROWPASS', gen)
         m, W, errors, _ = fit_gpu(X, H0, k, 3, 0, precision='bf16')
