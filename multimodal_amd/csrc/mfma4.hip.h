@@ -407,7 +407,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             if constexpr (false)
 #endif
             if constexpr (p < N2) {
+#ifdef KL_EMU_G8          // precision experiment: BOTH operands of MFMA-2 (Q.H^T) rounded to e4m3 and back (ratio / 8, image / 64)
+                auto r8 = [](opx8 v, float sc) {
+                    typedef __attribute__((ext_vector_type(2))) short s16x2_;
+                    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s16x2_ w8 = {0, 0};
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, f16x2_{v[2 * u], v[2 * u + 1]}, sc, false);
+                        const f16x2_ back = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(unsigned, w8), sc, false);
+                        v[2 * u] = back[0]; v[2 * u + 1] = back[1];
+                    }
+                    return v;
+                };
+                if constexpr (Q8 != 0 && MODE == ROW_UPDATE)      // where the fp8 ratio tiles are: from a loop's third iteration on
+                    acc[p >> 1] = KL_MFMA_BUILTIN(r8(ring[p % R], 64.f), r8((p & 1) ? b1 : b0, kQ8Scale), acc[p >> 1], 0, 0, 0);
+                else
+                    acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+#else
                 acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+#endif
             } else {
                 if constexpr (p == N2) {
 #pragma unroll
