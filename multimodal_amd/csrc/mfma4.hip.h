@@ -151,6 +151,19 @@ template <int N>
 __device__ __forceinline__ void mfma1_acc_w(f32x16 &d, const opx8 &a, const opx8 &b) {
     asm volatile("s_waitcnt lgkmcnt(%3)\n\t" KL_MFMA_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
 }
+#ifdef KL_ABL_MFMA16
+template <int Q>
+__device__ __forceinline__ void mfma16_pair(f32x16 &c, std::integral_constant<int, Q>, const opx8 &a, const opx8 &b) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4q;
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    f32x4q t0 = {c[4 * Q], c[4 * Q + 1], c[4 * Q + 2], c[4 * Q + 3]};
+    f32x4q t1 = {c[4 * Q + 4], c[4 * Q + 5], c[4 * Q + 6], c[4 * Q + 7]};
+    t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), t0, 0, 0, 0);
+    t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), t1, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c[4 * Q + e] = t0[e]; c[4 * Q + 4 + e] = t1[e]; }
+}
+#endif
 template <int N>
 __device__ __forceinline__ void lds_wait(opx8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
@@ -424,6 +437,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     acc[p >> 1] = KL_MFMA_BUILTIN(r8(ring[p % R], 64.f), r8((p & 1) ? b1 : b0, kQ8Scale), acc[p >> 1], 0, 0, 0);
                 else
                     acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+#elif defined(KL_ABL_MFMA16)   // timing-only ablation (finite data, wrong values): every 32x32x16 as two 16x16x32 on quarters of its accumulator
+                mfma16_pair(acc[p >> 1], std::integral_constant<int, 2 * (p & 1)>{}, ring[p % R], (p & 1) ? b1 : b0);
 #else
                 acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
 #endif
@@ -432,7 +447,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #pragma unroll
                     for (int e = 0; e < 16; ++e) d[e] = 0.f;
                 }
+#ifdef KL_ABL_MFMA16
+                mfma16_pair(d, std::integral_constant<int, (2 * (p - N2)) & 3>{}, ring[p % R], wf[p - N2]);
+#else
                 d = KL_MFMA_BUILTIN(ring[p % R], wf[p - N2], d, 0, 0, 0);
+#endif
             }
         });
 #ifdef KL_STAMPS

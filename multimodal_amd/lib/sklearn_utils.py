@@ -1,53 +1,55 @@
-"""Input contract of the NMF entry points (host-side validation).
+"""Input contract of the NMF entry points: what the host accepts before anything is uploaded.
 
-Mirrors the behaviour of reference multimodal/lib/sklearn_utils.py:59-110: the
-ValueErrors are raised in Python before anything is uploaded to the GPU.
+Behaviour (not code) of reference multimodal/lib/sklearn_utils.py:59-110, which the NMF front end relies on:
+dense input becomes an ndarray of at least two dimensions (np.matrix and nested lists included), sparse input
+becomes CSR, non-finite floats raise ValueError("array contains NaN or infinity") -- the message fixture G8 pins.
 """
 import numpy as np
 from scipy import sparse
 
+_NONFINITE = "array contains NaN or infinity"
+
 
 def assert_all_finite(X):
-    """ValueError("array contains NaN or infinity") for non-finite float data
-    (reference sklearn_utils.py:59-69: cheap sum test first, full test only if
-    the sum is not finite)."""
-    data = X.data if sparse.issparse(X) else X
-    if data.dtype.kind == 'f' and not np.isfinite(data.sum()) \
-            and not np.isfinite(data).all():
-        raise ValueError("array contains NaN or infinity")
+    """Raise ValueError for NaN / inf in float data (sklearn_utils.py:59-69).  One reduction decides the common
+    case: a finite sum proves every term finite (inf - inf would be NaN, overflow inf), so the element-wise test
+    only runs when the sum itself is not finite."""
+    values = X.data if sparse.issparse(X) else np.asarray(X)
+    if values.dtype.kind != 'f':
+        return
+    if np.isfinite(values.sum()):
+        return
+    if not np.all(np.isfinite(values)):
+        raise ValueError(_NONFINITE)
 
 
 def array2d(X, dtype=None, order=None, copy=False):
-    """At-least-2-D ndarray view of dense input (sklearn_utils.py:72-80)."""
+    """Dense input as an ndarray with ndim >= 2 (sklearn_utils.py:72-80); refuses scipy sparse matrices."""
     if sparse.issparse(X):
-        raise TypeError('A sparse matrix was passed, but dense data '
-                        'is required. Use X.todense() to convert to dense.')
-    X_2d = np.asarray(np.atleast_2d(X), dtype=dtype, order=order)
-    if X is X_2d and copy:
-        X_2d = np.copy(X_2d, order='K')
-    return X_2d
+        raise TypeError('A sparse matrix was passed, but dense data is required. Use X.todense() to convert to dense.')
+    out = np.asarray(np.atleast_2d(X), dtype=dtype, order=order)
+    return out.copy(order='K') if (copy and out is X) else out
 
 
 def atleast2d_or_csr(X, dtype=None, order=None, copy=False):
-    """>=2-D ndarray (np.matrix -> ndarray) or CSR; finite-checked
-    (sklearn_utils.py:83-97)."""
-    if sparse.issparse(X):
-        if dtype is None or X.dtype == dtype:
-            X = X.tocsr()
-        else:
-            X = sparse.csr_matrix(X, dtype=dtype)
+    """The validated form of a data matrix (sklearn_utils.py:83-97): CSR for sparse input (converted to `dtype` when
+    one is asked for and differs), `array2d` otherwise; finite-checked either way."""
+    if not sparse.issparse(X):
+        checked = array2d(X, dtype=dtype, order=order, copy=copy)
+    elif dtype is not None and X.dtype != dtype:
+        checked = sparse.csr_matrix(X, dtype=dtype)
     else:
-        X = array2d(X, dtype=dtype, order=order, copy=copy)
-    assert_all_finite(X)
-    return X
+        checked = X.tocsr()
+    assert_all_finite(checked)
+    return checked
 
 
 def safe_sparse_dot(a, b, dense_output=False):
-    """Dot product that also accepts scipy sparse operands
-    (sklearn_utils.py:102-110).  Host helper, not on the GPU path."""
-    if sparse.issparse(a) or sparse.issparse(b):
-        ret = a * b
-        if dense_output and hasattr(ret, "toarray"):
-            ret = ret.toarray()
-        return ret
-    return np.dot(a, b)
+    """a . b for any mix of ndarray and scipy sparse operands (sklearn_utils.py:102-110); host helper of the CPU-side
+    API mirror, never on the GPU path."""
+    if not (sparse.issparse(a) or sparse.issparse(b)):
+        return np.dot(a, b)
+    product = a * b
+    if dense_output and sparse.issparse(product):
+        product = product.toarray()
+    return product

@@ -103,6 +103,25 @@ def synthetic_problem(seed, n, f, k, block=8192):
     return X, H0
 
 
+def synthetic_modalities(seed, n, dims, k, scales=(1.0, 7.0, 0.2), block=8192):
+    """Three (or more) dense modalities of the section-8d family over SHARED latent coefficients (one Wt per row
+    block, one Ht per modality), each in its own units (`scales`), with the per-modality coefficients of
+    experiment.py:70-72 (1 / mean row sum) -- the inputs of fixture G14 (tests/golden/make_golden_large.py), stacked by
+    the learner as learner.py:53-56 does.  Returns (blocks, coefs, H0) with H0 [k, sum(dims)]."""
+    f = sum(dims)
+    Hts = [np.random.RandomState(seed + 100 * (m + 1)).gamma(0.5, 1.0, (k, d)) for m, d in enumerate(dims)]
+    blocks = [np.empty((n, d)) for d in dims]
+    for b, r0 in enumerate(range(0, n, block)):
+        r1 = min(n, r0 + block)
+        rs = np.random.RandomState(seed + 1 + b)
+        Wt = rs.gamma(1.0, 1.0, (r1 - r0, k))
+        for m, d in enumerate(dims):
+            blocks[m][r0:r1] = scales[m % len(scales)] * (Wt.dot(Hts[m]) / k + 0.05 * rs.random_sample((r1 - r0, d)))
+    coefs = [float(1.0 / np.mean(np.sum(x, axis=1))) for x in blocks]
+    H0 = _normalize_rows(np.random.RandomState(seed - 1).random_sample((k, f)) + .01)
+    return blocks, coefs, H0
+
+
 def experiment_modalities(seed, n_per_label=14, n_labels=10, dims=(48, 30)):
     """Two dense non-negative modalities with class structure (fixture G13, tests/golden/make_golden_experiment.py):
     a sample of label l is its label's template plus noise, histogram-like (rows of the first modality sum to 1 as the

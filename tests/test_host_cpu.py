@@ -228,3 +228,23 @@ def test_scale_inverse_scales_W_columns_and_H_rows():
     assert_array_almost_equal(sH, H / (factors + 1e-8)[:, None])
     assert_array_almost_equal(sW.dot(sH), W.dot(H))
     assert_array_almost_equal(nmf.KLdivNMF(eps=.5).scale(W, H, factors)[0], W * (factors + .5)[None, :])    # the one place self.eps is read
+
+
+def test_build_staleness_sees_every_kernel_header():
+    """__graft_entry__.build() recompiles when ANY source of the library is newer than the built .so -- the list is a
+    glob of csrc/, so a header added later (round 2: colq8x.hip.h was missing from a hand-kept list) cannot be forgotten."""
+    import __graft_entry__ as ge
+    names = {os.path.basename(p) for p in ge._sources()}
+    for must in ('klnmf_api.hip', 'mfma4.hip.h', 'colq.hip.h', 'colq8x.hip.h', 'exact.hip.h', 'sparse.hip.h', 'klnmf.h'):
+        assert must in names
+    if not os.path.exists(ge.LIB):
+        assert ge._stale()
+        return
+    hdr = os.path.join(ge.CSRC, 'colq8x.hip.h')
+    st = os.stat(hdr)
+    lib_t = os.path.getmtime(ge.LIB)
+    try:
+        os.utime(hdr, (lib_t + 10, lib_t + 10))
+        assert ge._stale()
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
