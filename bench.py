@@ -35,10 +35,51 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# MI355X peaks (MI355X_MICROARCH.md): dense bf16 MFMA, HBM3E
+# MI355X peaks (MI355X_MICROARCH.md): dense bf16 / fp16 MFMA, dense fp8 (block-scaled e4m3) MFMA, HBM3E
 PEAK_BF16_TFLOPS = 2500.0
+PEAK_FP8_TFLOPS = 5000.0
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
+PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r03_pmc_traffic.json'), os.path.join('profiles', 'r02_pmc_traffic.json')]
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the library's sources: the PMC traffic figures are constants measured in a
+    separate rocprofv3 run (counters cannot be read in-process) and go stale when the kernels change -- the line says
+    at which source state they were measured and whether that is the state it ran."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'multimodal_amd', 'csrc')
+    for path in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hip.h'))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+class Watchdog(object):
+    """A rank that sits in a collective no other rank will ever join (a peer died, RCCL hangs) would block the whole job for
+    ever: every timed or warm-up segment runs under this timer; when it expires the rank prints what it was doing and
+    leaves with a non-zero status (os._exit: no clean-up that could block again, and never a re-exec)."""
+
+    def __init__(self, seconds, what, rank):
+        import threading
+        self.what, self.rank, self.seconds = what, rank, seconds
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+
+    def fire(self):
+        sys.stderr.write('bench.py watchdog: rank %d spent more than %.0f s in "%s" -- a peer rank gone or a hung collective; '
+                         'exiting with status 3\n' % (self.rank, self.seconds, self.what))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
 
 
 def parse_args(argv=None):
@@ -54,8 +95,16 @@ def parse_args(argv=None):
     p.add_argument('--precision', default='f16', choices=['f16', 'f16_v32', 'bf16', 'bf16_v32', 'f32', 'f64'],
                    help="f16: fp16 MFMA operands (scaled images), fp32 accumulate; 'bf16' is the round-1 name of the same mode")
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-rows', type=int, default=100000, help='rows of the same V the CPU baseline is timed on (BASELINE.md 3)')
-    p.add_argument('--cpu-iters', type=int, default=3)
+    p.add_argument('--cpu-rows', type=int, default=65536,
+                   help='rows of the same V the CPU baseline is timed on (BASELINE.md 3); 65 536 = the smallest context that '
+                        'runs fp8 ratio tiles, so the parity leg on the same sample exercises them')
+    p.add_argument('--cpu-iters', type=int, default=7,
+                   help='timed CPU iterations after one warm-up; the parity leg runs the same 1 + N iterations on the GPU '
+                        '(8 by default: 6 of them on fp8 ratio tiles)')
+    p.add_argument('--no-16bit-segment', action='store_true',
+                   help='skip the extra segment that measures value_16bit (16-bit ratio tiles, f16 column pass)')
+    p.add_argument('--segment-timeout', type=float, default=float(os.environ.get('KLNMF_BENCH_SEGMENT_TIMEOUT', '300')),
+                   help='watchdog: seconds one warm-up + timed segment may take before the rank exits with status 3')
     p.add_argument('--seed', type=int, default=1234)
     p.add_argument('--data', default='blocks', choices=['blocks', 'device'],
                    help="blocks: the seeded RandomState blocks of SURVEY 8d (host-generated, identical to the CPU baseline's "
@@ -115,23 +164,25 @@ def fill_shard_device(torch, model, seed, rank, n_local, f, k, block=8192, vscal
 
 def measured_traffic(args, n_local):
     """HBM bytes per launch of the hot kernels from the committed PMC passes of this exact workload
-    (profiles/r02_pmc_traffic.json, produced by scripts/pmc_profile.sh: separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE runs, gfx950 correction applied); None if the workload differs -- counters cannot be read in-process."""
-    try:
-        d = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
-    except Exception:
-        return None, None
-    for entry in d.get('workloads', []):
-        w = entry.get('workload', {})
-        if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision.replace('bf16', 'f16')):
-            row = col = None
-            for name, v in entry.get('kernels', {}).items():
-                if 'k_rowpass' in name and 'column-split' not in name:      # the whole-row launch (the roofline entry)
-                    row = v['hbm_bytes_per_launch']
-                elif 'k_colpass' in name:
-                    col = v['hbm_bytes_per_launch']
-            return row, col
-    return None, None
+    (profiles/r0N_pmc_traffic.json, produced by scripts/pmc_profile.sh: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs, gfx950 correction applied); None if the workload differs -- counters cannot be read in-process.
+    Returns (row, col, file, source_hash the file was measured at or None)."""
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, name)))
+        except Exception:
+            continue
+        for entry in d.get('workloads', []):
+            w = entry.get('workload', {})
+            if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision.replace('bf16', 'f16')):
+                row = col = None
+                for kname, v in entry.get('kernels', {}).items():
+                    if 'k_rowpass' in kname and 'column-split' not in kname:      # the whole-row launch (the roofline entry)
+                        row = v['hbm_bytes_per_launch']
+                    elif 'k_colpass' in kname:
+                        col = v['hbm_bytes_per_launch']
+                return row, col, name, d.get('source_hash')
+    return None, None, None, None
 
 
 def host_info():
@@ -221,11 +272,13 @@ def gpu_parity_on_sample(args, sample):
         ctx.set_H(H0)
         ctx.init_W()
         errs, n_done, stopped = ctx.run(iters, True, 0.0)
+        fp8 = ctx.fp8_report()
         g_final = ctx.error()
     return {'final_kl_rel_err': abs(g_final - final) / abs(final),
             'max_loss_rel_err': float(max(abs(a - b) / abs(b) for a, b in zip(errs, losses))) if len(errs) == len(losses) else None,
             'len_errors': [int(len(errs)), int(len(losses))],
-            'iterations': iters, 'rows': int(X.shape[0]), 'tolerance': 1e-4}
+            'iterations': iters, 'rows': int(X.shape[0]), 'tolerance': 1e-4,
+            'iterations_on_fp8_ratio_tiles': fp8['tile_iterations'], 'iterations_with_fp8_x_fp8_column_pass': fp8['column_pass_iterations']}
 
 
 def main():
@@ -258,14 +311,30 @@ def main():
     iters_per_fit = args.warmup + args.steps
     t_setup = time.perf_counter()
     collective = args.collective if (world > 1 and not rehearsal) else 'torch'
-    try:
-        model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
-    except Exception as e:           # librccl not loadable, communicator refused, ...: say so and use the torch path
-        if collective != 'native':
-            raise
-        sys.stderr.write('bench.py: native collective path unavailable (%s); using torch.distributed\n' % e)
-        collective = 'torch'
-        model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
+    native_error = None
+    model = None
+    with Watchdog(args.segment_timeout, 'set-up of the model and its communicator', rank):
+        try:
+            model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
+        except Exception as e:           # librccl not loadable, communicator refused, ...
+            if collective != 'native':
+                raise
+            native_error = e
+        if collective == 'native' and world > 1:
+            # ALL ranks switch together or none does: a rank that fell back alone would wait in a torch collective while
+            # the others wait in RCCL
+            flag = torch.tensor([1.0 if native_error is not None else 0.0], device='cuda')
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag.item()) != 0.0:
+                if rank == 0:
+                    sys.stderr.write('bench.py: native collective path unavailable on at least one rank (%s); every rank uses '
+                                     'torch.distributed\n' % (native_error if native_error is not None else 'another rank'))
+                if model is not None:
+                    model.close()
+                collective = 'torch'
+                model = ShardedKLNMF(n, n_local, f, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
+        elif native_error is not None:
+            raise native_error
     if args.data == 'blocks':
         fill_shard_blocks(model, args.seed, r0, r1, n, f, k)
     else:
@@ -279,46 +348,77 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    segments, fits = [], []
-    prof_tot = {'rowpass_ms': 0.0, 'rowpass_launches': 0, 'colpass_ms': 0.0, 'colpass_launches': 0, 'tail_ms': 0.0,
-                'tail_launches': 0}
-    tail_rows = 0
-    for rep in range(max(1, args.repeats)):
-        model.set_H(H0)
-        model.init_W()
-        if collective == 'native':       # each call runs its iterations, collectives included, inside the C-ABI
-            _, wd, wstop = model.run(args.warmup, fit=True, tol=args.tol) if args.warmup else ([], 0, False)
-            model.ctx.profile_enable(True)
-            fence()
-            t0 = time.perf_counter()
-            errors, n_done, stopped = model.run(args.steps, fit=True, tol=args.tol)
-            fence()
-            elapsed = time.perf_counter() - t0
-            prof = model.ctx.profile_read(reset=True)
-            model.ctx.profile_enable(False)
-            n_done, stopped = n_done + wd, stopped or wstop
-        else:
-            model.begin()
-            for _ in range(args.warmup):
-                model.iterate(fit=True, tol=args.tol)
-            model.ctx.profile_enable(True)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                model.iterate(fit=True, tol=args.tol)
-            fence()
-            elapsed = time.perf_counter() - t0
-            prof = model.ctx.profile_read(reset=True)
-            model.ctx.profile_enable(False)
-            errors, n_done, stopped = model.end()
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        segments.append(float(t.item()))
-        fits.append((list(errors), int(n_done), bool(stopped)))
-        for key in prof_tot:
-            prof_tot[key] += prof[key]
-        tail_rows = prof.get('tail_rows', 0)
+    def run_segments(repeats):
+        """`repeats` independent fits from the same start; returns (segment times, fits, summed kernel profile, tail rows,
+        what the last fit's loop ran on fp8)."""
+        segments, fits = [], []
+        prof_tot = {'rowpass_ms': 0.0, 'rowpass_launches': 0, 'colpass_ms': 0.0, 'colpass_launches': 0, 'tail_ms': 0.0,
+                    'tail_launches': 0}
+        tail_rows, fp8 = 0, None
+        for rep in range(max(1, repeats)):
+            with Watchdog(args.segment_timeout, 'segment %d (init + %d warm-up + %d timed iterations, collective=%s)'
+                          % (rep, args.warmup, args.steps, collective), rank):
+                model.set_H(H0)
+                model.init_W()
+                if collective == 'native':       # each call runs its iterations, collectives included, inside the C-ABI
+                    _, wd, wstop = model.run(args.warmup, fit=True, tol=args.tol) if args.warmup else ([], 0, False)
+                    model.ctx.profile_enable(True)
+                    fence()
+                    t0 = time.perf_counter()
+                    errors, n_done, stopped = model.run(args.steps, fit=True, tol=args.tol)
+                    fence()
+                    elapsed = time.perf_counter() - t0
+                    prof = model.ctx.profile_read(reset=True)
+                    model.ctx.profile_enable(False)
+                    n_done, stopped = n_done + wd, stopped or wstop
+                else:
+                    model.begin()
+                    for _ in range(args.warmup):
+                        model.iterate(fit=True, tol=args.tol)
+                    model.ctx.profile_enable(True)
+                    fence()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        model.iterate(fit=True, tol=args.tol)
+                    fence()
+                    elapsed = time.perf_counter() - t0
+                    prof = model.ctx.profile_read(reset=True)
+                    model.ctx.profile_enable(False)
+                    errors, n_done, stopped = model.end()
+                t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                segments.append(float(t.item()))
+            fits.append((list(errors), int(n_done), bool(stopped)))
+            for key in prof_tot:
+                prof_tot[key] += prof[key]
+            tail_rows = prof.get('tail_rows', 0)
+            fp8 = model.ctx.fp8_report()
+        return segments, fits, prof_tot, tail_rows, fp8
+
+    segments, fits, prof_tot, tail_rows, fp8 = run_segments(args.repeats)
+    # The same workload with 16-bit ratio tiles and the f16-operand column pass (KLNMF_QTILE=16 is read at every loop's
+    # entry): the number the north star's "bf16/16-bit MFMA contractions" wording describes, beside the headline one.
+    value_16bit = None
+    fast16 = args.precision in ('f16', 'bf16')
+    if fast16 and not args.no_16bit_segment and fp8 is not None and fp8['tile_iterations'] > 0:
+        saved = os.environ.get('KLNMF_QTILE')
+        os.environ['KLNMF_QTILE'] = '16'
+        try:
+            seg16, fits16, prof16, _, fp8_16 = run_segments(1)
+        finally:
+            if saved is None:
+                del os.environ['KLNMF_QTILE']
+            else:
+                os.environ['KLNMF_QTILE'] = saved
+        value_16bit = {
+            'value': args.steps / seg16[0], 'unit': 'it/s', 'ms_per_step': 1e3 * seg16[0] / args.steps,
+            'what': 'one extra segment of the same run with KLNMF_QTILE=16: 16-bit (fp16) ratio tiles and f16 operands in '
+                    'every product, no e4m3 anywhere',
+            'row_pass_ms': prof16['rowpass_ms'] / max(1, prof16['rowpass_launches']),
+            'col_pass_ms': prof16['colpass_ms'] / max(1, prof16['colpass_launches']),
+            'fp8_tile_iterations': fp8_16['tile_iterations'],
+            'valid': all(nd == iters_per_fit and not st for _, nd, st in fits16)}
 
     if rank == 0:
         elapsed = statistics.median(segments)
@@ -331,8 +431,19 @@ def main():
         pingpong = (fast16 and (k <= 224 or 256 < k <= 512)
                     and os.environ.get('KLNMF_ROWPASS', '4') == '4')
         stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
-        qbytes = _native.ratio_tile_bytes(n_local, k) if stored_q else 0
-        col8 = stored_q and qbytes == 1 and os.environ.get('KLNMF_COL8', '1') != '0'      # fp8 x fp8 column pass (colq8x.hip.h)
+        # what the timed loop ran, as the LIBRARY reports it (klnmf_query), not a host-side copy of its rules: the loop's
+        # first two iterations keep 16-bit tiles (the torch path's warm-up absorbs them when --warmup >= 2; the native
+        # path's timed call is a loop of its own and starts with them)
+        timed_loop_only = collective == 'native'
+        fp8_iters = min(args.steps, fp8['tile_iterations']) if (fp8 and stored_q) else 0
+        col8_iters = min(args.steps, fp8['column_pass_iterations']) if (fp8 and stored_q) else 0
+        if not timed_loop_only and fp8 and stored_q:      # one loop = warm-up + timed: the 16-bit iterations come first
+            fp8_iters = max(0, min(args.steps, fp8['tile_iterations'] - max(0, args.warmup - (iters_per_fit - fp8['tile_iterations']))))
+            col8_iters = max(0, min(args.steps, fp8['column_pass_iterations'] - max(0, args.warmup - (iters_per_fit - fp8['column_pass_iterations']))))
+        frac8 = fp8_iters / float(args.steps)
+        qbytes = (2.0 - frac8) if stored_q else 0          # bytes per element of V, averaged over the timed iterations
+        col8 = col8_iters > 0                                # fp8 x fp8 column pass (colq8x.hip.h) in the timed region
+        frac_col8 = col8_iters / float(args.steps)
         # ---- the row-pass launch (W.H -> ratio, loss -> Q.H^T -> W rule): SURVEY 8d per-launch figures.
         # Hybrid update pass: the dominant kernel is the whole-row k_rowpass4 over the full rounds of
         # workgroups (n_row rows); the column-split last partial round + its slab W rule are reported beside it.
@@ -357,7 +468,8 @@ def main():
         row_s = row_ms * 1e-3
         row_tflops = flops_row / row_s / 1e12 if row_s > 0 else None
         row_gbs = alg_bytes_row / row_s / 1e9 if row_s > 0 else None
-        traffic_row, traffic_col = measured_traffic(args, n_local)
+        traffic_row, traffic_col, traffic_file, traffic_hash = measured_traffic(args, n_local)
+        src_hash = kernel_source_hash()
         roofline = {
             'kernel': ('k_rowpass4' if pingpong else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule'
                       + (', ratio tiles stored for the H rule)' if stored_q else ')'),
@@ -367,7 +479,11 @@ def main():
             'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
             'frac': ((row_tflops / PEAK_BF16_TFLOPS) if mfma_bound else (row_gbs / PEAK_HBM_GBS)) if row_s > 0 else None,
             'traffic': traffic_row,
-            'traffic_source': PMC_TRAFFIC_FILE if traffic_row else None,
+            'traffic_source': traffic_file if traffic_row else None,
+            'traffic_measured_at_source_hash': traffic_hash if traffic_row else None,
+            'source_hash': src_hash,
+            'traffic_is_current': bool(traffic_row and traffic_hash == src_hash),
+            'operands': 'f16 (v_mfma_f32_32x32x16_f16), fp32 accumulate' if fast16 else args.precision,
             'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'], 'rows_per_launch': n_row,
             'algorithmic_flops_per_launch': flops_row,
             'algorithmic_bytes_per_launch': alg_bytes_row,
@@ -392,11 +508,24 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'f16' if args.precision in ('f16', 'f16_v32', 'bf16', 'bf16_v32') else args.precision,      # MFMA operand type (fp32 accumulate)
+            # the arithmetic types the path computed in (not a precision claim): the W.H and Q.H^T contractions, the W rule
+            # and the loss always on f16 operands with fp32 accumulation; the H-numerator product W_new^T.Q on e4m3
+            # operands (ratio / 8 tiles, scaled W image) in the iterations the library reports
+            'dtype': (('f16 operands, fp32 accumulate; e4m3 ratio tiles and e4m3 W image in the H-numerator product'
+                       if col8 else ('f16 operands, fp32 accumulate; e4m3 ratio tiles (converted back to f16) in the H-numerator product'
+                                     if frac8 > 0 else 'f16'))
+                      if args.precision in ('f16', 'f16_v32', 'bf16', 'bf16_v32') else args.precision),
             'data': 'synthetic',
             'config': {'workload': 'KL-NMF fit iteration, V %dx%d (row-sharded), k=%d' % (n, f, k),
                        'n': n, 'f': f, 'k': k, 'rows_per_gpu': n_local,
-                       'precision': args.precision, 'parallelism': 'rows/%d' % n_gpus,
+                       'precision': args.precision + (' + e4m3 H-numerator product' if col8 else ''),
+                       'parallelism': 'rows/%d' % n_gpus,
+                       'fp8': {'loop_allowed': bool(fp8 and fp8['allowed']),
+                               'timed_iterations_with_fp8_ratio_tiles': fp8_iters,
+                               'timed_iterations_with_fp8_x_fp8_column_pass': col8_iters,
+                               'source': 'klnmf_query'},
+                       'rccl_ranks': model.rccl_ranks() if n_gpus > 1 else None,
+                       'collective_path': collective if n_gpus > 1 else None,
                        'collective': ('one grouped RCCL all-reduce of the k x f numerator + the loss per iteration, issued inside '
                                       'the C-ABI (klnmf_run_sharded)' if collective == 'native' else
                                       'torch.distributed all-reduce of the k x f numerator + async all-reduce of the loss')
@@ -406,6 +535,7 @@ def main():
                        'timing': 'median of %d segments of %d iterations, each after a fresh init + %d warm-up iterations'
                                  % (len(segments), args.steps, args.warmup)},
             'samples_per_sec': its * n,
+            'value_16bit': value_16bit,
             'segments_ms_per_step': [1e3 * s / args.steps for s in segments],
             'setup_s': t_setup,
             'iterations_done': n_done,
@@ -430,14 +560,21 @@ def main():
                 (('k_colpass_q8x' if col8 else 'k_colpass_q2') if stored_q else 'k_colpass'): {
                     'avg_launch_ms': col_ms, 'launches': prof_tot['colpass_launches'],
                     'algorithmic_tflops': flops_col / (col_ms * 1e-3) / 1e12 if col_ms > 0 else None,
-                    'frac_of_bf16_peak': flops_col / (col_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if col_ms > 0 else None,
+                    'operands': 'e4m3 x e4m3 (v_mfma_scale_f32_32x32x64_f8f6f4)' if col8 else 'f16',
+                    'peak_tflops_of_its_operand_type': PEAK_FP8_TFLOPS if col8 else PEAK_BF16_TFLOPS,
+                    'frac_of_own_peak': flops_col / (col_ms * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if col8 else PEAK_BF16_TFLOPS) if col_ms > 0 else None,
                     'schedule_bytes_per_launch': sched_bytes_col,
                     'schedule_hbm_gbs': sched_bytes_col / (col_ms * 1e-3) / 1e9 if col_ms > 0 else None,
                     'traffic': traffic_col},
                 'iteration_algorithmic_bytes': n * f * vbytes + 2 * n * k * 4 + 3 * k * f * 4,
                 'iteration_schedule_bytes': (sched_bytes_section + sched_bytes_col) * n_gpus,
                 'iteration_algorithmic_tflops': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12,
-                'iteration_frac_of_bf16_peak': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * n_gpus),
+                # dtype-true t_min of the iteration: 4nfk on 16-bit operands + 2nfk on the operands the column pass ran
+                'iteration_t_min_ms': 1e3 * (4.0 * n * f * k / (PEAK_BF16_TFLOPS * 1e12)
+                                             + 2.0 * n * f * k * (frac_col8 / (PEAK_FP8_TFLOPS * 1e12) + (1 - frac_col8) / (PEAK_BF16_TFLOPS * 1e12))) / n_gpus,
+                'iteration_frac': (4.0 * n * f * k / (PEAK_BF16_TFLOPS * 1e12)
+                                   + 2.0 * n * f * k * (frac_col8 / (PEAK_FP8_TFLOPS * 1e12) + (1 - frac_col8) / (PEAK_BF16_TFLOPS * 1e12)))
+                                  / n_gpus / (ms_per_step * 1e-3),
             },
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

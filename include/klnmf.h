@@ -143,6 +143,10 @@ int klnmf_run(klnmf_ctx *ctx, int64_t max_iter, int fit, double tol_abs,
  * After the stop rule fires every later piece is a no-op on the device, so the
  * host may enqueue all max_iter iterations without synchronising. */
 int klnmf_loop_begin(klnmf_ctx *ctx);
+/* The same for one rank of a row-sharded problem: the fp8 decision of the loop (16-bit modes) is taken from the sums over
+ * ALL shards -- sum of V (klnmf_query_f64 KLNMF_QF_SUM_V, all-reduced) and its element count -- so that every rank runs
+ * the same kernels and the result does not depend on the partition beyond summation order. */
+int klnmf_loop_begin_sharded(klnmf_ctx *ctx, double sum_v_all, double cells_all);
 int klnmf_iter_rowpass(klnmf_ctx *ctx, int fit);
 int klnmf_iter_decide(klnmf_ctx *ctx, double tol_abs);
 int klnmf_iter_colpass(klnmf_ctx *ctx);
@@ -216,6 +220,24 @@ int klnmf_generalized_kl(klnmf_ctx *ctx, const void *x, const void *y, int dtype
 int klnmf_get_W(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,k] */
 int klnmf_get_H(klnmf_ctx *ctx, void *dst, int dtype);   /* [k,f] */
 int klnmf_get_Q(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,f], F64/F32 modes */
+
+/* ---- introspection ------------------------------------------------------ */
+/* What a context decided and what its last loop actually ran -- no reference counterpart (the reference has one
+ * arithmetic); bench.py and the parity tests read it instead of mirroring the library's rules on the host.
+ *   KLNMF_Q_FP8_LOOP          1 if the current / last loop was allowed fp8 ratio tiles (data rule at the loop's entry)
+ *   KLNMF_Q_FP8_TILE_ITERS    iterations of that loop whose ratio tiles were fp8 (e4m3 of ratio / 8)
+ *   KLNMF_Q_FP8_COL_ITERS     iterations whose H-numerator product ran on e4m3 operands on both sides
+ *   KLNMF_Q_RATIO_TILE_BYTES  bytes per element of V the stored ratio tiles take in an fp8 iteration (1), else 2; 0: none stored
+ *   KLNMF_Q_COMM_RANKS        ranks RCCL reports for the context's communicator (ncclCommCount); 1 without one */
+#define KLNMF_Q_FP8_LOOP          0
+#define KLNMF_Q_FP8_TILE_ITERS    1
+#define KLNMF_Q_FP8_COL_ITERS     2
+#define KLNMF_Q_RATIO_TILE_BYTES  3
+#define KLNMF_Q_COMM_RANKS        4
+int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
+/*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */
+#define KLNMF_QF_SUM_V            0
+int klnmf_query_f64(klnmf_ctx *ctx, int what, double *value);
 
 /* ---- measurement -------------------------------------------------------- */
 /* When enabled, every row-pass / column-pass launch is bracketed by HIP events

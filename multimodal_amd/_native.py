@@ -55,6 +55,7 @@ SIGNATURES = {
                              _c.POINTER(_c.c_double), _c.POINTER(_i64),
                              _c.POINTER(_c.c_int)]),
     'klnmf_loop_begin': (_c.c_int, [_ctx_p]),
+    'klnmf_loop_begin_sharded': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double]),
     'klnmf_iter_rowpass': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_iter_decide': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_iter_colpass': (_c.c_int, [_ctx_p]),
@@ -90,6 +91,8 @@ SIGNATURES = {
                                       _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.c_int]),
     'klnmf_profile_read_tail': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.POINTER(_i64), _c.c_int]),
     'klnmf_synchronize': (_c.c_int, [_ctx_p]),
+    'klnmf_query': (_c.c_int, [_ctx_p, _c.c_int, _c.POINTER(_i64)]),
+    'klnmf_query_f64': (_c.c_int, [_ctx_p, _c.c_int, _c.POINTER(_c.c_double)]),
     'klnmf_set_problem_sparse': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64, _i64]),
     'klnmf_upload_csr': (_c.c_int, [_ctx_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                     _c.c_void_p, _c.c_void_p]),
@@ -203,15 +206,7 @@ def all_distances(A, B, metric, device=0):
     return out
 
 
-def ratio_tile_bytes(n_local=0, k=0):
-    """Bytes per element of V of the ratio tiles the row pass leaves for the column pass (stored-ratio schedule): fp8 from
-    the third iteration of a loop on, for k <= 224 and 256 < k <= 512, from 65 536 rows per context, on data whose maximum is at most 256 x
-    its mean (klnmf_set_problem and the loop entry points decide; KLNMF_QTILE = 8 / 16 forces either)."""
-    env = os.environ.get('KLNMF_QTILE')
-    k_ok = k <= 224 or (256 < k <= 512 and os.environ.get('KLNMF_COL8', '1') != '0')      # (k > 256: with the fp8 x fp8 column pass only)
-    if env is not None:
-        return 1 if (env == '8' and k_ok) else 2
-    return 1 if (n_local >= 65536 and k_ok) else 2
+Q_FP8_LOOP, Q_FP8_TILE_ITERS, Q_FP8_COL_ITERS, Q_RATIO_TILE_BYTES, Q_COMM_RANKS = 0, 1, 2, 3, 4
 
 
 def selftest(device=0):
@@ -432,8 +427,19 @@ class Context(object):
         nd = int(n_done.value)
         return [float(errs[i]) for i in range(min(nd, int(max_iter)))], nd, bool(stopped.value)
 
-    def loop_begin(self):
-        _check(self._lib.klnmf_loop_begin(self._h))
+    def loop_begin(self, sum_v_all=None, cells_all=None):
+        """klnmf_loop_begin; with the all-reduced sum of V and element count: klnmf_loop_begin_sharded (one rank of a
+        row-sharded problem -- every rank then takes the same fp8 decision)."""
+        if sum_v_all is None:
+            _check(self._lib.klnmf_loop_begin(self._h))
+        else:
+            _check(self._lib.klnmf_loop_begin_sharded(self._h, float(sum_v_all), float(cells_all)))
+
+    def sum_V(self):
+        """Sum of the uploaded V as stored (klnmf_query_f64 KLNMF_QF_SUM_V)."""
+        v = _c.c_double(0.0)
+        _check(self._lib.klnmf_query_f64(self._h, 0, ctypes.byref(v)))
+        return float(v.value)
 
     def iter_rowpass(self, fit=True):
         _check(self._lib.klnmf_iter_rowpass(self._h, 1 if fit else 0))
@@ -547,3 +553,14 @@ class Context(object):
 
     def synchronize(self):
         _check(self._lib.klnmf_synchronize(self._h))
+
+    def query(self, what):
+        """klnmf_query: what the context decided / what its last loop ran (Q_* items above)."""
+        v = _i64(0)
+        _check(self._lib.klnmf_query(self._h, int(what), ctypes.byref(v)))
+        return int(v.value)
+
+    def fp8_report(self):
+        """{'allowed', 'tile_iterations', 'column_pass_iterations'} of the last loop -- read from the library, not re-derived."""
+        return {'allowed': bool(self.query(Q_FP8_LOOP)), 'tile_iterations': self.query(Q_FP8_TILE_ITERS),
+                'column_pass_iterations': self.query(Q_FP8_COL_ITERS)}

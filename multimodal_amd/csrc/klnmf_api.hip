@@ -88,6 +88,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
 };
 RcclApi &rccl() {
     static RcclApi api = [] {
@@ -103,7 +104,7 @@ RcclApi &rccl() {
         KL_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") KL_RCCL_SYM(CommInitRank, "ncclCommInitRank")
         KL_RCCL_SYM(CommDestroy, "ncclCommDestroy") KL_RCCL_SYM(AllReduce, "ncclAllReduce")
         KL_RCCL_SYM(GroupStart, "ncclGroupStart") KL_RCCL_SYM(GroupEnd, "ncclGroupEnd")
-        KL_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+        KL_RCCL_SYM(GetErrorString, "ncclGetErrorString") KL_RCCL_SYM(CommCount, "ncclCommCount")
 #undef KL_RCCL_SYM
         return a;
     }();
@@ -237,6 +238,11 @@ struct klnmf_ctx {
     // loop's third iteration on (the first updates from W0 = V.H0^T can carry ratios far beyond fp8's range).
     bool q8_ok = false, q8_loop = false;
     int64_t iter_in_loop = 0;
+    // what the last loop actually ran (klnmf_query): iterations whose ratio tiles were fp8, whose column pass was fp8 x fp8
+    int64_t stat_q8_tiles = 0, stat_col8 = 0;
+    // the refusal counters of DevState (v_overflow, op_range) change only on uploads and image measurements: they are read
+    // back (one copy + synchronisation) only when one of those happened since the last check
+    bool refusals_dirty = true;
     double v_max = 0.0;          // the maximum announced with klnmf_set_v_max (0: none)
     // fp8 ratio tiles in this iteration?  k > 256 (FUSED row pass, KSPLIT = 2 column pass) has only the fp8 x fp8 column pass
     // for them: there the W image's scales must have been measured (the loop's second iteration does that)
@@ -506,6 +512,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
         a.w8max = c->w8max;
     }
     const int grid = (c->nrt + kWavesPerWG - 1) / kWavesPerWG;
+    if (mode == ROW_UPDATE && a.Qt && c->pingpong() && c->q8()) c->stat_q8_tiles += 1;      // this update leaves fp8 ratio tiles
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
     const bool v16 = c->prec == KLNMF_PREC_BF16;
@@ -622,6 +629,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         if (!c->w8_tail) w8_convert();
         if (!c->w8_tail) c->w8_meas = true;
         if (use8) {
+        c->stat_col8 += 1;
         if (c->profiling) ev = begin_event(c, c->ev_col);
         ColPass8Args a8{a, c->W8, c->w8s};
         switch (c->KT) {
@@ -735,6 +743,7 @@ void fast_pack_W(klnmf_ctx *c) {
 // klnmf_set_W -- see opnd_t in mfma.hip.h).  They are valid for one update; the update's W rule packs the next W image
 // with the hs-based / row-normalised scale again.
 void measure_and_pack(klnmf_ctx *c) {
+    c->refusals_dirty = true;
     HIPCHK(hipMemsetAsync(c->wmax, 0, (size_t)c->KP * 4, c->stream));
     HIPCHK(hipMemsetAsync(&c->st->op_range, 0, sizeof(int), c->stream));
     const int rows_grid = (int)std::min<int64_t>(c->n_pad, 1024);
@@ -961,6 +970,7 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
     }
     HIPCHK(hipGetLastError());
     c->v_uploaded = true;
+    c->refusals_dirty = true;
 }
 
 void check_block(klnmf_ctx *c, int64_t rows, int64_t cols, int64_t ld, int64_t row0, int64_t col0) {
@@ -1215,6 +1225,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         c->cur = 0;
         c->sparse = false;
         c->v_uploaded = false;
+        c->refusals_dirty = true;
         c->v_scale = 1.0;
         c->nnz = 0;
         c->st = (DevState *)c->dalloc(sizeof(DevState));
@@ -1279,6 +1290,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->nst = c->nct / 2;
             c->v_scale = 1.0;
             c->v_uploaded = false;
+            c->refusals_dirty = true;
             const int total_stages = c->nrt / kStageRowTiles;
             // bf16 W images are streamed in 64-row stages by global_load_lds in 8 KiB rounds: pad the tail
             c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + 64;
@@ -1422,6 +1434,7 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         c->cur = 0;
         c->sparse = true;
         c->v_uploaded = false;
+        c->refusals_dirty = true;
         c->v_scale = 1.0;
         c->nnz = nnz;
         const size_t es = c->esize();
@@ -1472,6 +1485,7 @@ int klnmf_upload_csr(klnmf_ctx *c, int dtype, const int64_t *indptr, const int64
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         c->v_uploaded = true;
+        c->refusals_dirty = true;
     });
 }
 
@@ -1518,6 +1532,7 @@ int klnmf_reset_V(klnmf_ctx *c) {
         HIPCHK(hipMemsetAsync(&c->st->v_overflow, 0, sizeof(int), c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->v_uploaded = false;
+        c->refusals_dirty = true;
     });
 }
 
@@ -1626,40 +1641,77 @@ int klnmf_init_W(klnmf_ctx *c) {
 }
 
 // fp16 storage: values above the maximum announced with klnmf_set_v_max were saturated on upload; a fit on such
-// a matrix is not the fit of the caller's data, so the loop entry points refuse it (one 4-byte read per loop).
-static void check_v_overflow(klnmf_ctx *c) {
-    if (c->is_exact()) return;
+// a matrix is not the fit of the caller's data, so every entry point that computes refuses it -- and a pair of factors the
+// fp16 operand images cannot hold (op_range).  The counters change only on uploads and image measurements: they are read
+// back (one copy + one synchronisation) only when one of those happened since the last check.
+struct Refusals { int v_overflow = 0, op_range = 0; };
+static Refusals read_refusals(klnmf_ctx *c) {
+    if (c->is_exact()) return Refusals{};
+    if (!c->refusals_dirty) return Refusals{};          // the last check of this state passed (a failing one stays dirty)
     DevState ds{};
     HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int flags[2] = {ds.v_overflow, ds.op_range};
-    // fp8 ratio tiles for this loop?  Their range ends at 3584 (saturating): data whose largest entry is more than 256 times
-    // the mean entry can hold ratios beyond that for many iterations (a spike the model has not fitted yet) -- those keep
-    // the 16-bit tiles.  KLNMF_QTILE = 8 forces the tiles on (from the third iteration), = 16 off.
+    Refusals r;
+    r.op_range = ds.op_range;
+    r.v_overflow = (c->prec == KLNMF_PREC_BF16 && c->v_uploaded) ? ds.v_overflow : 0;
+    return r;
+}
+static void raise_refusals(klnmf_ctx *c, const Refusals &r) {
+    if (r.op_range != 0)
+        fail(KLNMF_ERR_UNSUPP, "the factors exceed the fp16 operand range (max W x max H of " + std::to_string(r.op_range) +
+                                   " component(s) is more than 2^15 times the largest entry of V: an initial dictionary whose rows "
+                                   "sum to far more than 1?); run KLNMF_PREC_F32 / F64");
+    if (r.v_overflow != 0)
+        fail(KLNMF_ERR_ARG, "uploaded V exceeds the maximum given to klnmf_set_v_max (" + std::to_string(r.v_overflow) +
+                                " values out of the fp16 storage range)");
+    c->refusals_dirty = false;
+}
+static void check_v_overflow(klnmf_ctx *c) { raise_refusals(c, read_refusals(c)); }
+
+// Loop entry points only (klnmf_run, klnmf_run_sharded, klnmf_loop_begin): does THIS loop use fp8 ratio tiles?  Their range
+// ends at 3584 (saturating): data whose largest entry is more than 256 times the mean entry can hold ratios beyond that for
+// many iterations (a spike the model has not fitted yet) -- those keep the 16-bit tiles.  KLNMF_QTILE = 8 forces the tiles on
+// (from the third iteration), = 16 off.  `sum_x_global` / `cells_global`: the sums over ALL ranks' shards (the sharded loop
+// passes the all-reduced values, so that every rank takes the same path); negative: this context's own.
+static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cells_global = -1.0) {
     c->q8_loop = false;
     c->iter_in_loop = 0;
     c->w8_meas = false;
     c->w8_use = false;
-    if (c->q8_ok) {
-        const char *g = std::getenv("KLNMF_QTILE");
-        const double mean = ds.sum_x / c->v_scale / ((double)c->n * (double)c->f);
-        c->q8_loop = g ? std::atoi(g) == 8 : (c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean);
+    c->stat_q8_tiles = 0;
+    c->stat_col8 = 0;
+    if (c->is_exact() || !c->q8_ok) return;
+    const char *g = std::getenv("KLNMF_QTILE");
+    if (g) { c->q8_loop = std::atoi(g) == 8; return; }
+    double sum_x = sum_x_global, cells = cells_global;
+    if (sum_x < 0) {
+        DevState ds{};
+        HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        sum_x = ds.sum_x;
+        cells = (double)c->n * (double)c->f;
     }
-    if (flags[1] != 0)
-        fail(KLNMF_ERR_UNSUPP, "the factors exceed the fp16 operand range (max W x max H of " + std::to_string(flags[1]) +
-                                   " component(s) is more than 2^15 times the largest entry of V: an initial dictionary whose rows "
-                                   "sum to far more than 1?); run KLNMF_PREC_F32 / F64");
-    if (c->prec != KLNMF_PREC_BF16 || !c->v_uploaded) return;
-    const int ov = flags[0];
-    if (ov != 0)
-        fail(KLNMF_ERR_ARG, "uploaded V exceeds the maximum given to klnmf_set_v_max (" + std::to_string(ov) +
-                                " values out of the fp16 storage range)");
+    const double mean = sum_x / c->v_scale / cells;
+    c->q8_loop = c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean;
 }
 
 int klnmf_loop_begin(klnmf_ctx *c) {
     return guarded([&] {
         need_problem(c);
         check_v_overflow(c);
+        begin_fp8_loop(c);
+        reset_state(c);
+        c->loop_start_cur = c->cur;
+        c->loop_iters = 0;
+    });
+}
+
+int klnmf_loop_begin_sharded(klnmf_ctx *c, double sum_x_all, double cells_all) {
+    return guarded([&] {
+        need_problem(c);
+        if (!(sum_x_all >= 0) || !(cells_all > 0)) fail(KLNMF_ERR_ARG, "klnmf_loop_begin_sharded: the all-reduced sums must be given");
+        check_v_overflow(c);
+        begin_fp8_loop(c, sum_x_all * c->v_scale, cells_all);      // (the caller's sums are in the data's own units)
         reset_state(c);
         c->loop_start_cur = c->cur;
         c->loop_iters = 0;
@@ -1720,6 +1772,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         if (max_iter < 0) fail(KLNMF_ERR_ARG, "max_iter < 0");
         if (max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter exceeds the capacity given to klnmf_set_problem");
         check_v_overflow(c);
+        begin_fp8_loop(c);
         reset_state(c);
         c->loop_start_cur = c->cur;
         // bf16 modes: the stop rule inside the loss kernel -- one launch fewer per iteration (a small problem's
@@ -1815,7 +1868,7 @@ int klnmf_comm_init(klnmf_ctx *c, const void *id, int rank, int nranks) {
         RCCLCHK(rccl().CommInitRank(&c->comm, nranks, uid, rank));
         c->comm_rank = rank;
         c->comm_size = nranks;
-        HIPCHK(hipMalloc((void **)&c->comm_scratch, 2 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->comm_scratch, 8 * sizeof(double)));
     });
 }
 
@@ -1847,7 +1900,41 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         if (n_total < c->n) fail(KLNMF_ERR_ARG, "n_total smaller than this rank's rows");
         if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_run_sharded: dense problems only");
         const bool multi = c->comm != nullptr && c->comm_size > 1;
-        check_v_overflow(c);
+        // Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
+        // (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8
+        // decision is taken from the all-reduced sums, so that all ranks run the same kernels and N = 1 / N = 8 differ by
+        // summation order only.
+        Refusals mine;
+        std::string local_msg;
+        double sum_x_all = -1.0, cells_all = -1.0;
+        if (multi) {
+            c->refusals_dirty = true;
+            mine = read_refusals(c);
+            DevState ds{};
+            HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            double h[4] = {(double)(mine.v_overflow != 0), (double)(mine.op_range != 0), ds.sum_x, (double)c->n * (double)c->f};
+            HIPCHK(hipMemcpyAsync(c->comm_scratch, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+            RCCLCHK(rccl().GroupStart());
+            ncclResult_t r1 = rccl().AllReduce(c->comm_scratch, c->comm_scratch, 2, ncclDouble, ncclMax, c->comm, c->stream);
+            ncclResult_t r2 = rccl().AllReduce(c->comm_scratch + 2, c->comm_scratch + 2, 2, ncclDouble, ncclSum, c->comm, c->stream);
+            ncclResult_t r3 = rccl().GroupEnd();            // always closed, whatever the calls inside returned
+            RCCLCHK(r1); RCCLCHK(r2); RCCLCHK(r3);
+            HIPCHK(hipMemcpyAsync(h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (h[0] != 0 || h[1] != 0) {
+                if (mine.v_overflow || mine.op_range) raise_refusals(c, mine);       // this rank's own message
+                fail(h[1] != 0 ? KLNMF_ERR_UNSUPP : KLNMF_ERR_ARG,
+                     h[1] != 0 ? "another rank's factors exceed the fp16 operand range: the sharded loop is refused on every rank"
+                               : "another rank's shard of V exceeds the maximum given to klnmf_set_v_max: the sharded loop is refused on every rank");
+            }
+            c->refusals_dirty = false;
+            sum_x_all = h[2];
+            cells_all = h[3];
+        } else {
+            check_v_overflow(c);
+        }
+        begin_fp8_loop(c, sum_x_all, cells_all);
         reset_state(c);
         c->loop_start_cur = c->cur;
         const double tol_abs = tol * (double)n_total * (double)c->f;          // nmf.py:207 on the GLOBAL shape
@@ -1863,9 +1950,10 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
             if (fit) piece_colpass(c);                 // ... and of the numerator (it does not depend on the stop decision)
             if (multi) {
                 RCCLCHK(rccl().GroupStart());
-                if (fit) RCCLCHK(rccl().AllReduce(nbuf, nbuf, ncount, ntype, ncclSum, c->comm, c->stream));
-                RCCLCHK(rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream));
-                RCCLCHK(rccl().GroupEnd());
+                ncclResult_t ra = fit ? rccl().AllReduce(nbuf, nbuf, ncount, ntype, ncclSum, c->comm, c->stream) : ncclSuccess;
+                ncclResult_t rb = rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream);
+                ncclResult_t rc = rccl().GroupEnd();        // closed on the error path too
+                RCCLCHK(ra); RCCLCHK(rb); RCCLCHK(rc);
             }
             if (multi || c->is_exact()) piece_decide(c, tol_abs);      // identical inputs on every rank -> identical decisions
             if (fit) piece_update_H(c);
@@ -1968,6 +2056,9 @@ int klnmf_update(klnmf_ctx *c, int fit) {
         need_problem(c);
         check_v_overflow(c);
         reset_state(c);
+        // a single step always runs on 16-bit ratio tiles; the fp8 state of a loop around it is left as it was
+        struct Keep { klnmf_ctx *c; bool q8; ~Keep() { c->q8_loop = q8; } } keep{c, c->q8_loop};
+        c->q8_loop = false;
         piece_rowpass(c, fit);
         if (fit) {
             piece_colpass(c);
@@ -2133,6 +2224,41 @@ int klnmf_profile_read_tail(klnmf_ctx *c, int64_t *tail_n, double *tail_ms, int6
             for (auto &e : c->ev_tail) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
             c->ev_tail.clear();
         }
+    });
+}
+
+int klnmf_query(klnmf_ctx *c, int what, int64_t *value) {
+    return guarded([&] {
+        use(c);
+        if (!value) fail(KLNMF_ERR_ARG, "null value");
+        switch (what) {
+            case KLNMF_Q_FP8_LOOP: *value = c->q8_loop ? 1 : 0; break;
+            case KLNMF_Q_FP8_TILE_ITERS: *value = c->stat_q8_tiles; break;
+            case KLNMF_Q_FP8_COL_ITERS: *value = c->stat_col8; break;
+            case KLNMF_Q_RATIO_TILE_BYTES:          // per element of V: 0 = no stored ratio tiles, 2 = 16-bit, 1 = fp8 once a loop allows them
+                *value = (c->have_problem && c->Qt) ? (c->q8_ok ? 1 : 2) : 0;
+                break;
+            case KLNMF_Q_COMM_RANKS: {
+                int cnt = 1;
+                if (c->comm) RCCLCHK(rccl().CommCount(c->comm, &cnt));
+                *value = cnt;
+                break;
+            }
+            default: fail(KLNMF_ERR_ARG, "klnmf_query: unknown item");
+        }
+    });
+}
+
+int klnmf_query_f64(klnmf_ctx *c, int what, double *value) {
+    return guarded([&] {
+        need_problem(c);
+        if (!value) fail(KLNMF_ERR_ARG, "null value");
+        if (what != KLNMF_QF_SUM_V) fail(KLNMF_ERR_ARG, "klnmf_query_f64: unknown item");
+        if (c->is_exact()) { *value = 0.0; return; }
+        DevState ds{};
+        HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *value = ds.sum_x / c->v_scale;
     });
 }
 

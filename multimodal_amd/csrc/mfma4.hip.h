@@ -227,7 +227,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
     constexpr int TBUF = (MODE != ROW_LOSS && SPLIT == 0) ? NW * 32 * kTLD * 4 : 0;
 #endif
-    constexpr int ARENA = 4 * OBJ > TBUF ? 4 * OBJ : TBUF;
+    // EXPERIMENT (round 3, -DKL_VLDS=1; off): V tiles through wave-private LDS slots -- the tile of column tile t + VP - 1
+    // requested by LDS-DMA in E(t), three tiles = more than 4 us ahead of its use, and every wait of the main loop a COUNTED
+    // vmcnt over the wave's copies only (see seg_E), so that neither the HBM latency of a V tile nor the completion of a
+    // ratio store is ever waited for.  Results bit-identical (G11 green); row pass 3.63 vs 3.56 ms at C4 on one box
+    // (profiles/r03_ab_rowpass_experiments.txt): the latency was not what the kernel waits for -- the two extra LDS reads
+    // and the strided copies cost more than the deeper prefetch gives.  V served from L2 (-DKL_ABL_NOVDMA) is 6.8 % faster:
+    // that gain is the HBM traffic itself (power), not its latency.  DESIGN.md section 8, h25.
+#ifndef KL_VLDS
+#define KL_VLDS 0
+#endif
+#ifndef KL_VLDS_MIN_KT
+#define KL_VLDS_MIN_KT 5       // smaller k: fewer than 128 registers, two workgroups per CU hide the latency; 64 KiB of slots would cost that
+#endif
+    constexpr bool VL = KL_VLDS != 0 && NW == 8 && KT >= KL_VLDS_MIN_KT;
+    constexpr int VP = 4;                                         // slots per wave = tiles in flight + the one being consumed
+    constexpr int VSLOTS = VL ? NW * VP * TB : 0;
+    constexpr int ARENA = 4 * OBJ + VSLOTS > TBUF ? 4 * OBJ + VSLOTS : TBUF;
+    static_assert(ARENA + KP * 16 + 64 <= 160 * 1024, "LDS budget of the row pass");
     __shared__ __attribute__((aligned(16))) unsigned char arena[ARENA];
     KL_LDS unsigned char *const h0 = (KL_LDS unsigned char *)arena, *const h1 = h0 + OBJ, *const h2 = h0 + 2 * OBJ, *const h3 = h0 + 3 * OBJ;
     __shared__ __attribute__((aligned(16))) double hsum_lds[KP];     // row sums of H, for the sum(W.H) term of the loss
@@ -324,6 +341,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(t16), "s"(gbase) : "memory");
     };
     const unsigned vl32 = (unsigned)lane * 32u;              // this lane's 32 bytes of a V tile (vt is wave-uniform)
+    // ---- V through LDS (VL): this wave's slot ring, the copy of one tile (two 1 KiB pieces: the lanes' first / second 16
+    // bytes -> [piece][lane][16 B] in the slot, read back with two conflict-free ds_read_b128), the counted waits
+    constexpr int kDictFull = IMG / (NW * 1024), kDictRem = IMG % (NW * 1024);
+    const bool dict_extra = kDictRem > 0 && wave * 1024 < kDictRem;          // scalar: this wave issues one more piece per tile
+    const unsigned vs_base = VL ? (unsigned)(uintptr_t)h0 + 4u * OBJ + (unsigned)wave * (VP * TB) : 0u;      // scalar
+    const unsigned vs_lane = vs_base + (unsigned)lane * 16u;
+    auto v_dma = [&](int slot, int tg) {
+        const unsigned char *g0 = vt + (int64_t)min(tg, a.nct - 1) * TB, *g1 = g0 + 16;
+        const unsigned m0a = vs_base + (unsigned)slot * TB, m0b = m0a + 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4"
+                     ::"s"(m0a), "v"(vl32), "s"(g0), "s"(m0b), "s"(g1) : "memory");
+    };
+    // vmcnt counts loads, copies AND stores; stores may complete out of order with respect to loads, copies complete in
+    // issue order among themselves.  N below counts only the COPIES issued after the one waited for: a pending store makes
+    // the wait longer, never shorter than needed.
+    auto vm_wait = [&](auto NHI, auto NLO) {
+        if (dict_extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NHI)::value) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NLO)::value) : "memory");
+    };
     // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
     // ratio tiles: wave-uniform base (tiles of one column tile are consecutive in rt) + this lane's 16-byte piece(s)
     const bool qon = a.Qt != nullptr && active;                                      // scalar
@@ -558,13 +595,25 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #ifdef KL_STAMPS
         unsigned long long tw; KL_STAMP(tw);
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+        if constexpr (VL) {
+            // copies issued after the two pieces of V(tg) (in E(tg - VP + 1)): that segment's dictionary pieces, then
+            // (VP - 2) segments of 2 + dictionary pieces each
+            constexpr int NHI = (kDictFull + 1) + (VP - 2) * (2 + kDictFull + 1), NLO = kDictFull + (VP - 2) * (2 + kDictFull);
+            vm_wait(std::integral_constant<int, NHI>{}, std::integral_constant<int, NLO>{});
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va) : "v"(vs_lane), "n"((ts % VP) * TB));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb) : "v"(vs_lane), "n"((ts % VP) * TB + 1024));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+        }
 #ifdef KL_STAMPS
         { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
 #endif
 #ifndef KL_QSTORE_EARLY   // the previous tile's ratios (still in b0 / b1) leave here, a whole tile interval before the next wait
         if (tg > ct0) store_q(tg - 1);
 #endif
+        if constexpr (VL) {
+            v_dma((ts + VP - 1) % VP, tg + VP - 1);           // into the slot E(tg - 1) consumed
+        } else {
 #ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
         v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)((tg + 1) & 3) * TB, vl32);
 #else
@@ -573,8 +622,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // asm output before the data lands; and a pointer passed through an asm statement comes back as a FLAT one)
         v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)min(tg + 1, a.nct - 1) * TB, vl32);
 #endif
+        }
         if (grpY) dma((ts + 3) % 4, tg + 3);
         else dma((ts + 2) % 4, tg + 2);
+        if constexpr (VL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb));      // the two slot reads (nothing else of this wave is in flight in LDS)
         float q[16];
 #ifdef KL_NO_NUM_EPS
         float zero_f = 0.f;
@@ -615,6 +666,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
             const unsigned ra = lds_addr(Hobj(ts % 4));
             static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
+        }
+        if constexpr (VL) {
+            // this wave's slices of the dictionary tile it requested ONE E segment ago must have landed before the next
+            // barrier it joins (their first read follows that barrier): copies issued since = this segment's 2 + pieces
+            vm_wait(std::integral_constant<int, 2 + kDictFull + 1>{}, std::integral_constant<int, 2 + kDictFull>{});
         }
 #ifdef KL_STAMPS
         KL_STAMP(t1);
@@ -741,7 +797,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // ---- prologue: dictionary tiles 0 and 1 and V tile 0 in flight; the object of "tile -1" zero-filled
     dma(0, ct0);
     dma(1, ct0 + 1);
-    v_tile_load(vreg[0], vreg[1], vt + (int64_t)ct0 * TB, vl32);
+    if constexpr (VL) {
+        static_for<0, VP - 1>([&](auto S) { v_dma(decltype(S)::value, ct0 + decltype(S)::value); });
+    } else {
+        v_tile_load(vreg[0], vreg[1], vt + (int64_t)ct0 * TB, vl32);
+    }
     if constexpr (FUSED) v_tile_load(vreg[2], vreg[3], vt + (int64_t)min(1, a.nct - 1) * TB, vl32);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
@@ -945,7 +1005,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     opx4 wb;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
+#ifdef KL_ABL_WCLAMP       // timing-only builds whose matrix products are scrambled: W must stay sane over the bench's iterations
+                        w[t] *= fminf(fmaxf(gq[t] * tc[t], 0.999f), 1.001f);
+#else
                         w[t] *= gq[t] * tc[t];                              // the accumulator saw the dictionary image H / t
+#endif
                         wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);      // eps carrier
                     }
                     *(f32x4 *)(a.W32_new + (row0 + rl) * KP + comp) = w;
@@ -1076,7 +1140,11 @@ __global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nch
         opx4 wb;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+#ifdef KL_ABL_WCLAMP
+            w[t] *= fminf(fmaxf(g[t] * tc[t], 0.999f), 1.001f);
+#else
             w[t] *= g[t] * tc[t];
+#endif
             wb[t] = (comp + t == kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);
         }
         *(f32x4 *)(W32_new + off) = w;

@@ -141,8 +141,23 @@ class ShardedKLNMF(object):
         return None
 
     def begin(self):
-        self.ctx.loop_begin()
+        # every rank must take the same fp8 decision (16-bit modes): it is made from the sums over ALL shards, as
+        # klnmf_run_sharded does on the native path
+        if self.dist is not None and self.world_size > 1 and hasattr(self.ctx, 'sum_V'):
+            t = self.torch.tensor([self.ctx.sum_V(), float(self.n_local) * float(self.f)], dtype=self.torch.float64,
+                                  device=self.tensor_device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.ctx.loop_begin(float(t[0].item()), float(t[1].item()))
+        else:
+            self.ctx.loop_begin()
         self.iterations_enqueued = 0
+
+    def rccl_ranks(self):
+        """What RCCL reports for the native communicator (ncclCommCount); None on the torch path."""
+        if self.collective == 'native' and hasattr(self.ctx, 'query'):
+            from . import _native
+            return self.ctx.query(_native.Q_COMM_RANKS)
+        return None
 
     def iterate(self, fit=True, tol=0.0):
         """Enqueue one iteration (no host synchronisation)."""

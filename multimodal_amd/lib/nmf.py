@@ -122,6 +122,7 @@ class KLdivNMF(object):
         self.subit = subit
         self.precision = precision if precision is not None else _default_precision()
         self.device = device if device is not None else _default_device()
+        self.last_fp8_report = None         # set by every loop: what it ran on e4m3 operands (klnmf_query)
 
     # ------------------------------------------------------------ helpers ---
     def _sparse_route(self, *blocks):
@@ -201,6 +202,9 @@ class KLdivNMF(object):
                 ctx.set_H(self.components_)    # loop runs on components_ (nmf.py:214)
             tol_abs = self.tol * n_samples * n_features      # nmf.py:207
             errors, n_done, stopped = ctx.run(max_iter, _fit, tol_abs)
+            # what the loop ran on e4m3 operands (16-bit modes, large problems; all zero otherwise) -- as the library
+            # reports it (klnmf_query); no reference counterpart
+            self.last_fp8_report = ctx.fp8_report()
             W = ctx.get_W(dtype=out_dtype)
             if _fit and n_done > 0:
                 self.components_ = ctx.get_H(dtype=out_dtype)

@@ -214,7 +214,9 @@ def test_bench_defaults_follow_the_measurement_contract():
     import bench
     a = bench.parse_args([])
     assert (a.gpus, a.n, a.f, a.k, a.precision) == (1, 1000000, 4096, 200, 'f16')       # BASELINE.json configs[3]
-    assert a.tol == 0.0 and a.repeats == 5 and a.cpu_rows == 100000 and a.data == 'blocks'
+    assert a.tol == 0.0 and a.repeats == 5 and a.data == 'blocks'
+    # the CPU sample is the smallest context that runs fp8 ratio tiles, 1 + 7 iterations: the parity leg on it covers 6 fp8 ones
+    assert a.cpu_rows == 65536 and a.cpu_iters == 7 and a.segment_timeout > 0
 
 
 def test_scale_inverse_scales_W_columns_and_H_rows():

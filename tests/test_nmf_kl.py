@@ -184,6 +184,46 @@ def _fixture_or_skip(name):
 
 
 @pytest.mark.gpu
+def test_k500_fp8_path_50_iterations_against_reference():
+    """Fixture G14 = the REFERENCE on three stacked 1024-column modalities in different units (learner.py:53-56 with the
+    coefficients of experiment.py:70-72), 65 536 x 3072, k = 500, 50 iterations, tol = 0 (learner.py:39-41).  This is
+    the configuration where fp8 pays most (one rank's shard of C5): the FUSED row pass leaving fp8 half-tiles and the
+    KSPLIT = 2 fp8 x fp8 column pass -- asserted to have run (klnmf_query) -- must keep len(errors), every recorded
+    loss and the final KL within the north star's 1e-4 of the reference's own numbers."""
+    from multimodal_amd.learner import MultimodalLearner
+    g = _fixture_or_skip('g14_c5shape_k500_50it')
+    n, k, iters = int(g['n']), int(g['k']), int(g['iters'])
+    dims = [int(d) for d in g['dims']]
+    blocks, coefs, H0 = gi.synthetic_modalities(int(g['seed']), n, dims, k)
+    assert_allclose(coefs, g['coefs'], rtol=1e-12)
+    mods = ['m%d' % i for i in range(len(dims))]
+    X = MultimodalLearner(mods, dims, coefs, k).stack_data(mods, blocks)          # the stacked matrix train() fits
+    del blocks
+    assert abs(X.sum() - float(g['X_sum'])) <= 1e-9 * float(g['X_sum'])
+    ref = np.asarray(g['errors'])
+    assert len(ref) == iters and np.all(np.diff(ref) < 0)
+    m = nmf.KLdivNMF(n_components=k, max_iter=iters, tol=0, precision='f16')
+    m._init_dictionary = H0
+    with contextlib.redirect_stderr(io.StringIO()):
+        W, e = m.fit_transform(X, return_errors=True, scale_W=True)
+    e = np.asarray(e)
+    rep = m.last_fp8_report
+    assert rep['allowed'] and rep['tile_iterations'] >= iters - 2 and rep['column_pass_iterations'] >= iters - 3, rep
+    assert len(e) == len(ref) and np.all(np.diff(e) < 0)
+    assert_allclose(e[:3], ref[:3], rtol=1e-3)
+    assert_allclose(e[3:], ref[3:], rtol=KL_TOL)
+    final_ref = float(g['final'])
+    assert abs(m.error(X, W) - final_ref) <= KL_TOL * final_ref
+    true_g = nmf.KLdivNMF(n_components=k, precision='f64').error(X, W, H=m.components_)
+    assert abs(true_g - final_ref) <= KL_TOL * final_ref
+    f = X.shape[1]
+    sn, sf = n // 64, f // 64
+    assert_allclose(W[::sn], g['W_rows'], rtol=2e-2, atol=2e-3 * np.abs(g['W_rows']).max())
+    assert_allclose(m.components_[:, ::sf], g['H_cols'], rtol=2e-2, atol=2e-3 * np.abs(g['H_cols']).max())
+    assert_allclose(m.components_.sum(axis=1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['g11_c4shape_50it', 'g12_c2shape_200it'])
 def test_real_iteration_counts_tol0_against_reference(name):
     """MultimodalLearner.train runs tol = 0 (learner.py:39-40): the loop stops on ANY rise of the loss (nmf.py:215).
