@@ -173,9 +173,12 @@ template <typename VT> struct VTraits;
 template <> struct VTraits<_Float16> {
     typedef VRegsF16 Regs;
     static constexpr int kLaneBytes = 32;
+    // global tile = [16-byte piece p][lane][16 B] (k_tile_V): every load instruction of a wave moves 1 KiB of CONTIGUOUS
+    // memory = 8 whole cache lines (lane-major tiles -- [lane][32 B] -- made each of the two instructions touch all 16 lines
+    // of the tile and use half of each)
     static __device__ __forceinline__ Regs load(const void *tile, int lane) {
-        const f16x8 *p = (const f16x8 *)((const unsigned char *)tile + lane * 32);
-        Regs r; r.a = p[0]; r.b = p[1]; return r;
+        const unsigned char *p = (const unsigned char *)tile + lane * 16;
+        Regs r; r.a = *(const f16x8 *)p; r.b = *(const f16x8 *)(p + 1024); return r;
     }
     // tile image in LDS as written by stage_v_tile(): two 1 KiB halves, lane-linear
     static __device__ __forceinline__ Regs load_lds(const KL_LDS unsigned char *tile, int lane) {
@@ -193,8 +196,9 @@ template <> struct VTraits<float> {
     typedef VRegsF32 Regs;
     static constexpr int kLaneBytes = 64;
     static __device__ __forceinline__ Regs load(const void *tile, int lane) {
-        const f32x4 *p = (const f32x4 *)((const unsigned char *)tile + lane * 64);
-        Regs r; r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; return r;
+        const unsigned char *p = (const unsigned char *)tile + lane * 16;
+        Regs r; r.a = *(const f32x4 *)p; r.b = *(const f32x4 *)(p + 1024); r.c = *(const f32x4 *)(p + 2048); r.d = *(const f32x4 *)(p + 3072);
+        return r;
     }
     static __device__ __forceinline__ Regs load_lds(const KL_LDS unsigned char *tile, int lane) {
         Regs r;
@@ -221,12 +225,12 @@ __device__ __forceinline__ void glds_copy(const unsigned char *gsrc, KL_LDS unsi
     }
 }
 
-// One wave-private V tile (64 lanes x kLaneBytes) -> LDS, lane-linear 1 KiB pieces.
+// One wave-private V tile (kLaneBytes / 16 pieces of 1 KiB, each lane-linear) -> LDS.
 template <int LANE_BYTES>
 __device__ __forceinline__ void stage_v_tile(const unsigned char *gtile, KL_LDS unsigned char *ldst, int lane) {
 #pragma unroll
     for (int p = 0; p < LANE_BYTES / 16; ++p)
-        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gtile + lane * LANE_BYTES + 16 * p),
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gtile + 1024 * p + lane * 16),      // (the LDS image IS the global one)
                                          (KL_LDS void *)(ldst + 1024 * p), 16, 0, 0);
 }
 
@@ -242,7 +246,7 @@ __device__ __forceinline__ void stage_v_tile(const unsigned char *gtile, KL_LDS 
 #endif
 
 struct RowPassArgs {
-    const void *VtA;          // [nrt][nct][64 lanes][16] tiles, layout A
+    const void *VtA;          // [nrt][nct] tiles of 16 values per lane (layout A), stored piece-major: [16-byte piece][64 lanes][16 B]
     const opnd_t *Ht;         // [nst][KP][kHRow] dictionary stage images
     const opnd_t *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
     const float *W32_old;     // [n_pad][KP]
@@ -1002,8 +1006,10 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
         const int i = row & 31, c = col & 31;
         const int laneA = i + 32 * ((c >> 2) & 1), eA = 4 * (c >> 3) + (c & 3);
         const int laneB = c + 32 * ((i >> 2) & 1), eB = 4 * (i >> 3) + (i & 3);
-        VtA[((rt * nct + ctile) * 64 + laneA) * 16 + eA] = xs;
-        if (VtB) VtB[((ctile * nrt + rt) * 64 + laneB) * 16 + eB] = xs;      // only the recomputing column pass reads it
+        // a lane's 16 values are stored as 16-byte pieces, piece-major: [tile][piece][lane][EPP values] (VTraits::load)
+        constexpr int EPP = 16 / (int)sizeof(VT);
+        VtA[(rt * nct + ctile) * 1024 + (eA / EPP) * (64 * EPP) + laneA * EPP + (eA % EPP)] = xs;
+        if (VtB) VtB[(ctile * nrt + rt) * 1024 + (eB / EPP) * (64 * EPP) + laneB * EPP + (eB % EPP)] = xs;      // only the recomputing column pass reads it
         sx += xt;
         cc += (xt > 0 && xv > 0) ? xt * log(xt / xv) - (xt - xv) : (xv - xt);
     }

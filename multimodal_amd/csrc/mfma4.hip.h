@@ -110,8 +110,8 @@ __device__ __forceinline__ void lds_read_tr_pair(opx8 &dst, unsigned addr0, unsi
 // p: wave-uniform (scalar) address of the tile, off: this lane's byte offset -- the form the compiler turns into
 // `global_load_dwordx4 v, v_off, s[base]` (no 64-bit VALU address arithmetic in the epilogue segment)
 __device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p, unsigned off) {
-    a = *(const f16x8 *)(p + off);
-    b = *(const f16x8 *)(p + off + 16);
+    a = *(const f16x8 *)(p + off);              // tiles are piece-major (k_tile_V): each instruction = 1 KiB of contiguous memory
+    b = *(const f16x8 *)(p + off + 1024);
 }
 // global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
 template <int BYTES, int NW = kWaves4>
@@ -201,7 +201,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
     constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
     constexpr int NF = N1 + N2;              // fragments (= MFMAs) per M segment
-    constexpr int D = KL_PF < NF - 1 ? KL_PF : NF - 1;      // reads run D fragments ahead of their MFMA
+#ifndef KL_PF8
+#define KL_PF8 4               // the 8-wave kernels' distance (the FUSED order's ring is fixed by its interval at KL_PF = 3).  Round 3, C4,
+#endif                         // one box: 2 / 3 / 4 / 5 fragments ahead = 3.66 / 3.69 / 3.62 / 3.70 ms (profiles/r03_ab_rowpass_experiments.txt); 4 = 256 registers, no scratch
+    constexpr int PFD = NW == 8 ? KL_PF8 : KL_PF;
+    constexpr int D = PFD < NF - 1 ? PFD : NF - 1;      // reads run D fragments ahead of their MFMA
     constexpr int R = D + 1;
     constexpr int DP = D < N2 ? D : N2;      // fragments of the lead that are MFMA-2 reads (issued one segment early)
     // One wave per SIMD (NW = 4) has no partner whose matrix segment could cover its epilogue: the update pass then runs
@@ -219,6 +223,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     constexpr int IMG = KP * kRow4B;          // bytes of one dictionary tile image
     static_assert(IMG <= kObj4 && IMG % 16 == 0, "dictionary tile image size");
     constexpr int OBJ = IMG;
+    // bytes of a tile image that are actually copied per tile: component rows >= 16 KS are zero in every image (k and the
+    // eps carrier lie below), so they are zero-filled ONCE in the prologue and never copied -- at k = 200 (KT = 7, KS = 13)
+    // 13 instead of 14 copy instructions per tile and workgroup (-DKL_DICT_TRIM=0: copy whole images)
+#ifndef KL_DICT_TRIM
+#define KL_DICT_TRIM 1
+#endif
+    constexpr int CPY = (KL_DICT_TRIM != 0 && KS * 1024 < IMG) ? KS * 1024 : IMG;
     // one arena: the four dictionary tile objects of the main loop; after it, the waves' 32 x 32 fp32 transposition
     // buffers of the W rule (kTLD dwords per row: conflict-free 16-byte writes of the accumulator layout)
     constexpr int kTLD = 36;
@@ -312,11 +323,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #endif
         tg = min(tg, a.nct - 1);
 #if !(KL_SADDR & 1)
-        glds_copy_exact<IMG, NW>(ht + (int64_t)tg * IMG, Hobj(o), tid);
+        glds_copy_exact<CPY, NW>(ht + (int64_t)tg * IMG, Hobj(o), tid);
 #else
         // scalar base + this lane's 32-bit offset, LDS destination (M0) from scalars: no VALU address arithmetic in the
         // epilogue segment (hipcc makes a 64-bit per-lane pointer of the builtin's operand: v_mad_i64_i32 + v_readfirstlane)
-        constexpr int kRound4 = NW * 1024, FULL = IMG / kRound4, REM = IMG % kRound4;
+        constexpr int kRound4 = NW * 1024, FULL = CPY / kRound4, REM = CPY % kRound4;
         const unsigned char *gbase = ht + (int64_t)tg * IMG;
         const unsigned m0b = lds_addr(Hobj(o)) + (unsigned)wave * 1024u, t16 = (unsigned)tid * 16u;
 #pragma unroll
@@ -340,15 +351,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         unsigned t16 = tid * 16;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(t16), "s"(gbase) : "memory");
     };
-    const unsigned vl32 = (unsigned)lane * 32u;              // this lane's 32 bytes of a V tile (vt is wave-uniform)
+    const unsigned vl32 = (unsigned)lane * 16u;              // this lane's 16 bytes of each of the two pieces of a V tile (vt is wave-uniform)
     // ---- V through LDS (VL): this wave's slot ring, the copy of one tile (two 1 KiB pieces: the lanes' first / second 16
     // bytes -> [piece][lane][16 B] in the slot, read back with two conflict-free ds_read_b128), the counted waits
-    constexpr int kDictFull = IMG / (NW * 1024), kDictRem = IMG % (NW * 1024);
+    constexpr int kDictFull = CPY / (NW * 1024), kDictRem = CPY % (NW * 1024);
     const bool dict_extra = kDictRem > 0 && wave * 1024 < kDictRem;          // scalar: this wave issues one more piece per tile
     const unsigned vs_base = VL ? (unsigned)(uintptr_t)h0 + 4u * OBJ + (unsigned)wave * (VP * TB) : 0u;      // scalar
     const unsigned vs_lane = vs_base + (unsigned)lane * 16u;
     auto v_dma = [&](int slot, int tg) {
-        const unsigned char *g0 = vt + (int64_t)min(tg, a.nct - 1) * TB, *g1 = g0 + 16;
+        const unsigned char *g0 = vt + (int64_t)min(tg, a.nct - 1) * TB, *g1 = g0 + 1024;
         const unsigned m0a = vs_base + (unsigned)slot * TB, m0b = m0a + 1024u;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
                      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4"
@@ -806,6 +817,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int e = tid; e < IMG / 16; e += kThreads4) ((KL_LDS u32x4 *)h3)[e] = z;
+        if constexpr (CPY < IMG) {             // the never-copied rows of the other three objects
+            for (int e = tid; e < 3 * ((IMG - CPY) / 16); e += kThreads4) {
+                const int o = e / ((IMG - CPY) / 16), w = e % ((IMG - CPY) / 16);
+                ((KL_LDS u32x4 *)(h0 + o * OBJ + CPY))[w] = z;
+            }
+        }
         if (MODE != ROW_INIT)
             for (int e = tid; e < KP; e += kThreads4) hsum_lds[e] = a.hsum[e];
         if (MODE != ROW_LOSS)
