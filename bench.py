@@ -428,9 +428,8 @@ def main():
         col_ms = prof_tot['colpass_ms'] / max(1, prof_tot['colpass_launches'])
         fast16 = args.precision in ('f16', 'bf16')
         vbytes = 2 if fast16 else 4
-        pingpong = (fast16 and (k <= 224 or 256 < k <= 512)
-                    and os.environ.get('KLNMF_ROWPASS', '4') == '4')
-        stored_q = pingpong and (k > 256 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
+        pingpong = fast16 and k <= 512 and os.environ.get('KLNMF_ROWPASS', '4') == '4'      # (224 < k <= 256 joined in round 3)
+        stored_q = pingpong and (k > 224 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         # what the timed loop ran, as the LIBRARY reports it (klnmf_query), not a host-side copy of its rules: the loop's
         # first two iterations keep 16-bit tiles (the torch path's warm-up absorbs them when --warmup >= 2; the native
         # path's timed call is a loop of its own and starts with them)

@@ -221,6 +221,27 @@ int klnmf_get_W(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,k] */
 int klnmf_get_H(klnmf_ctx *ctx, void *dst, int dtype);   /* [k,f] */
 int klnmf_get_Q(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,f], F64/F32 modes */
 
+/* ---- device-resident operands (next-row N1) -------------------------------
+ * The evaluation of an experiment (experiment.py:233-277, 332-371) runs 2 M .. 12 transforms per run on a fixed dictionary,
+ * reconstructs modalities from the coefficients (learner.py:80-84) and compares in every space (evaluation.py:103-116).
+ * With these the dictionary, the coefficients and the reconstructions never leave the GPU: pointers are DEVICE memory on the
+ * context's device (e.g. torch tensors), row strides in elements.
+ *   klnmf_set_H_device           a column block of `components_` (nmf.py:283-284; get_dico / get_stacked_dicos,
+ *                                learner.py:43-51) from a device-resident dictionary: H[:, col0 : col0 + ncols] <- src
+ *                                ([k, ncols], rows `ld` apart); `last` != 0 on the block that completes the dictionary
+ *   klnmf_get_W_device           the coefficients of the last loop (what transform returns, nmf.py:291) -> [n, k], rows `ld` apart
+ *   klnmf_upload_V_device_rows_dt klnmf_upload_V_device_rows for float32 or float64 device-resident modalities
+ *   klnmf_matmul_device          reconstruct_modalit{y,ies} (learner.py:80-84): C[m,n] = A[m,kk] . B[kk,n]
+ *   klnmf_all_distances_device   all_distances (metrics.py:80-86) of two device matrices -> [na, nb] on the device */
+int klnmf_set_H_device(klnmf_ctx *ctx, const void *dsrc, int dtype, int64_t ld, int64_t col0, int64_t ncols, int last);
+int klnmf_get_W_device(klnmf_ctx *ctx, void *ddst, int dtype, int64_t ld);
+int klnmf_upload_V_device_rows_dt(klnmf_ctx *ctx, const void *dsrc, int dtype, const int64_t *drow_idx, int64_t rows,
+                                  int64_t cols, int64_t ld, int64_t row0, int64_t col0, double scale);
+int klnmf_matmul_device(int device, int dtype, int64_t m, int64_t n, int64_t kk, const void *dA, int64_t lda,
+                        const void *dB, int64_t ldb, void *dC, int64_t ldc);
+int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, int64_t nb, int64_t d, const void *dA,
+                               int64_t lda, const void *dB, int64_t ldb, void *dout);
+
 /* ---- introspection ------------------------------------------------------ */
 /* What a context decided and what its last loop actually ran -- no reference counterpart (the reference has one
  * arithmetic); bench.py and the parity tests read it instead of mirroring the library's rules on the host.
@@ -234,6 +255,17 @@ int klnmf_get_Q(klnmf_ctx *ctx, void *dst, int dtype);   /* [n,f], F64/F32 modes
 #define KLNMF_Q_FP8_COL_ITERS     2
 #define KLNMF_Q_RATIO_TILE_BYTES  3
 #define KLNMF_Q_COMM_RANKS        4
+/* e4m3 saturation in the last loop -- counted, and kept out of the result:
+ *   KLNMF_Q_W8_SATURATED     entries of the e4m3 W image beyond 448 x their component's scale (a column that more than doubled
+ *                            in one update), KLNMF_Q_W8_FALLBACKS the iterations whose H-numerator product therefore ran on the
+ *                            f16 W image instead;
+ *   KLNMF_Q_RATIO_SATURATED  ratio-tile entries at the tiles' maximum (ratio >= 3584): each is recomputed exactly and its excess
+ *                            added to the H numerator; KLNMF_Q_RATIO_UNFIXED those beyond the correction list's capacity (8192 per
+ *                            iteration) -- non-zero means H numerators of this loop were clipped; the loop then drops fp8 tiles */
+#define KLNMF_Q_W8_SATURATED      5
+#define KLNMF_Q_W8_FALLBACKS      6
+#define KLNMF_Q_RATIO_SATURATED   7
+#define KLNMF_Q_RATIO_UNFIXED     8
 int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 /*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */
 #define KLNMF_QF_SUM_V            0

@@ -92,6 +92,14 @@ SIGNATURES = {
     'klnmf_profile_read_tail': (_c.c_int, [_ctx_p, _c.POINTER(_i64), _c.POINTER(_c.c_double), _c.POINTER(_i64), _c.c_int]),
     'klnmf_synchronize': (_c.c_int, [_ctx_p]),
     'klnmf_query': (_c.c_int, [_ctx_p, _c.c_int, _c.POINTER(_i64)]),
+    'klnmf_set_H_device': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64, _i64, _i64, _c.c_int]),
+    'klnmf_get_W_device': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _i64]),
+    'klnmf_upload_V_device_rows_dt': (_c.c_int, [_ctx_p, _c.c_void_p, _c.c_int, _c.c_void_p, _i64, _i64, _i64, _i64, _i64,
+                                                 _c.c_double]),
+    'klnmf_matmul_device': (_c.c_int, [_c.c_int, _c.c_int, _i64, _i64, _i64, _c.c_void_p, _i64, _c.c_void_p, _i64,
+                                       _c.c_void_p, _i64]),
+    'klnmf_all_distances_device': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _i64, _i64, _i64, _c.c_void_p, _i64,
+                                              _c.c_void_p, _i64, _c.c_void_p]),
     'klnmf_query_f64': (_c.c_int, [_ctx_p, _c.c_int, _c.POINTER(_c.c_double)]),
     'klnmf_set_problem_sparse': (_c.c_int, [_ctx_p, _i64, _i64, _i64, _i64, _i64]),
     'klnmf_upload_csr': (_c.c_int, [_ctx_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
@@ -206,7 +214,20 @@ def all_distances(A, B, metric, device=0):
     return out
 
 
+def matmul_device(dA, lda, dB, ldb, dC, ldc, m, n, kk, f64=True, device=0):
+    """C[m, n] = A[m, kk] . B[kk, n] between DEVICE matrices (pointers, row strides in elements): klnmf_matmul_device."""
+    _check(load().klnmf_matmul_device(device, DT_F64 if f64 else DT_F32, int(m), int(n), int(kk), _c.c_void_p(dA), int(lda),
+                                      _c.c_void_p(dB), int(ldb), _c.c_void_p(dC), int(ldc)))
+
+
+def all_distances_device(dA, lda, dB, ldb, dout, na, nb, d, metric, f64=True, device=0):
+    """out[na, nb] = metric(A[i], B[j]) between DEVICE matrices: klnmf_all_distances_device."""
+    _check(load().klnmf_all_distances_device(device, DT_F64 if f64 else DT_F32, int(metric), int(na), int(nb), int(d),
+                                             _c.c_void_p(dA), int(lda), _c.c_void_p(dB), int(ldb), _c.c_void_p(dout)))
+
+
 Q_FP8_LOOP, Q_FP8_TILE_ITERS, Q_FP8_COL_ITERS, Q_RATIO_TILE_BYTES, Q_COMM_RANKS = 0, 1, 2, 3, 4
+Q_W8_SATURATED, Q_W8_FALLBACKS, Q_RATIO_SATURATED, Q_RATIO_UNFIXED = 5, 6, 7, 8
 
 
 def selftest(device=0):
@@ -365,6 +386,21 @@ class Context(object):
         """Rows row_idx[0..rows) (int64 device array) of a device-resident fp32 matrix."""
         _check(self._lib.klnmf_upload_V_device_rows(self._h, _c.c_void_p(dev_ptr), _c.c_void_p(row_idx_ptr),
                                                     rows, cols, ld, row0, col0, float(scale)))
+
+    def upload_V_device_rows_dt(self, dev_ptr, f64, row_idx_ptr, rows, cols, ld, row0=0, col0=0, scale=1.0):
+        """The same for a float32 or float64 device-resident matrix; row_idx_ptr 0: rows 0 .. rows - 1."""
+        _check(self._lib.klnmf_upload_V_device_rows_dt(self._h, _c.c_void_p(dev_ptr), DT_F64 if f64 else DT_F32,
+                                                       _c.c_void_p(row_idx_ptr) if row_idx_ptr else None, rows, cols, ld,
+                                                       row0, col0, float(scale)))
+
+    def set_H_device(self, dev_ptr, f64, ld, col0, ncols, last=True):
+        """H[:, col0 : col0 + ncols] from a device-resident dictionary (klnmf_set_H_device)."""
+        _check(self._lib.klnmf_set_H_device(self._h, _c.c_void_p(dev_ptr), DT_F64 if f64 else DT_F32, int(ld), int(col0),
+                                            int(ncols), 1 if last else 0))
+
+    def get_W_device(self, dev_ptr, f64, ld):
+        """The coefficients into device memory ([n, k], rows ld apart): klnmf_get_W_device."""
+        _check(self._lib.klnmf_get_W_device(self._h, _c.c_void_p(dev_ptr), DT_F64 if f64 else DT_F32, int(ld)))
 
     def set_H(self, H):
         H = _as_float_array(H)
@@ -563,4 +599,7 @@ class Context(object):
     def fp8_report(self):
         """{'allowed', 'tile_iterations', 'column_pass_iterations'} of the last loop -- read from the library, not re-derived."""
         return {'allowed': bool(self.query(Q_FP8_LOOP)), 'tile_iterations': self.query(Q_FP8_TILE_ITERS),
-                'column_pass_iterations': self.query(Q_FP8_COL_ITERS)}
+                'column_pass_iterations': self.query(Q_FP8_COL_ITERS),
+                # e4m3 saturation: counted and kept out of the result (see include/klnmf.h)
+                'w_image_saturated': self.query(Q_W8_SATURATED), 'w_image_fallback_iterations': self.query(Q_W8_FALLBACKS),
+                'ratio_saturated': self.query(Q_RATIO_SATURATED), 'ratio_unfixed': self.query(Q_RATIO_UNFIXED)}

@@ -43,6 +43,26 @@ constexpr int kQTile8 = 1024;                    // bytes of one 32 x 32 fp8 rat
 #define KL_COLQ8_NB (KL_COLQ8_PAIR == 2 ? 6 : 4)
 #endif
 
+// Ratio-tile bytes the H numerator cannot take as they are: 0x7E = e4m3 448 = a ratio of 3584 or MORE (the row pass's
+// conversion saturates: the excess would be missing), and every byte >= 0x60 = a ratio >= 256 -- a single entry that large
+// is not averaged over the rows any more (it can dominate its column's numerator: a spike the model has not fitted), so its
+// 3-bit significand (+-6 %) would show.  The column passes test their B-operand bytes (two VALU instructions per dword, in
+// the shadow of the stage's MFMAs) and list position + stored byte; k_q8_fixup recomputes those ratios exactly from V and
+// the masters and adds (exact - stored) to the summed numerator.  `dw` = the bytes of rows row0 .. row0 + 3 of column col.
+__device__ __forceinline__ unsigned q8_sat_mask(unsigned dw) { return (dw + 0x20202020u) & 0x80808080u; }      // bytes <= 0x7E: no carries
+__device__ __noinline__ void q8_list_append(DevState *st, uint2 *list, unsigned mask, unsigned dw, int row0, int col) {
+    for (int b = 0; b < 4; ++b)
+        if (mask & (0x80u << (8 * b))) {
+            const unsigned byte = (dw >> (8 * b)) & 0xffu;
+            const bool saturated = byte >= 0x7eu;
+            if (saturated) atomicAdd(&st->q8_sat_total, 1);
+            else if (st->q8_list_n >= kQ8ListCap / 2) continue;          // merely large entries never crowd out saturated ones
+            const int at = atomicAdd(&st->q8_list_n, 1);
+            if (at < kQ8ListCap) list[at] = make_uint2((unsigned)(row0 + b), (unsigned)col | (byte << 24));
+            else if (saturated) atomicAdd(&st->q8_unfixed, 1);
+        }
+}
+
 __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
 }
@@ -58,7 +78,9 @@ __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
 template <int KT, int NB, int KSPLIT = 1, int Q8 = 0, int PAIR = 1>
 __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     static_assert(kWavesPerWG == 8 && (KSPLIT == 1 || KSPLIT == 2) && KT % KSPLIT == 0, "wave decomposition");
-    static_assert(Q8 == 0 || (KSPLIT == 1 && sizeof(opnd_t) == 2), "fp8 ratio tiles: one wave per column tile");
+    static_assert(Q8 == 0 || sizeof(opnd_t) == 2, "fp8 ratio tiles: 16-bit operand builds");
+    // (Q8 with KSPLIT = 2 -- k > 256 -- exists only as the fallback of the fp8 x fp8 pass: both waves of a column tile copy
+    // the same 1 KiB tile, so that every wave issues the same number of copies and the counted wait stays valid)
     constexpr int QTB = Q8 ? kQTile8 : kQTile;      // bytes of a ratio tile
     constexpr int CTW = kWavesPerWG / KSPLIT;      // column tiles per workgroup
     constexpr int KTW = KT / KSPLIT;               // accumulator blocks per wave
@@ -81,6 +103,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char o4[NB > 4 ? OBJ : 16];
     __shared__ __attribute__((aligned(16))) unsigned char o5[NB > 5 ? OBJ : 16];
     if (a.st->stop) return;
+    if (a.guard == 2 && a.st->w8_sat == 0) return;           // fallback of the fp8 x fp8 pass: only when its W image clipped
+    if (a.guard == 2 && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&a.st_rw->w8_fallbacks, 1);
+        atomicAdd(&a.st_rw->w8_sat_total, a.st->w8_sat);
+    }
 #ifdef KL_COL_PRIO       // experiment: static priority for the second-dispatched half of the workgroup
     if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(KL_COL_PRIO);
 #endif
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         const unsigned char *qs = qt + (int64_t)sg * QTB;
 #pragma unroll
         for (int pp = 0; pp < QP; ++pp) {
-            const int p = kh * QP + pp;            // KSPLIT = 2: the two waves of a column tile copy one piece each
+            const int p = Q8 ? pp : kh * QP + pp;  // KSPLIT = 2: the two waves of a column tile copy one piece each (Q8: the same tile)
             __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + p * 256),
                                              (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
         }
@@ -153,7 +180,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         const unsigned char *qbase = qt_s + (int64_t)sg * QTB;
 #pragma unroll
         for (int pp = 0; pp < QP; ++pp) {
-            const int p = kh * QP + pp;            // KSPLIT = 2: the two waves of a column tile copy one piece each
+            const int p = Q8 ? pp : kh * QP + pp;  // KSPLIT = 2: the two waves of a column tile copy one piece each (Q8: the same tile)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + ctl * QTB + 1024 * p), "v"(ql32), "s"(qbase + p * 256) : "memory");
         }
 #endif
@@ -168,13 +195,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             __builtin_amdgcn_global_load_lds((const KL_GLB void *)(wn + (int64_t)sg * WST + i * kGldsRound + tid * 16),
                                              (KL_LDS void *)(obj(o) + i * kGldsRound + (tid & ~63) * 16), 16, 0, 0);
         } else {
-            const int p = kh * QP + (i - WR);
+            const int p = Q8 ? (i - WR) : kh * QP + (i - WR);
             __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qt + (int64_t)sg * QTB + p * 256),
                                              (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
         }
     };
     // o_next >= 0: the copies of stage sg_next into object o_next are issued BETWEEN this stage's MFMAs (KL_COLQ_INTERLEAVE)
-    auto compute = [&](unsigned base, int o_next = -1, int sg_next = 0) {
+    auto compute = [&](unsigned base, int stage_row0, int o_next = -1, int sg_next = 0) {
         opx8 ring[3];
         s16x4 q0, q1, q2, q3;
         if constexpr (Q8 != 0) {                   // q0 / q2: the 8 fp8 values of k-step 0 / 1 (two dwords each)
@@ -202,6 +229,17 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
             typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
             const u32x2 w0 = __builtin_bit_cast(u32x2, q0), w1 = __builtin_bit_cast(u32x2, q2);
+            if (a.q8_list != nullptr && kh == 0) {        // large / saturated ratio bytes (ratio >= 256 / >= 3584): listed for k_q8_fixup (colq8x.hip.h)
+                const unsigned m00 = q8_sat_mask(w0[0]), m01 = q8_sat_mask(w0[1]), m10 = q8_sat_mask(w1[0]), m11 = q8_sat_mask(w1[1]);
+                if ((m00 | m01 | m10 | m11) != 0u && active) {
+                    // dword w of k-step s: rows 16 s + 8 h + 4 w .. + 3 of the 32-row stage, physical column r
+                    const int col = 32 * ct + (8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3));
+                    if (m00) q8_list_append(a.st_rw, a.q8_list, m00, w0[0], stage_row0 + 8 * h, col);
+                    if (m01) q8_list_append(a.st_rw, a.q8_list, m01, w0[1], stage_row0 + 8 * h + 4, col);
+                    if (m10) q8_list_append(a.st_rw, a.q8_list, m10, w1[0], stage_row0 + 16 + 8 * h, col);
+                    if (m11) q8_list_append(a.st_rw, a.q8_list, m11, w1[1], stage_row0 + 16 + 8 * h + 4, col);
+                }
+            }
             // rows 8h + 2j, 8h + 2j + 1 of k-step 0 (b0) and of k-step 1 (b1); the byte-pair selector must be a literal
 #define KL_Q8_PAIR(dst, src, j, sel)                                                              \
             { const f16x2 p_ = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, kQ8Scale, sel); dst[2 * (j)] = p_[0]; dst[2 * (j) + 1] = p_[1]; }
@@ -261,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             constexpr int i = PAIR * decltype(I)::value;
             if (s0 + i < send) {                                   // uniform
 #ifdef KL_COLQ_INTERLEAVE
-                if constexpr (PAIR == 1) compute(lds_addr(obj(i)), (i + NB - 1) % NB, s0 + i + NB - 1);
+                if constexpr (PAIR == 1) compute(lds_addr(obj(i)), 32 * (s0 + i), (i + NB - 1) % NB, s0 + i + NB - 1);
                 else
 #endif
                 {
@@ -269,10 +307,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
                     constexpr int u = decltype(U)::value;
                     stage_in((i + NB - PAIR + u) % NB, s0 + i + NB - PAIR + u);
                 });
-                compute(lds_addr(obj(i)));
+                compute(lds_addr(obj(i)), 32 * (s0 + i));
                 }
                 if constexpr (PAIR == 2) {
-                    if (s0 + i + 1 < send) compute(lds_addr(obj((i + 1) % NB)));
+                    if (s0 + i + 1 < send) compute(lds_addr(obj((i + 1) % NB)), 32 * (s0 + i + 1));
                 }
                 fence();
             }

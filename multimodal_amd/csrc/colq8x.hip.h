@@ -27,8 +27,11 @@ __host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 
 // the column maxima of the f16 image for the NEXT iteration's scales (W moves slowly from one update to the next; the
 // scale leaves one binade of headroom and the conversion saturates).  Block = 8 rows x (KP / 8) threads: a thread keeps its
 // 8 components over all its rows.
+// sat != nullptr: entries whose scaled value exceeds e4m3's 448 (they are stored as 448) are counted there -- the image's
+// scales come from the PREVIOUS iteration's maxima with one binade of headroom, so a column that more than doubles in one
+// update clips; the column passes act on the count (k_colpass_q8x returns, the f16-operand pass runs instead).
 __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
-                                                    const float *w8s, unsigned *w8max, const DevState *st) {
+                                                    const float *w8s, unsigned *w8max, const DevState *st, int *sat = nullptr) {
     const int ld8 = w8_ld(kp);
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -41,6 +44,7 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
     const int comp = 8 * c8;
     f16x2 inv[4];
     float mx[8];
+    int nsat = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) inv[u] = f16x2{(_Float16)(1.f / w8s[comp + 2 * u]), (_Float16)(1.f / w8s[comp + 2 * u + 1])};
 #pragma unroll
@@ -67,6 +71,9 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
                     const f16x2 p0 = f16x2{v[q][4 * u], v[q][4 * u + 1]} * inv[2 * u], p1 = f16x2{v[q][4 * u + 2], v[q][4 * u + 3]} * inv[2 * u + 1];
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p0, 1.f, false);
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p1, 1.f, true);
+                    const f16x2 top = __builtin_elementwise_max(p0, p1);                    // (448 is an f16 number)
+                    nsat += (top[0] > (_Float16)448.f || top[1] > (_Float16)448.f) ? ((p0[0] > (_Float16)448.f) + (p0[1] > (_Float16)448.f)
+                                                                                     + (p1[0] > (_Float16)448.f) + (p1[1] > (_Float16)448.f)) : 0;
 #endif
                     out[u] = __builtin_bit_cast(unsigned, w);
                 }
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
             }
         }
     }
+    if (sat != nullptr && nsat != 0) atomicAdd(sat, nsat);
     // block maximum per component (positive floats order like their bit patterns)
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[e][threadIdx.x] = mx[e];
@@ -102,9 +110,10 @@ __global__ void k_w8_reduce(const unsigned *w8max, int64_t entries, int per_bloc
     for (int64_t e = e0; e < e1; ++e) mb = max(mb, w8max[e * kp + c]);
     atomicMax(final_max + c, mb);
 }
-__global__ void k_w8_scales(unsigned *final_max, float *w8s, int kp, const DevState *st) {
+__global__ void k_w8_scales(unsigned *final_max, float *w8s, int kp, DevState *st) {
     if (st->stop) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) st->w8_sat = 0;                       // the conversion that follows counts its own saturated entries
     if (c >= kp) return;
     const float m = __uint_as_float(final_max[c]);
     final_max[c] = 0u;
@@ -129,6 +138,71 @@ struct ColPass8Args {
     const unsigned char *W8;      // [rows][KP] e4m3 = f16 image / w8s[component]
     const float *w8s;             // [KP]
 };
+
+
+
+// The exact correction for ratio entries the fp8 tiles could not hold or hold too coarsely (listed by the column passes: colq.hip.h;
+// ONE block, after the slab sum, before the H rule).  For each (row i, column j, stored byte): the ratio from the masters,
+//   q = (x + eps) / (sum_a W_old[i][a] H[a][j] + eps),     excess = q - 8 x e4m3(byte)     (what the tile held)
+// and numer[a][j] += W_new image[i][a] * excess for every component -- what the product would have added had the tile held q.
+// (The masters instead of the f16 operand images: the difference is the operands' own rounding of a ratio that is hundreds
+// of times off -- second order.)  Saturated entries beyond the list's capacity are counted (q8_unfixed).
+struct Q8FixArgs {
+    DevState *st;
+    const uint2 *list;
+    const _Float16 *VtA;       // piece-major 32 x 32 tiles (k_tile_V)
+    const float *W32_old;      // [n_pad][KP]
+    const float *H32;          // [KP][f_pad]  (the OLD dictionary: the H rule has not run yet)
+    const opnd_t *Wb_new;      // [rows][wld] swizzled f16 image of W_new
+    float *numer;              // [KP][f_pad]
+    int nct, kp, k, wld;
+    int64_t f_pad;
+    float eps;
+};
+constexpr int kQ8FixBlocks = 64;      // entries are dealt round robin; usually the list is empty and every block leaves at once
+__global__ __launch_bounds__(512) void k_q8_fixup(Q8FixArgs a) {
+    if (a.st->stop) return;
+    __shared__ float red[8];
+    __shared__ float excess_s;
+    const int n_all = a.st->q8_list_n;
+    if (n_all == 0) return;                                   // (uniform over the grid: nobody resets the list while blocks still start)
+    const int n = n_all < kQ8ListCap ? n_all : kQ8ListCap;
+    const int tid = threadIdx.x;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const int64_t i = a.list[e].x, j = a.list[e].y & 0xffffffu;
+        const unsigned byte = a.list[e].y >> 24;
+        const float held = kQ8Scale * ldexpf(1.f + 0.125f * (float)(byte & 7u), (int)(byte >> 3) - 7);      // e4m3 normal (byte >= 0x60)
+        float part = 0.f;
+        for (int c = tid; c < a.k; c += blockDim.x) part += a.W32_old[i * a.kp + c] * a.H32[(int64_t)c * a.f_pad + j];
+        part = wave_sum(part);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        if (tid == 0) {
+            float d = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) d += red[w];
+            const int ii = (int)(i & 31), c = (int)(j & 31);
+            const int laneA = ii + 32 * ((c >> 2) & 1), eA = 4 * (c >> 3) + (c & 3);
+            const float x = (float)a.VtA[((i >> 5) * a.nct + (j >> 5)) * 1024 + (eA >> 3) * 512 + laneA * 8 + (eA & 7)];
+            const float rinv = 1.f / (d + a.eps);
+            excess_s = fmaf(x, rinv, a.eps * rinv) - held;
+        }
+        __syncthreads();
+        const float ex = excess_s;
+        for (int c = tid; c < a.kp; c += blockDim.x)       // (several listed rows may share a column: atomic adds)
+            atomicAdd(&a.numer[(int64_t)c * a.f_pad + j], (float)a.Wb_new[i * a.wld + wb_col((int)(i & 31), c)] * ex);
+        __syncthreads();
+    }
+    // the block that finishes last empties the list for the next iteration's column pass
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&a.st->q8_fix_done, 1) == (int)gridDim.x - 1) {
+            a.st->q8_fix_done = 0;
+            a.st->q8_list_n = 0;
+        }
+    }
+}
 
 // KSPLIT = 2 (KT > 8, k <= 512): the 8 waves are 4 column tiles x 2 halves of the component range (the accumulators of a
 // half fit two waves per SIMD); the two waves of a column tile read the same two ratio tiles and copy one each.
@@ -156,6 +230,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     __shared__ __attribute__((aligned(16))) unsigned char o3[NB > 3 ? OBJ : 16];
     __shared__ __attribute__((aligned(16))) unsigned char o4[NB > 4 ? OBJ : 16];
     if (a.st->stop) return;
+    if (a.guard == 1 && a.st->w8_sat != 0) return;           // this iteration's e4m3 W image clipped: the f16-operand pass behind runs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -209,7 +284,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + (2 * ctl + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
         }
     };
-    auto compute = [&](unsigned base) {
+    const int rcol_of_r = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);      // logical column of this lane's physical column
+    auto compute = [&](unsigned base, int stage_row0) {
         i32x2 bq[4];
         static_for<0, 4>([&](auto U) {
             constexpr int u = decltype(U)::value;
@@ -228,6 +304,19 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
         fetch(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
         const i32x8 bo = {bq[0][0], bq[0][1], bq[1][0], bq[1][1], bq[2][0], bq[2][1], bq[3][0], bq[3][1]};
+        if (a.q8_list != nullptr && kh == 0) {                // saturated ratio bytes of this lane's column (the two waves of a
+            unsigned any = 0u;                                  // column tile hold the same bytes: the first one reports)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) any |= q8_sat_mask((unsigned)bo[e]);
+            if (any != 0u && active) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned mk = q8_sat_mask((unsigned)bo[e]);
+                    // dword e = (u = e >> 1, w = e & 1): rows 32 h + 8 u + 4 w .. + 3 of the 64-row stage, physical column r
+                    if (mk) q8_list_append(a.st_rw, a.q8_list, mk, (unsigned)bo[e], stage_row0 + 32 * h + 8 * (e >> 1) + 4 * (e & 1), 32 * ct + rcol_of_r);
+                }
+            }
+        }
         static_for<0, KTW>([&](auto M) {
             constexpr int m = decltype(M)::value;
             fetch(std::integral_constant<int, m + 1>{});
@@ -250,7 +339,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             constexpr int i = decltype(I)::value;
             if (s0 + i < send) {
                 stage_in((i + NB - 1) % NB, s0 + i + NB - 1);
-                compute(lds_addr(obj(i)));
+                compute(lds_addr(obj(i)), 64 * (s0 + i));
                 fence();
             }
         });

@@ -23,7 +23,19 @@ struct DevState {
     int n_done;        // updates executed == len(errors)
     int v_overflow;    // uploaded values that exceeded the fp16 range announced with klnmf_set_v_max (saturated)
     int op_range;      // components whose measured fp16 operand images could not hold both factors (max W x max H > 2^30)
+    // ---- e4m3 saturation (16-bit modes, fp8 iterations; reset at every loop's entry).  Nothing that saturates reaches an H
+    // numerator uncorrected without being counted here (colq8x.hip.h, klnmf_query):
+    int w8_sat;        // entries of THIS iteration's e4m3 W image beyond 448 x its scale (reset before each conversion): non-zero ->
+                       // the fp8 x fp8 column pass of the iteration returns at once and the f16-operand one runs in its place
+    int w8_sat_total;  // ... summed over the loop
+    int w8_fallbacks;  // iterations whose column pass ran on the f16 W image for that reason
+    int q8_sat_total;  // ratio-tile entries found saturated (ratio > 3584) by the column passes, over the loop
+    int q8_list_n;     // entries appended to the fix-up list in this iteration (k_q8_fixup recomputes them exactly and resets it)
+    int q8_unfixed;    // saturated ratio entries beyond the list's capacity: their excess over 3584 is missing from an H numerator
+    int q8_fix_done;   // blocks of the running k_q8_fixup launch that have finished (the last one resets the list)
+    int pad_;
 };
+constexpr int kQ8ListCap = 8192;      // (row, column) pairs of saturated ratio entries per iteration that are corrected exactly
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -70,6 +82,8 @@ __global__ void k_reset_state(DevState *st) {
         st->prev_err = __longlong_as_double(0x7ff0000000000000LL);
         st->stop = 0;
         st->n_done = 0;
+        st->w8_sat = 0; st->w8_sat_total = 0; st->w8_fallbacks = 0;
+        st->q8_sat_total = 0; st->q8_list_n = 0; st->q8_unfixed = 0; st->q8_fix_done = 0;
     }
 }
 

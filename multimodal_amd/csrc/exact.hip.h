@@ -227,12 +227,14 @@ enum DistMetric { DIST_KL = 0, DIST_REV_KL = 1, DIST_SYM_KL = 2, DIST_FROBENIUS 
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_all_distances(const T *A, const T *B, T *out, int64_t na, int64_t nb,
-                                                        int64_t d, int metric, double eps) {
+                                                        int64_t d, int metric, double eps, int64_t lda = -1, int64_t ldb = -1) {
+    if (lda < 0) lda = d;
+    if (ldb < 0) ldb = d;
     const int lane = threadIdx.x & 63;
     const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= na * nb) return;
     const int64_t i = pair / nb, j = pair % nb;
-    const T *a = A + i * d, *b = B + j * d;
+    const T *a = A + i * lda, *b = B + j * ldb;
     double s0 = 0, s1 = 0, s2 = 0;
     for (int64_t e = lane; e < d; e += 64) {
         const double x = (double)a[e], y = (double)b[e];

@@ -240,13 +240,21 @@ struct klnmf_ctx {
     int64_t iter_in_loop = 0;
     // what the last loop actually ran (klnmf_query): iterations whose ratio tiles were fp8, whose column pass was fp8 x fp8
     int64_t stat_q8_tiles = 0, stat_col8 = 0;
+    uint2 *q8_list = nullptr;                 // [kQ8ListCap] saturated ratio entries of the current iteration (colq.hip.h)
+    bool in_capture = false;                  // a hipGraph capture is recording this context's launches (no synchronising polls)
+    // the saturation counters of the last loop as its end found them (DevState is reset by the next entry point)
+    int64_t stat_w8_sat = 0, stat_w8_fallbacks = 0, stat_q8_sat = 0, stat_q8_unfixed = 0;
     // the refusal counters of DevState (v_overflow, op_range) change only on uploads and image measurements: they are read
     // back (one copy + synchronisation) only when one of those happened since the last check
     bool refusals_dirty = true;
+    // single-context fit loops: the loss reduction + stop decision of an iteration ride in the slab-sum launch behind the
+    // column pass (k_sum_partials_f32) instead of a launch of their own behind the row pass; set by piece_rowpass,
+    // consumed by the next fast_colpass.  KLNMF_LOSS_DEFER=0: off.
+    LossArgs pending_loss{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0};
     double v_max = 0.0;          // the maximum announced with klnmf_set_v_max (0: none)
     // fp8 ratio tiles in this iteration?  k > 256 (FUSED row pass, KSPLIT = 2 column pass) has only the fp8 x fp8 column pass
     // for them: there the W image's scales must have been measured (the loop's second iteration does that)
-    bool q8() const { return q8_loop && iter_in_loop >= 2 && (KT <= 7 || (W8 != nullptr && w8_meas)); }
+    bool q8() const { return q8_loop && iter_in_loop >= 2 && (!big || (W8 != nullptr && w8_meas)); }
     float *W32[2] = {nullptr, nullptr};
     opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
@@ -277,9 +285,17 @@ struct klnmf_ctx {
     double *comm_scratch = nullptr;       // 2 doubles on the device, owned by the communicator (not by a problem)
 
     bool is_exact() const { return prec == KLNMF_PREC_F64 || prec == KLNMF_PREC_F32; }
-    static bool row_chunks_possible_q8(int64_t n) { return n >= 65536; }      // (below that the column-split update pass runs)
+    // fp8 ratio tiles from how many rows per context?  Their e4m3 rounding only enters the H numerator, a sum over all rows
+    // (relative error ~ 0.036 sqrt(2 / n)); measured against the fp64 oracle (scripts/fp8_rows_survey.py,
+    // profiles/r03_fp8_rows_survey.txt): final-KL deviation 1.7e-5 .. 3.5e-5 from 4096 to 50 000 rows at k = 50, 6.7e-6 .. 1.5e-5
+    // at k = 200 -- a floor that does not depend on n, a fifth of the 1e-4 budget.  k <= 224: from 32 769 rows, where the
+    // column-split update pass of small problems no longer runs (round 2: 65 536; C2 = 50 000 rows now qualifies).
+    // 256 < k <= 512: 65 536, the size fixture G14 pins.
+    static bool row_chunks_possible_q8(int64_t n, bool big_k) { return big_k ? n >= 65536 : n > 32768; }
     // ping-pong row pass (mfma4.hip.h): fp16-stored V; 8-wave workgroups for KT <= 7, 4-wave ones for 10 <= KT <= 16 (even)
-    bool pingpong() const { return prec == KLNMF_PREC_BF16 && row_gen == 4 && (KT <= 7 || KT > 8); }
+    // big: 224 < k <= 512 (KT = 8 .. 16, even): 4-wave workgroups, FUSED order, component-split column passes
+    bool big = false;
+    bool pingpong() const { return prec == KLNMF_PREC_BF16 && row_gen == 4 && (KT <= 7 || big); }
     size_t esize() const { return prec == KLNMF_PREC_F64 ? 8 : 4; }
     size_t vsize() const { return prec == KLNMF_PREC_BF16 ? 2 : 4; }
 
@@ -434,7 +450,7 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
 #else
         KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
         KL_ROW4_CASE(5) KL_ROW4_CASE(6) KL_ROW4_CASE(7)
-        KL_ROW4_BIG(10) KL_ROW4_BIG(12) KL_ROW4_BIG(14) KL_ROW4_BIG(16)
+        KL_ROW4_BIG(8) KL_ROW4_BIG(10) KL_ROW4_BIG(12) KL_ROW4_BIG(14) KL_ROW4_BIG(16)
 #endif
         default: fail(KLNMF_ERR_UNSUPP, "ping-pong row pass: 224 < k <= 256 runs on the generation-1 kernel");
     }
@@ -474,7 +490,7 @@ void w8_make_scales(klnmf_ctx *c, int64_t entries) {
     const int per_block = entries > 4096 ? 64 : 8;      // (128 rows per block left 8 blocks walking 1024 rows one by one: 58 us)
     hipLaunchKernelGGL(k_w8_reduce, dim3((unsigned)((entries + per_block - 1) / per_block)), dim3(512), 0, c->stream,
                        (const unsigned *)c->w8max, entries, per_block, c->w8fin, c->KP, (const DevState *)c->st);
-    hipLaunchKernelGGL(k_w8_scales, dim3(2), dim3(256), 0, c->stream, c->w8fin, c->w8s, c->KP, (const DevState *)c->st);
+    hipLaunchKernelGGL(k_w8_scales, dim3(2), dim3(256), 0, c->stream, c->w8fin, c->w8s, c->KP, c->st);
     HIPCHK(hipGetLastError());
 }
 
@@ -518,7 +534,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     const bool v16 = c->prec == KLNMF_PREC_BF16;
     if (c->pingpong()) {                               // ping-pong schedule (mfma4.hip.h), fp16 V only
         RowPass4Args a4{a, c->Ht4};
-        const int nw = c->KT > 8 ? 4 : kWaves4;
+        const int nw = c->big ? 4 : kWaves4;
         const int grid4 = (c->nrt + nw - 1) / nw;
         if (mode == ROW_UPDATE && c->row_chunks > 1) {     // few rows: column chunks in blockIdx.y, W rule from the slabs
             a4.base.gpart = c->Gpart;
@@ -589,6 +605,14 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
 }
 
+void launch_sum_partials(klnmf_ctx *c, int64_t count) {
+    const LossArgs la = c->pending_loss;
+    c->pending_loss.part = nullptr;
+    hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4) + (la.part ? 1 : 0)), dim3(256), 0, c->stream,
+                       (const float *)c->NpartF, c->numerF, count / 4, c->nchunks, (const DevState *)c->st, la);
+    HIPCHK(hipGetLastError());
+}
+
 void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     ColPassQArgs a{};
     a.Qt = c->Qt;
@@ -601,15 +625,47 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     a.nchunks = c->nchunks;
     a.stages_per_chunk = c->stages_per_chunk;
     a.f_pad = c->f_pad;
+    a.guard = 0;
+    a.st_rw = c->st;
+    a.q8_list = c->q8() ? c->q8_list : nullptr;       // fp8 tiles: the column pass lists saturated ratio bytes for k_q8_fixup
     const int grid = c->ncb * c->nchunks;
     EventPair ev{};
+    auto q8_fixup = [&]() {            // behind the slab sum, before the H rule: the excess of ratios beyond the tiles' 3584
+        if (!a.q8_list) return;
+        const bool off = std::getenv("KLNMF_Q8_FIXUP") && std::atoi(std::getenv("KLNMF_Q8_FIXUP")) == 0;      // (tests: the control run)
+        if (off) { HIPCHK(hipMemsetAsync(&c->st->q8_list_n, 0, sizeof(int), c->stream)); return; }
+        Q8FixArgs fa{c->st, c->q8_list, (const _Float16 *)c->VtA, (const float *)c->W32[c->cur], (const float *)c->H32,
+                     (const opnd_t *)c->Wb[c->cur ^ 1], c->numerF, c->nct, c->KP, (int)c->k, (int)w_ld(c->KP), c->f_pad,
+                     (float)(kEpsRatio * c->v_scale)};
+        hipLaunchKernelGGL(k_q8_fixup, dim3(kQ8FixBlocks), dim3(512), 0, c->stream, fa);
+        HIPCHK(hipGetLastError());
+    };
+    // the f16-operand pass on fp8 tiles (guard 2: only if this iteration's e4m3 W image clipped; 0: the regular pass of k <= 96)
+    auto launch_q2_on_fp8 = [&](int guard) {
+        ColPassQArgs g = a;
+        g.guard = guard;
+        switch (c->KT) {
+#define KL_Q2F8(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ8_NB, 1, 1, KL_COLQ8_PAIR>), dim3(grid), dim3(kThreads), 0, c->stream, g); break;
+#define KL_Q2F8_BIG(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, g); break;
+#ifdef KL_DEV_BUILD
+            KL_Q2F8(7) KL_Q2F8_BIG(16)
+#else
+            KL_Q2F8(1) KL_Q2F8(2) KL_Q2F8(3) KL_Q2F8(4) KL_Q2F8(5) KL_Q2F8(6) KL_Q2F8(7)
+            KL_Q2F8_BIG(8) KL_Q2F8_BIG(10) KL_Q2F8_BIG(12) KL_Q2F8_BIG(14) KL_Q2F8_BIG(16)
+#endif
+#undef KL_Q2F8
+#undef KL_Q2F8_BIG
+            default: fail(KLNMF_ERR_UNSUPP, "column pass on fp8 ratio tiles: k <= 224 or 256 < k <= 512");
+        }
+        HIPCHK(hipGetLastError());
+    };
     auto w8_convert = [&]() {          // e4m3 image of W_new with the current scales + this image's column maxima
         const int groups = c->KP / 8, rpb = std::max(1, 256 / groups);
         const int64_t rows = c->n_pad;
         const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
         c->w8_blocks = blocks;
         hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
-                           c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st);
+                           c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st, &c->st->w8_sat);
         HIPCHK(hipGetLastError());
     };
     if (c->W8 && c->q8_loop && !c->w8_tail && c->iter_in_loop == 1 && !c->w8_meas) {
@@ -631,6 +687,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         if (use8) {
         c->stat_col8 += 1;
         if (c->profiling) ev = begin_event(c, c->ev_col);
+        a.guard = c->w8_tail ? 0 : 1;      // (KLNMF_COL8=2: the W rule writes the image itself and does not count: no guard)
         ColPass8Args a8{a, c->W8, c->w8s};
         switch (c->KT) {
 #ifdef KL_DEV_BUILD
@@ -644,6 +701,8 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
             case 5: hipLaunchKernelGGL((k_colpass_q8x<5, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 6: hipLaunchKernelGGL((k_colpass_q8x<6, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            case 8: if (c->big) { hipLaunchKernelGGL((k_colpass_q8x<8, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break; }
+                    fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: KT = 8 only on the component-split path");
             case 10: hipLaunchKernelGGL((k_colpass_q8x<10, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 12: hipLaunchKernelGGL((k_colpass_q8x<12, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
             case 14: hipLaunchKernelGGL((k_colpass_q8x<14, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
@@ -652,12 +711,11 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
             default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: k <= 224 or 256 < k <= 512");
         }
         HIPCHK(hipGetLastError());
+        if (a.guard == 1) launch_q2_on_fp8(2);      // runs only if the conversion counted saturated entries (then the pass above returned)
         if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
         if (!sum_slabs) return;
-        const int64_t count8 = (int64_t)c->KP * c->f_pad;
-        hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count8 / 4)), dim3(256), 0, c->stream,
-                           (const float *)c->NpartF, c->numerF, count8 / 4, c->nchunks, (const DevState *)c->st);
-        HIPCHK(hipGetLastError());
+        launch_sum_partials(c, (int64_t)c->KP * c->f_pad);
+        q8_fixup();
         return;
         }
     }
@@ -674,7 +732,7 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         KL_COLQ_CASE(7) KL_COLQ_BIG(16)
 #else
         KL_COLQ_CASE(1) KL_COLQ_CASE(2) KL_COLQ_CASE(3) KL_COLQ_CASE(4) KL_COLQ_CASE(5) KL_COLQ_CASE(6) KL_COLQ_CASE(7)
-        KL_COLQ_BIG(10) KL_COLQ_BIG(12) KL_COLQ_BIG(14) KL_COLQ_BIG(16)
+        KL_COLQ_BIG(8) KL_COLQ_BIG(10) KL_COLQ_BIG(12) KL_COLQ_BIG(14) KL_COLQ_BIG(16)
 #endif
 #undef KL_COLQ_BIG
         default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: 224 < k <= 256 runs on the recomputing kernel");
@@ -683,11 +741,8 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     if (!sum_slabs) return;          // the H rule sums them itself (fast_pack_H from_slabs)
-    const int64_t count = (int64_t)c->KP * c->f_pad;
-    hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4)), dim3(256), 0, c->stream,
-                       (const float *)c->NpartF, c->numerF, count / 4, c->nchunks,
-                       (const DevState *)c->st);
-    HIPCHK(hipGetLastError());
+    launch_sum_partials(c, (int64_t)c->KP * c->f_pad);
+    q8_fixup();
 }
 
 void fast_colpass(klnmf_ctx *c) {
@@ -712,11 +767,7 @@ void fast_colpass(klnmf_ctx *c) {
     if (c->prec == KLNMF_PREC_BF16) launch_colpass_kt<_Float16>(c, a, grid);
     else launch_colpass_kt<float>(c, a, grid);
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
-    const int64_t count = (int64_t)c->KP * c->f_pad;
-    hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4)), dim3(256), 0, c->stream,
-                       (const float *)c->NpartF, c->numerF, count / 4, c->nchunks,
-                       (const DevState *)c->st);
-    HIPCHK(hipGetLastError());
+    launch_sum_partials(c, (int64_t)c->KP * c->f_pad);
 }
 
 void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false, const unsigned *wmax = nullptr) {
@@ -752,6 +803,20 @@ void measure_and_pack(klnmf_ctx *c) {
     HIPCHK(hipGetLastError());
     fast_pack_H(c, 0, false, c->wmax);
     fast_pack_W(c);
+}
+
+// Bulk saturation of the fp8 ratio tiles (more entries per iteration than k_q8_fixup's list holds: the data rule at the
+// loop's entry normally excludes such matrices): the loop gives the tiles up for its remaining iterations.  Polled at fp8
+// iterations 1, 2, 4, 8 and then every 16th (one DevState read-back each) -- bulk saturation is a property of the data and
+// the first updates, not something that develops late.
+void poll_fp8_overflow(klnmf_ctx *c) {
+    if (!c->q8_loop || !c->q8() || c->in_capture) return;
+    const int64_t n8 = c->stat_q8_tiles;
+    if (!(n8 == 1 || n8 == 2 || n8 == 4 || n8 == 8 || (n8 & 15) == 0)) return;
+    DevState hs{};
+    HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hs.q8_unfixed > 0) c->q8_loop = false;        // 16-bit tiles from the next iteration on (klnmf_query reports the count)
 }
 
 // ------------------------------------------------------------ exact pieces ---
@@ -899,6 +964,14 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
         // measured image scales live for one update: the new W image already carries the hs-based scale (tnext); in a fit
         // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
         if (measured && !fit) fast_pack_H(c, 0);
+        static const bool defer_ok = !(std::getenv("KLNMF_LOSS_DEFER") && std::atoi(std::getenv("KLNMF_LOSS_DEFER")) == 0);
+        if (fit && fused_tol && defer_ok) {
+            // a fit in one context: nothing needs the loss before the H rule -- it is reduced (and the stop rule applied) by
+            // one extra block of the slab-sum launch behind the column pass (launch_sum_partials)
+            c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 1, c->st,
+                                       *fused_tol, c->errors, c->cap};
+            return;
+        }
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const double2 *)c->loss_part2, c->loss_parts(),
                            (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
@@ -938,6 +1011,8 @@ void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopp
     }
     if (n_done) *n_done = hs.n_done;
     if (stopped) *stopped = hs.stop;
+    c->stat_w8_sat = hs.w8_sat_total; c->stat_w8_fallbacks = hs.w8_fallbacks;
+    c->stat_q8_sat = hs.q8_sat_total; c->stat_q8_unfixed = hs.q8_unfixed;
     // the current W is the one the last *executed* update wrote
     c->cur = (c->loop_start_cur + (int)(hs.n_done & 1)) & 1;
 }
@@ -1065,6 +1140,15 @@ void get_matrix(klnmf_ctx *c, void *dst, int dtype, int64_t rows, int64_t cols, 
 }  // namespace
 
 // =============================================================== exports ===
+template <typename D, typename S>
+static void copy_2d(klnmf_ctx *c, D *dst, int64_t dld, const S *src, int64_t sld, int64_t rows, int64_t cols, double mul = 1.0) {
+    if (rows * cols == 0) return;
+    hipLaunchKernelGGL((k_copy_2d<D, S>), dim3(grid_for(rows * cols, 256, 8192)), dim3(256), 0, c->stream, dst, dld, src, sld,
+                       rows, cols, mul);
+    HIPCHK(hipGetLastError());
+}
+
+
 template <typename T>
 static void distances_on_device(int metric, int64_t na, int64_t nb, int64_t d, const void *A, const void *B, void *out) {
     T *dA = nullptr, *dB = nullptr, *dO = nullptr;
@@ -1268,17 +1352,25 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->loss_part_count = ((f + GT - 1) / GT) * ((n + GT - 1) / GT);
             c->loss_part = (double *)c->dalloc(sizeof(double) * c->loss_part_count);
         } else {
+            c->row_gen = 4;          // (a pooled context keeps its handle across problems: an override of an earlier problem must not stick)
+            c->col_gen = 2;
             if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
             if (const char *g = std::getenv("KLNMF_COLPASS")) c->col_gen = std::atoi(g);
             c->KT = (int)((k + 31) / 32);
             c->ks = (int)((k + 15) / 16);
-            if (c->KT > 8) {
-                // 256 < k <= 512: 4-wave workgroups of the ping-pong row pass (whole register file per wave) and the
-                // component-split column pass; component tiles in pairs, the W.H contraction over all of them
-                if (!(c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && k <= 512))
+            c->big = false;
+            if (c->KT >= 8) {
+                // 224 < k <= 512: 4-wave workgroups of the ping-pong row pass (whole register file per wave, FUSED order) and
+                // the component-split column passes; component tiles in pairs, the W.H contraction over all of them.
+                // (Round 3: KT = 8 joined -- 224 < k <= 256 ran the generation-1 kernels with a second copy of V before.)
+                const bool can = c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && k <= 512;
+                if (c->KT > 8 && !can)
                     fail(KLNMF_ERR_UNSUPP, "k > 256 runs in KLNMF_PREC_BF16 (k <= 512, ping-pong row pass) or KLNMF_PREC_F32/F64");
-                c->KT = 2 * (int)((k + 63) / 64);
-                c->ks = 2 * c->KT;
+                if (can) {
+                    c->big = true;
+                    c->KT = 2 * (int)((k + 63) / 64);
+                    c->ks = 2 * c->KT;
+                }
             }
             c->KP = 32 * c->KT;
             // both passes work on 64-row / 64-column stages: pad to 64 (zero padding is inert)
@@ -1298,14 +1390,14 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * vs;
             // column pass on the ratios the ping-pong row pass stores (k_colpass_q) where that row pass runs;
             // otherwise the recomputing one, which needs the second, column-tiled copy of V
-            const bool stored_q = c->pingpong() && (c->col_gen >= 2 || c->KT > 8);
+            const bool stored_q = c->pingpong() && (c->col_gen >= 2 || c->big);
             // fp8 ratio tiles: only the H numerator -- a sum over all rows -- sees their 4-bit significands; its relative
             // error falls like 0.036 sqrt(2 / n) (5e-5 at 1M rows, 2e-4 at 65 536: below the operands' own rounding), so
             // they are used from 65 536 rows per context on (KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
             const bool col8_off = std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 0;
-            const bool q8_kt = c->KT <= 7 || (c->KT > 8 && !col8_off);      // (k > 256: fp8 tiles only with the fp8 x fp8 column pass)
-            c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->KT > 8) && c->row_chunks_possible_q8(n);
-            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->KT > 8) && std::atoi(g) == 8;
+            const bool q8_kt = !c->big || !col8_off;      // (k > 224: fp8 tiles only with the fp8 x fp8 column pass)
+            c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->big) && c->row_chunks_possible_q8(n, c->big);
+            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->big) && std::atoi(g) == 8;
             c->q8_loop = false;
             c->iter_in_loop = 0;
             c->v_max = 0.0;
@@ -1313,10 +1405,15 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
             c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8fin = nullptr; c->w8_meas = false;
-            if (c->q8_ok && !col8_off) {
+            c->q8_list = c->q8_ok ? (uint2 *)c->dalloc(sizeof(uint2) * kQ8ListCap) : nullptr;
+            // fp8 x fp8 column pass (e4m3 image of W_new): where the H-numerator product is worth three more small launches per
+            // iteration (conversion, maxima, scales) -- k > 96 and 65 536 rows or more; below that the f16-operand column pass
+            // reads the fp8 tiles (C2, k = 50: 0.053 ms against 0.050 + 0.03 ms of conversions; profiles/r03_c2_schedules.txt)
+            const bool col8_size = c->big || (c->KT >= 4 && n >= 65536) || (std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) >= 1);
+            if (c->q8_ok && !col8_off && col8_size) {
                 c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * w8_ld(c->KP) + 65536);
                 c->w8max = (unsigned *)c->dalloc(((size_t)c->nrt + kW8Blocks) * c->KP * 4);
-                c->w8_tail = c->KT <= 7 && std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
+                c->w8_tail = !c->big && std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
                 c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
                 c->w8fin = (unsigned *)c->dalloc((size_t)c->KP * 4);      // (dalloc hands out zero-filled blocks)
                 const std::vector<float> unit8((size_t)c->KP, 256.f);
@@ -1351,7 +1448,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
 #endif
             // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
-            const int ctw = c->KT > 8 ? kWavesPerWG / 2 : kWavesPerWG;      // column tiles per workgroup (colq.hip.h, KSPLIT)
+            const int ctw = c->big ? kWavesPerWG / 2 : kWavesPerWG;      // column tiles per workgroup (colq.hip.h, KSPLIT)
             c->ncb = (c->nct_used + ctw - 1) / ctw;
             int nch = 8;
             int64_t wg_per_cu = 1;       // workgroups per CU the decomposition aims at (one is resident per CU; 2 measured 1-3 % slower)
@@ -1369,7 +1466,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
             c->row_chunks = 1;
             c->row_ct_chunk = c->nct;
-            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8 && !c->q8_ok) {
+            if (c->pingpong() && !c->big && kWaves4 == 8 && !c->q8_ok) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 int want = (2 * nwg <= c->cu_count) ? c->cu_count / nwg : 1;
                 if (const char *g = std::getenv("KLNMF_ROW_SPLIT")) want = std::max(1, std::atoi(g));
@@ -1386,7 +1483,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // workgroup per CU: 254 registers).  Its workgroups are split into as many column chunks as fill the chip
             // once (n = 10^6: 67 workgroups x 3 chunks; 90 000 rows: 96 x 2).  KLNMF_ROW_TAIL = 0 switches it off.
             c->tail_wg = 0; c->tail_chunks = 1; c->tail_ct_chunk = c->nct;
-            if (c->pingpong() && c->KT <= 7 && kWaves4 == 8 && c->row_chunks == 1) {
+            if (c->pingpong() && !c->big && kWaves4 == 8 && c->row_chunks == 1) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 const int rem = nwg % c->cu_count;
                 int want = (nwg > c->cu_count && rem > 0) ? c->cu_count / rem : 1;
@@ -1602,6 +1699,69 @@ int klnmf_set_H(klnmf_ctx *c, const void *src, int dtype) {
     });
 }
 
+// ---- device-resident operands (next-row N1: the transforms of an evaluation keep dictionary, coefficients and
+// reconstructions on the GPU).  Pointers are DEVICE memory of the context's device; row strides in elements.
+int klnmf_set_H_device(klnmf_ctx *c, const void *dsrc, int dtype, int64_t ld, int64_t col0, int64_t ncols, int last) {
+    return guarded([&] {
+        need_problem(c);
+        if (!dsrc) fail(KLNMF_ERR_ARG, "null source");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (col0 < 0 || ncols < 0 || col0 + ncols > c->f || ld < ncols) fail(KLNMF_ERR_ARG, "klnmf_set_H_device: column block out of range");
+        if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_set_H_device: dense problems");
+        const bool f64 = dtype == KLNMF_DT_F64;
+        if (c->prec == KLNMF_PREC_F64) {
+            if (f64) copy_2d(c, (double *)c->H + col0, c->f, (const double *)dsrc, ld, c->k, ncols);
+            else copy_2d(c, (double *)c->H + col0, c->f, (const float *)dsrc, ld, c->k, ncols);
+        } else if (c->prec == KLNMF_PREC_F32) {
+            if (f64) copy_2d(c, (float *)c->H + col0, c->f, (const double *)dsrc, ld, c->k, ncols);
+            else copy_2d(c, (float *)c->H + col0, c->f, (const float *)dsrc, ld, c->k, ncols);
+        } else {
+            if (f64) copy_2d(c, c->H32 + col0, c->f_pad, (const double *)dsrc, ld, c->k, ncols);
+            else copy_2d(c, c->H32 + col0, c->f_pad, (const float *)dsrc, ld, c->k, ncols);
+        }
+        if (last) {
+            if (!c->is_exact()) {
+                fast_pack_H(c, 0);
+                measure_and_pack(c);
+            }
+            HIPCHK(hipStreamSynchronize(c->stream));      // the caller's buffer may go away
+        }
+    });
+}
+
+int klnmf_get_W_device(klnmf_ctx *c, void *ddst, int dtype, int64_t ld) {
+    return guarded([&] {
+        need_problem(c);
+        if (!ddst) fail(KLNMF_ERR_ARG, "null destination");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (ld < c->k) fail(KLNMF_ERR_ARG, "klnmf_get_W_device: row stride shorter than k");
+        const bool f64 = dtype == KLNMF_DT_F64;
+        if (c->prec == KLNMF_PREC_F64) {
+            if (f64) copy_2d(c, (double *)ddst, ld, (const double *)c->W[c->cur], c->k, c->n, c->k);
+            else copy_2d(c, (float *)ddst, ld, (const double *)c->W[c->cur], c->k, c->n, c->k);
+        } else if (c->prec == KLNMF_PREC_F32) {
+            if (f64) copy_2d(c, (double *)ddst, ld, (const float *)c->W[c->cur], c->k, c->n, c->k);
+            else copy_2d(c, (float *)ddst, ld, (const float *)c->W[c->cur], c->k, c->n, c->k);
+        } else {
+            if (f64) copy_2d(c, (double *)ddst, ld, (const float *)c->W32[c->cur], (int64_t)c->KP, c->n, c->k, 1.0 / c->v_scale);
+            else copy_2d(c, (float *)ddst, ld, (const float *)c->W32[c->cur], (int64_t)c->KP, c->n, c->k, 1.0 / c->v_scale);
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int klnmf_upload_V_device_rows_dt(klnmf_ctx *c, const void *dsrc, int dtype, const int64_t *drow_idx, int64_t rows,
+                                  int64_t cols, int64_t ld, int64_t row0, int64_t col0, double scale) {
+    return guarded([&] {
+        need_problem(c);
+        if (!dsrc) fail(KLNMF_ERR_ARG, "null source");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        check_block(c, rows, cols, ld, row0, col0);
+        if (dtype == KLNMF_DT_F64) place_block<double>(c, (const double *)dsrc, rows, cols, ld, row0, col0, scale, drow_idx);
+        else place_block<float>(c, (const float *)dsrc, rows, cols, ld, row0, col0, scale, drow_idx);
+    });
+}
+
 int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
     return guarded([&] {
         need_problem(c);
@@ -1792,6 +1952,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
             }
             c->cur ^= 1;
             c->iter_in_loop += 1;
+            if (fit) poll_fp8_overflow(c);
         };
         auto stopped_already = [&]() -> bool {        // the stop rule may have fired: the remaining (no-op) iterations need not be enqueued
             DevState hs{};
@@ -1816,14 +1977,17 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
             const int cur_before = c->cur;
             hipError_t ge = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
             if (ge == hipSuccess) {
+                c->in_capture = true;
                 try {
                     one_iteration();
                     one_iteration();
                 } catch (...) {
+                    c->in_capture = false;
                     (void)hipStreamEndCapture(c->stream, &graph);
                     if (graph) (void)hipGraphDestroy(graph);
                     throw;
                 }
+                c->in_capture = false;
                 ge = hipStreamEndCapture(c->stream, &graph);
                 if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             }
@@ -1959,6 +2123,7 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
             if (fit) piece_update_H(c);
             c->cur ^= 1;
             c->iter_in_loop += 1;
+            if (fit) poll_fp8_overflow(c);
             if (tol_abs > 0 && (it & 15) == 15) {
                 DevState hs{};
                 HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
@@ -2238,6 +2403,10 @@ int klnmf_query(klnmf_ctx *c, int what, int64_t *value) {
             case KLNMF_Q_RATIO_TILE_BYTES:          // per element of V: 0 = no stored ratio tiles, 2 = 16-bit, 1 = fp8 once a loop allows them
                 *value = (c->have_problem && c->Qt) ? (c->q8_ok ? 1 : 2) : 0;
                 break;
+            case KLNMF_Q_W8_SATURATED: *value = c->stat_w8_sat; break;
+            case KLNMF_Q_W8_FALLBACKS: *value = c->stat_w8_fallbacks; break;
+            case KLNMF_Q_RATIO_SATURATED: *value = c->stat_q8_sat; break;
+            case KLNMF_Q_RATIO_UNFIXED: *value = c->stat_q8_unfixed; break;
             case KLNMF_Q_COMM_RANKS: {
                 int cnt = 1;
                 if (c->comm) RCCLCHK(rccl().CommCount(c->comm, &cnt));
@@ -2281,6 +2450,53 @@ int klnmf_matmul(int device, int dtype, int64_t m, int64_t n, int64_t kk, const 
         if (kk == 0) { std::memset(C, 0, (size_t)(m * n) * (dtype == KLNMF_DT_F64 ? 8 : 4)); return; }
         if (dtype == KLNMF_DT_F64) matmul_on_device<double>(m, n, kk, A, B, C);
         else matmul_on_device<float>(m, n, kk, A, B, C);
+    });
+}
+
+int klnmf_matmul_device(int device, int dtype, int64_t m, int64_t n, int64_t kk, const void *dA, int64_t lda, const void *dB,
+                        int64_t ldb, void *dC, int64_t ldc) {
+    return guarded([&] {
+        if (m < 0 || n < 0 || kk < 0 || m > (1LL << 30) || n > (1LL << 30) || kk > (1LL << 30))
+            fail(KLNMF_ERR_ARG, "klnmf_matmul_device: bad shape");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_matmul_device: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (m == 0 || n == 0) return;
+        if (m > (int64_t)65535 * GT) fail(KLNMF_ERR_UNSUPP, "klnmf_matmul_device: more than 65535 x 64 rows");
+        if (!dA || !dB || !dC || lda < kk || ldb < n || ldc < n) fail(KLNMF_ERR_ARG, "klnmf_matmul_device: null pointer or short stride");
+        HIPCHK(hipSetDevice(device));
+        dim3 grid((unsigned)((n + GT - 1) / GT), (unsigned)((m + GT - 1) / GT), 1);
+        if (dtype == KLNMF_DT_F64) {
+            EpiStore<double> epi{(double *)dC, ldc};
+            hipLaunchKernelGGL((k_gemm<double, EpiStore<double>>), grid, dim3(256), 0, 0, (int)m, (int)n, (int)kk, (const double *)dA,
+                               lda, (int64_t)1, (const double *)dB, ldb, (int64_t)1, (int)kk + GK, (const DevState *)nullptr, epi);
+        } else {
+            EpiStore<float> epi{(float *)dC, ldc};
+            hipLaunchKernelGGL((k_gemm<float, EpiStore<float>>), grid, dim3(256), 0, 0, (int)m, (int)n, (int)kk, (const float *)dA,
+                               lda, (int64_t)1, (const float *)dB, ldb, (int64_t)1, (int)kk + GK, (const DevState *)nullptr, epi);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(0));
+    });
+}
+
+int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, int64_t nb, int64_t d, const void *dA, int64_t lda,
+                               const void *dB, int64_t ldb, void *dout) {
+    return guarded([&] {
+        if (na < 0 || nb < 0 || d < 0 || na > (1LL << 24) || nb > (1LL << 24) || d > (1LL << 30))
+            fail(KLNMF_ERR_ARG, "klnmf_all_distances_device: bad shape");
+        if (metric < DIST_KL || metric > DIST_COSINE_DIFF) fail(KLNMF_ERR_ARG, "klnmf_all_distances_device: unknown metric");
+        if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_all_distances_device: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
+        if (na == 0 || nb == 0) return;
+        if (!dout || (d > 0 && (!dA || !dB)) || lda < d || ldb < d) fail(KLNMF_ERR_ARG, "klnmf_all_distances_device: null pointer or short stride");
+        HIPCHK(hipSetDevice(device));
+        const int64_t pairs = na * nb;
+        if (dtype == KLNMF_DT_F64)
+            hipLaunchKernelGGL((k_all_distances<double>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, 0, (const double *)dA,
+                               (const double *)dB, (double *)dout, na, nb, d, metric, kEpsRatio, lda, ldb);
+        else
+            hipLaunchKernelGGL((k_all_distances<float>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, 0, (const float *)dA,
+                               (const float *)dB, (float *)dout, na, nb, d, metric, kEpsRatio, lda, ldb);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(0));
     });
 }
 

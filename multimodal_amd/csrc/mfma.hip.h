@@ -720,6 +720,11 @@ struct ColPassQArgs {
     const DevState *st;
     int nrt, nct, ncb, nchunks, stages_per_chunk;
     int64_t f_pad;
+    // fp8 iterations: guard = 1: the fp8 x fp8 pass, returns at once when this iteration's e4m3 W image saturated (st->w8_sat);
+    // guard = 2: the f16-operand pass launched behind it, runs ONLY then.  0: no guard.
+    int guard;
+    DevState *st_rw;          // saturation counters and the fix-up list's fill (fp8 ratio tiles only)
+    uint2 *q8_list;           // [kQ8ListCap] (row, feature column) of saturated ratio entries
 };
 constexpr int kQTile = 2048;                                         // bytes of one 32x32 bf16 ratio tile
 __host__ __device__ constexpr int colq_lds_stage(int kp) { return w_stage_lds(kp) + kWavesPerWG * kStageRowTiles * kQTile; }
@@ -961,6 +966,17 @@ __global__ void k_place_padded(float *dst, int64_t dld, const S *src, int64_t ro
         dst[i * dld + c] = (float)(mul * (double)src[e]);
     }
 }
+// [rows, cols] block between two device matrices of any row strides and element types (device-resident operands:
+// klnmf_set_H_device, klnmf_get_W_device)
+template <typename D, typename S>
+__global__ void k_copy_2d(D *dst, int64_t dld, const S *src, int64_t sld, int64_t rows, int64_t cols, double mul) {
+    const int64_t total = rows * cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / cols, c = e % cols;
+        dst[i * dld + c] = (D)(mul * (double)src[i * sld + c]);
+    }
+}
 template <typename D>
 __global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t rows, int64_t cols,
                                 double mul) {
@@ -1024,6 +1040,42 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
 // loss_local = (ln2 * sum(s1) + sum(s2) - sum_x - C) / c   (fixed summation order)
 // decide != 0 (single-context loop, klnmf_run): the stop rule of nmf.py:214-220 in the same launch (k_decide's body;
 // one kernel latency less per iteration, which is what a small problem's iteration consists of).
+struct LossArgs {
+    const double2 *part;      // nullptr: no loss work in this launch
+    int64_t count;
+    double inv_c;
+    double *out;
+    int decide;
+    DevState *st_rw;
+    double tol_abs;
+    double *errors;
+    int64_t cap;
+};
+// one block: fixed-order fp64 reduction of the row pass's loss partials, then (decide) the stop rule of nmf.py:214-220
+__device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const DevState *st, double *red) {
+    double a = 0, b = 0;
+    for (int64_t e = threadIdx.x; e < la.count; e += blockDim.x) {
+        const double2 p = la.part[e];
+        a += p.x;
+        b += p.y;
+    }
+    const double ta = block_sum(a, red);
+    const double tb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        const double err = (kLn2 * ta + tb - st->sum_x - st->corr_c) * la.inv_c;
+        la.out[0] = err;
+        la.out[1] = 0;
+        if (la.decide) {
+            if (la.st_rw->prev_err - err < la.tol_abs) {
+                la.st_rw->stop = 1;
+            } else {
+                la.st_rw->prev_err = err;
+                if (la.st_rw->n_done < la.cap) la.errors[la.st_rw->n_done] = err;
+                la.st_rw->n_done += 1;
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, int64_t count,
                                                           const DevState *st, double inv_c,
                                                           double *out, int decide = 0, DevState *st_rw = nullptr,
@@ -1031,37 +1083,28 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, i
                                                           int64_t cap = 0) {
     if (st->stop) return;
     __shared__ double red[16];
-    double a = 0, b = 0;
-    for (int64_t e = threadIdx.x; e < count; e += blockDim.x) {
-        const double2 p = part[e];
-        a += p.x;
-        b += p.y;
-    }
-    const double ta = block_sum(a, red);
-    const double tb = block_sum(b, red);
-    if (threadIdx.x == 0) {
-        const double err = (kLn2 * ta + tb - st->sum_x - st->corr_c) * inv_c;
-        out[0] = err;
-        out[1] = 0;
-        if (decide) {
-            if (st_rw->prev_err - err < tol_abs) {
-                st_rw->stop = 1;
-            } else {
-                st_rw->prev_err = err;
-                if (st_rw->n_done < cap) errors[st_rw->n_done] = err;
-                st_rw->n_done += 1;
-            }
-        }
-    }
+    const LossArgs la{part, count, inv_c, out, decide, st_rw, tol_abs, errors, cap};
+    loss_from_parts_block(la, st, red);
 }
 
+// Fixed-order sum of the column pass's slabs.  With la.part set, ONE extra block (the grid's last) also reduces the row
+// pass's loss partials and takes the stop decision: in a fit the loss is only needed before the H rule, so it rides in
+// this launch instead of one of its own between the two passes (a launch + a dependent boundary per iteration: 2 % of a
+// C2 iteration, 15 % of one at the reference's own data sizes).  If the rule fires, this iteration's column pass has run
+// for nothing and k_update_pack_H (next on the stream) does not apply it.
 __global__ void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
-                                   const DevState *st) {
+                                   const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0}) {
     if (st && st->stop) return;
+    if (la.part != nullptr && blockIdx.x == gridDim.x - 1) {
+        __shared__ double red[16];
+        loss_from_parts_block(la, st, red);
+        return;
+    }
+    const int64_t nblk = la.part != nullptr ? gridDim.x - 1 : gridDim.x;
     const f32x4 *p = (const f32x4 *)part;
     f32x4 *o = (f32x4 *)out;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < count4;
-         e += (int64_t)gridDim.x * blockDim.x) {
+         e += nblk * blockDim.x) {
         f32x4 s = p[e];
         for (int z = 1; z < nslab; ++z) s += p[z * count4 + e];
         o[e] = s;

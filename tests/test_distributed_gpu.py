@@ -85,6 +85,7 @@ def test_native_collective_path_single_rank_communicator(precision):
             if native:
                 ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
                 assert ctx.comm_max(3.25) == 3.25
+                assert ctx.query(_native.Q_COMM_RANKS) == 1          # what RCCL itself reports (ncclCommCount): bench.py prints it
             ctx.upload_blocks([X])
             ctx.set_H(H0)
             ctx.init_W()
@@ -117,3 +118,9 @@ def test_bench_two_rank_rehearsal():
     assert d['n_gpus'] == 2 and d['valid'] and d['scaling'] == 'strong' and d['steps'] == 4
     assert d['config']['rows_per_gpu'] == 10016 and len(d['segments_ms_per_step']) == 2
     assert d['loss_finite_and_decreasing'] and d['value'] > 0
+    # what a driver needs to trust an N > 1 line: which collective path ran, how many ranks RCCL saw (None on the gloo
+    # rehearsal: no RCCL communicator), and what the loop ran on e4m3 operands as the LIBRARY reports it
+    cfg = d['config']
+    assert cfg['collective_path'] == 'torch' and 'rccl_ranks' in cfg and cfg['rccl_ranks'] is None
+    assert cfg['fp8']['source'] == 'klnmf_query' and cfg['fp8']['timed_iterations_with_fp8_ratio_tiles'] == 0      # 10 016 rows per rank
+    assert d['dtype'] == 'f16' and d['value_16bit'] is None

@@ -250,3 +250,19 @@ def test_build_staleness_sees_every_kernel_header():
         assert ge._stale()
     finally:
         os.utime(hdr, (st.st_atime, st.st_mtime))
+
+
+def test_bench_watchdog_exits_nonzero_with_a_diagnostic():
+    """A rank stuck in a collective no peer will join must not hang the job: bench.py runs every segment under a timer
+    that prints what the rank was doing and leaves with status 3 (os._exit: never a re-exec, no clean-up that could block)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(0.3, 'segment 0 (test)', 5):\n    time.sleep(20)\n" % root)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3
+    assert 'watchdog' in r.stderr and 'rank 5' in r.stderr and 'segment 0 (test)' in r.stderr
+    ok = subprocess.run([sys.executable, '-c', "import sys; sys.path.insert(0, %r); import bench\nwith bench.Watchdog(30, 'x', 0):\n    pass\n" % root],
+                        capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0

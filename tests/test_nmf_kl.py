@@ -148,7 +148,8 @@ def test_config4_k500_three_modalities():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,f,k', [(4096, 1536, 500), (3000, 700, 300), (2048, 512, 384), (2048, 384, 430), (1024, 256, 512)])
+@pytest.mark.parametrize('n,f,k', [(4096, 1536, 500), (3000, 700, 300), (2048, 512, 384), (2048, 384, 430), (1024, 256, 512),
+                                   (2048, 512, 256), (3000, 700, 240), (1500, 384, 225)])      # 224 < k <= 256: KT = 8 on the same path (round 3)
 def test_config4_k_up_to_512_bf16_final_kl(n, f, k):
     """256 < k <= 512 in the bf16 mode against the fp64 reference: every accumulator count of the 4-wave row pass
     (KT = 10, 12, 14, 16), k a multiple of 64 (no spare component for the eps carrier) and not, ragged n and f,
