@@ -522,6 +522,11 @@ def main():
                        'fp8': {'loop_allowed': bool(fp8 and fp8['allowed']),
                                'timed_iterations_with_fp8_ratio_tiles': fp8_iters,
                                'timed_iterations_with_fp8_x_fp8_column_pass': col8_iters,
+                               # e4m3 saturation of the last timed loop: counted and kept out of the result (include/klnmf.h)
+                               'w_image_saturated_entries': fp8['w_image_saturated'] if fp8 else None,
+                               'w_image_fallback_iterations': fp8['w_image_fallback_iterations'] if fp8 else None,
+                               'ratio_entries_saturated': fp8['ratio_saturated'] if fp8 else None,
+                               'ratio_entries_unfixed': fp8['ratio_unfixed'] if fp8 else None,
                                'source': 'klnmf_query'},
                        'rccl_ranks': model.rccl_ranks() if n_gpus > 1 else None,
                        'collective_path': collective if n_gpus > 1 else None,

@@ -46,21 +46,14 @@ constexpr int kQTile8 = 1024;                    // bytes of one 32 x 32 fp8 rat
 // Ratio-tile bytes the H numerator cannot take as they are: 0x7E = e4m3 448 = a ratio of 3584 or MORE (the row pass's
 // conversion saturates: the excess would be missing), and every byte >= 0x60 = a ratio >= 256 -- a single entry that large
 // is not averaged over the rows any more (it can dominate its column's numerator: a spike the model has not fitted), so its
-// 3-bit significand (+-6 %) would show.  The column passes test their B-operand bytes (two VALU instructions per dword, in
-// the shadow of the stage's MFMAs) and list position + stored byte; k_q8_fixup recomputes those ratios exactly from V and
-// the masters and adds (exact - stored) to the summed numerator.  `dw` = the bytes of rows row0 .. row0 + 3 of column col.
+// 3-bit significand (+-6 %) would show.  The column passes only keep a branch-free sticky flag per feature column while they
+// stream (a rarely-taken branch with a call inside the stage loop cost the fp8 x fp8 pass 12 %: profiles/r03_ab_colpass_detection.txt)
+// and report (row chunk, column tile, physical column) SUSPECTS when they finish; k_q8_fixup (colq8x.hip.h) re-reads the
+// suspects' tile bytes, recomputes every large ratio exactly from V and the masters and corrects the summed numerator.
 __device__ __forceinline__ unsigned q8_sat_mask(unsigned dw) { return (dw + 0x20202020u) & 0x80808080u; }      // bytes <= 0x7E: no carries
-__device__ __noinline__ void q8_list_append(DevState *st, uint2 *list, unsigned mask, unsigned dw, int row0, int col) {
-    for (int b = 0; b < 4; ++b)
-        if (mask & (0x80u << (8 * b))) {
-            const unsigned byte = (dw >> (8 * b)) & 0xffu;
-            const bool saturated = byte >= 0x7eu;
-            if (saturated) atomicAdd(&st->q8_sat_total, 1);
-            else if (st->q8_list_n >= kQ8ListCap / 2) continue;          // merely large entries never crowd out saturated ones
-            const int at = atomicAdd(&st->q8_list_n, 1);
-            if (at < kQ8ListCap) list[at] = make_uint2((unsigned)(row0 + b), (unsigned)col | (byte << 24));
-            else if (saturated) atomicAdd(&st->q8_unfixed, 1);
-        }
+__device__ __forceinline__ void q8_suspect_append(DevState *st, uint2 *list, int chunk, int ct, int pcol) {
+    const int at = atomicAdd(&st->q8_list_n, 1);
+    if (at < kQ8ListCap) list[at] = make_uint2((unsigned)chunk | ((unsigned)pcol << 16), (unsigned)ct);
 }
 
 __device__ __forceinline__ void lds_read_tr(s16x4 &dst, unsigned addr) {
@@ -200,8 +193,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
                                              (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
         }
     };
+    unsigned q8_flag = 0u;             // fp8 tiles: sticky "a byte >= 0x60 passed through this lane" (its feature column: physical column r)
     // o_next >= 0: the copies of stage sg_next into object o_next are issued BETWEEN this stage's MFMAs (KL_COLQ_INTERLEAVE)
     auto compute = [&](unsigned base, int stage_row0, int o_next = -1, int sg_next = 0) {
+        (void)stage_row0;
         opx8 ring[3];
         s16x4 q0, q1, q2, q3;
         if constexpr (Q8 != 0) {                   // q0 / q2: the 8 fp8 values of k-step 0 / 1 (two dwords each)
@@ -229,17 +224,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
             typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
             const u32x2 w0 = __builtin_bit_cast(u32x2, q0), w1 = __builtin_bit_cast(u32x2, q2);
-            if (a.q8_list != nullptr && kh == 0) {        // large / saturated ratio bytes (ratio >= 256 / >= 3584): listed for k_q8_fixup (colq8x.hip.h)
-                const unsigned m00 = q8_sat_mask(w0[0]), m01 = q8_sat_mask(w0[1]), m10 = q8_sat_mask(w1[0]), m11 = q8_sat_mask(w1[1]);
-                if ((m00 | m01 | m10 | m11) != 0u && active) {
-                    // dword w of k-step s: rows 16 s + 8 h + 4 w .. + 3 of the 32-row stage, physical column r
-                    const int col = 32 * ct + (8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3));
-                    if (m00) q8_list_append(a.st_rw, a.q8_list, m00, w0[0], stage_row0 + 8 * h, col);
-                    if (m01) q8_list_append(a.st_rw, a.q8_list, m01, w0[1], stage_row0 + 8 * h + 4, col);
-                    if (m10) q8_list_append(a.st_rw, a.q8_list, m10, w1[0], stage_row0 + 16 + 8 * h, col);
-                    if (m11) q8_list_append(a.st_rw, a.q8_list, m11, w1[1], stage_row0 + 16 + 8 * h + 4, col);
-                }
-            }
+            // large / saturated ratio bytes (ratio >= 256 / >= 3584) of this lane's column: sticky, reported at the kernel's end
+            q8_flag |= q8_sat_mask(w0[0]) | q8_sat_mask(w0[1]) | q8_sat_mask(w1[0]) | q8_sat_mask(w1[1]);
             // rows 8h + 2j, 8h + 2j + 1 of k-step 0 (b0) and of k-step 1 (b1); the byte-pair selector must be a literal
 #define KL_Q8_PAIR(dst, src, j, sel)                                                              \
             { const f16x2 p_ = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(src, kQ8Scale, sel); dst[2 * (j)] = p_[0]; dst[2 * (j) + 1] = p_[1]; }
@@ -319,6 +305,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS copy may outlive the workgroup
 
     if (!active) return;
+    if constexpr (Q8 != 0) {
+        // suspects: the two lanes of a physical column (h = 0 / 1: different rows) report once; the two waves of a column tile
+        // (KSPLIT = 2) saw the same bytes: the first reports
+        if (a.q8_list != nullptr && kh == 0) {
+            const unsigned both = q8_flag | (unsigned)__shfl_xor((int)q8_flag, 32, 64);
+            if (h == 0 && both != 0u) q8_suspect_append(a.st_rw, a.q8_list, chunk, ct, r);
+        }
+    }
     // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r (Q8: the logical column of physical column r)
     const int rcol = Q8 ? 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3) : r;
     float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + rcol;

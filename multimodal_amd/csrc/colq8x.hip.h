@@ -31,7 +31,8 @@ __host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 
 // scales come from the PREVIOUS iteration's maxima with one binade of headroom, so a column that more than doubles in one
 // update clips; the column passes act on the count (k_colpass_q8x returns, the f16-operand pass runs instead).
 __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
-                                                    const float *w8s, unsigned *w8max, const DevState *st, int *sat = nullptr) {
+                                                    const float *w8s, unsigned *w8max, const DevState *st, int *sat = nullptr,
+                                                    int probe_col = -1) {
     const int ld8 = w8_ld(kp);
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -76,6 +77,12 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
                                                                                      + (p1[0] > (_Float16)448.f) + (p1[1] > (_Float16)448.f)) : 0;
 #endif
                     out[u] = __builtin_bit_cast(unsigned, w);
+                }
+                // the probe column (an unused pad component; k_colpass_q8x): e4m3 1.0 in every row -- its accumulator is the sum of the
+                // stage's ratio bytes per feature column
+                if (probe_col >= comp && probe_col < comp + 8) {
+                    const int pc = probe_col - comp;
+                    out[pc >> 2] = (out[pc >> 2] & ~(0xffu << (8 * (pc & 3)))) | (0x38u << (8 * (pc & 3)));
                 }
                 *(uint2 *)(W8 + row * ld8 + comp) = make_uint2(out[0], out[1]);
 #pragma unroll
@@ -137,67 +144,105 @@ struct ColPass8Args {
     ColPassQArgs q;
     const unsigned char *W8;      // [rows][KP] e4m3 = f16 image / w8s[component]
     const float *w8s;             // [KP]
+    int probe;                    // != 0: column KP - 1 of the image is the probe (1.0 in every row, k_w8_from_wb)
 };
 
 
 
-// The exact correction for ratio entries the fp8 tiles could not hold or hold too coarsely (listed by the column passes: colq.hip.h;
-// ONE block, after the slab sum, before the H rule).  For each (row i, column j, stored byte): the ratio from the masters,
-//   q = (x + eps) / (sum_a W_old[i][a] H[a][j] + eps),     excess = q - 8 x e4m3(byte)     (what the tile held)
-// and numer[a][j] += W_new image[i][a] * excess for every component -- what the product would have added had the tile held q.
+// The exact correction for ratio entries the fp8 tiles could not hold or hold too coarsely (after the slab sum, before the H
+// rule).  The column passes report SUSPECTS -- (row chunk, column tile, physical column) whose bytes included one >= 0x60 --;
+// each block takes suspects round robin, re-reads that column's bytes over the chunk's rows (the tiles are still in memory),
+// and for every byte >= 0x60 at (row i, column j):
+//   q = (x + eps) / (sum_a W_old[i][a] H[a][j] + eps)  from the masters,     held = 8 x e4m3(byte)  (what the tile held)
+//   numer[a][j] += W_new image[i][a] * q  -  (what the product added: its W operand x held)            for every component.
 // (The masters instead of the f16 operand images: the difference is the operands' own rounding of a ratio that is hundreds
-// of times off -- second order.)  Saturated entries beyond the list's capacity are counted (q8_unfixed).
+// of times off -- second order.)  Suspects beyond the list's capacity are counted (q8_unfixed): the loop then gives fp8 up.
 struct Q8FixArgs {
     DevState *st;
     const uint2 *list;
+    const unsigned char *Qt;   // fp8 ratio tiles [col tile][row tile][32 rows][32 physical columns]
     const _Float16 *VtA;       // piece-major 32 x 32 tiles (k_tile_V)
     const float *W32_old;      // [n_pad][KP]
     const float *H32;          // [KP][f_pad]  (the OLD dictionary: the H rule has not run yet)
     const opnd_t *Wb_new;      // [rows][wld] swizzled f16 image of W_new
     float *numer;              // [KP][f_pad]
-    int nct, kp, k, wld;
+    int nrt, nct, kp, k, wld, stages_per_chunk;
     int64_t f_pad;
     float eps;
+    // the fp8 x fp8 pass multiplied the e4m3 image of W_new, not the f16 one: what it added for a listed entry is
+    // e4m3(W8[i][a]) x w8s[a] x held -- that is taken out and W image x exact ratio put in (W8 = nullptr: the f16-operand pass ran)
+    const unsigned char *W8;
+    const float *w8s;
+    int w8ld;
 };
-constexpr int kQ8FixBlocks = 64;      // entries are dealt round robin; usually the list is empty and every block leaves at once
+__device__ __forceinline__ float e4m3_value(unsigned b) {
+    const int ex = (int)((b >> 3) & 15u), man = (int)(b & 7u);
+    return ex == 0 ? ldexpf((float)man, -9) : ldexpf(1.f + 0.125f * (float)man, ex - 7);
+}
+constexpr int kQ8FixBlocks = 64;      // suspects are dealt round robin; usually the list is empty and every block leaves at once
 __global__ __launch_bounds__(512) void k_q8_fixup(Q8FixArgs a) {
     if (a.st->stop) return;
     __shared__ float red[8];
-    __shared__ float excess_s;
+    __shared__ float q_s;
+    __shared__ int hits[64], nhit;
     const int n_all = a.st->q8_list_n;
     if (n_all == 0) return;                                   // (uniform over the grid: nobody resets the list while blocks still start)
     const int n = n_all < kQ8ListCap ? n_all : kQ8ListCap;
     const int tid = threadIdx.x;
+    const bool used_w8 = a.W8 != nullptr && a.st->w8_sat == 0;       // (a clipped image: the f16-operand pass ran in its place)
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
-        const int64_t i = a.list[e].x, j = a.list[e].y & 0xffffffu;
-        const unsigned byte = a.list[e].y >> 24;
-        const float held = kQ8Scale * ldexpf(1.f + 0.125f * (float)(byte & 7u), (int)(byte >> 3) - 7);      // e4m3 normal (byte >= 0x60)
-        float part = 0.f;
-        for (int c = tid; c < a.k; c += blockDim.x) part += a.W32_old[i * a.kp + c] * a.H32[(int64_t)c * a.f_pad + j];
-        part = wave_sum(part);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = part;
-        __syncthreads();
-        if (tid == 0) {
-            float d = 0.f;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) d += red[w];
-            const int ii = (int)(i & 31), c = (int)(j & 31);
-            const int laneA = ii + 32 * ((c >> 2) & 1), eA = 4 * (c >> 3) + (c & 3);
-            const float x = (float)a.VtA[((i >> 5) * a.nct + (j >> 5)) * 1024 + (eA >> 3) * 512 + laneA * 8 + (eA & 7)];
-            const float rinv = 1.f / (d + a.eps);
-            excess_s = fmaf(x, rinv, a.eps * rinv) - held;
+        const int chunk = (int)(a.list[e].x & 0xffffu), pcol = (int)(a.list[e].x >> 16), ct = (int)a.list[e].y;
+        const int64_t j = (int64_t)ct * 32 + (8 * ((pcol >> 2) & 3) + 4 * (pcol >> 4) + (pcol & 3));      // the logical column
+        const int row_lo = chunk * a.stages_per_chunk * 64, row_hi = min(a.nrt * 32, row_lo + a.stages_per_chunk * 64);
+        for (int base = row_lo; base < row_hi; base += 64 * 8) {          // 512 rows per sweep, hits handled 64 at a time
+            if (tid == 0) nhit = 0;
+            __syncthreads();
+            const int row = base + tid;
+            if (row < row_hi) {
+                const unsigned byte = a.Qt[((int64_t)ct * a.nrt + (row >> 5)) * 1024 + (row & 31) * 32 + pcol];
+                if (byte >= 0x60u) {
+                    if (byte >= 0x7eu) atomicAdd(&a.st->q8_sat_total, 1);
+                    const int at = atomicAdd(&nhit, 1);
+                    if (at < 64) hits[at] = (row - base) | ((int)byte << 16);
+                    else atomicAdd(&a.st->q8_unfixed, 1);         // (65 large ratios of one column within 512 rows: not a spike)
+                }
+            }
+            __syncthreads();
+            const int nh = min(nhit, 64);
+            for (int t = 0; t < nh; ++t) {
+                const int64_t i = base + (hits[t] & 0xffff);
+                const float held = kQ8Scale * e4m3_value((unsigned)hits[t] >> 16);
+                float part = 0.f;
+                for (int c = tid; c < a.k; c += blockDim.x) part += a.W32_old[i * a.kp + c] * a.H32[(int64_t)c * a.f_pad + j];
+                part = wave_sum(part);
+                if ((tid & 63) == 0) red[tid >> 6] = part;
+                __syncthreads();
+                if (tid == 0) {
+                    float d = 0.f;
+                    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) d += red[w];
+                    const int ii = (int)(i & 31), cc = (int)(j & 31);
+                    const int laneA = ii + 32 * ((cc >> 2) & 1), eA = 4 * (cc >> 3) + (cc & 3);
+                    const float x = (float)a.VtA[((i >> 5) * a.nct + (j >> 5)) * 1024 + (eA >> 3) * 512 + laneA * 8 + (eA & 7)];
+                    const float rinv = 1.f / (d + a.eps);
+                    q_s = fmaf(x, rinv, a.eps * rinv);
+                }
+                __syncthreads();
+                const float q_exact = q_s;
+                for (int c = tid; c < a.k; c += blockDim.x) {      // (several rows may share a column: atomic adds)
+                    const float wimg = (float)a.Wb_new[i * a.wld + wb_col((int)(i & 31), c)];
+                    const float wprod = used_w8 ? e4m3_value(a.W8[i * a.w8ld + c]) * a.w8s[c] : wimg;
+                    atomicAdd(&a.numer[(int64_t)c * a.f_pad + j], wimg * q_exact - wprod * held);
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        const float ex = excess_s;
-        for (int c = tid; c < a.kp; c += blockDim.x)       // (several listed rows may share a column: atomic adds)
-            atomicAdd(&a.numer[(int64_t)c * a.f_pad + j], (float)a.Wb_new[i * a.wld + wb_col((int)(i & 31), c)] * ex);
-        __syncthreads();
     }
     // the block that finishes last empties the list for the next iteration's column pass
     __syncthreads();
     if (tid == 0) {
         __threadfence();
         if (atomicAdd(&a.st->q8_fix_done, 1) == (int)gridDim.x - 1) {
+            if (n_all > kQ8ListCap) a.st->q8_unfixed += n_all - kQ8ListCap;
             a.st->q8_fix_done = 0;
             a.st->q8_list_n = 0;
         }
@@ -206,7 +251,9 @@ __global__ __launch_bounds__(512) void k_q8_fixup(Q8FixArgs a) {
 
 // KSPLIT = 2 (KT > 8, k <= 512): the 8 waves are 4 column tiles x 2 halves of the component range (the accumulators of a
 // half fit two waves per SIMD); the two waves of a column tile read the same two ratio tiles and copy one each.
-template <int KT, int NB, int KSPLIT = 1>
+// PROBE: the e4m3 W image carries the probe column (aa.probe, compile-time here: the byte test of the other case would
+// otherwise sit in every stage, 3 % of the kernel).
+template <int KT, int NB, int KSPLIT = 1, int PROBE = 1>
 __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     const ColPassQArgs &a = aa.q;
     typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -285,38 +332,31 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
         }
     };
     const int rcol_of_r = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);      // logical column of this lane's physical column
+    float probe_prev = 0.f, probe_max = 0.f;
+    unsigned q8_flag = 0u;
+
     auto compute = [&](unsigned base, int stage_row0) {
+        (void)stage_row0;
         i32x2 bq[4];
         static_for<0, 4>([&](auto U) {
             constexpr int u = decltype(U)::value;
             lds_read_tr8<u * 8 * 32>(bq[u], base + off_b);
         });
         i32x2 ring[2][4];
+        // accumulator blocks in DESCENDING order: the last block (it holds the probe component KP - 1) is multiplied first, so that
+        // its result is there, without a wait, when the stage's other products have been issued
         auto fetch = [&](auto M) {
             constexpr int m = decltype(M)::value;
             if constexpr (m < KTW) {
                 static_for<0, 4>([&](auto U) {
                     constexpr int u = decltype(U)::value;
-                    lds_read_tr8<u * 8 * LD8 + 32 * m>(ring[m & 1][u], base + off_a);
+                    lds_read_tr8<u * 8 * LD8 + 32 * (KTW - 1 - m)>(ring[m & 1][u], base + off_a);
                 });
             }
         };
         fetch(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
         const i32x8 bo = {bq[0][0], bq[0][1], bq[1][0], bq[1][1], bq[2][0], bq[2][1], bq[3][0], bq[3][1]};
-        if (a.q8_list != nullptr && kh == 0) {                // saturated ratio bytes of this lane's column (the two waves of a
-            unsigned any = 0u;                                  // column tile hold the same bytes: the first one reports)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) any |= q8_sat_mask((unsigned)bo[e]);
-            if (any != 0u && active) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned mk = q8_sat_mask((unsigned)bo[e]);
-                    // dword e = (u = e >> 1, w = e & 1): rows 32 h + 8 u + 4 w .. + 3 of the 64-row stage, physical column r
-                    if (mk) q8_list_append(a.st_rw, a.q8_list, mk, (unsigned)bo[e], stage_row0 + 32 * h + 8 * (e >> 1) + 4 * (e & 1), 32 * ct + rcol_of_r);
-                }
-            }
-        }
         static_for<0, KTW>([&](auto M) {
             constexpr int m = decltype(M)::value;
             fetch(std::integral_constant<int, m + 1>{});
@@ -324,8 +364,30 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
             const i32x8 ao = {ring[m & 1][0][0], ring[m & 1][0][1], ring[m & 1][1][0], ring[m & 1][1][1],
                               ring[m & 1][2][0], ring[m & 1][2][1], ring[m & 1][3][0], ring[m & 1][3][1]};
-            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[m], 0, 0, 0, 127, 0, 127);
+            acc[KTW - 1 - m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[KTW - 1 - m], 0, 0, 0, 127, 0, 127);
+            // the source order IS the schedule (read, counted wait, product, ...): without the fence hipcc moved the probe block's
+            // product behind the others as soon as its accumulator was read below, hoisted every read in front of the products
+            // (189 registers) and the read of the probe register then waited a whole product out -- 12 % of the kernel
+            __builtin_amdgcn_sched_barrier(0);
         });
+#ifndef KL_NO_Q8_DETECT
+        {
+            // The probe: component KP - 1 of the e4m3 W image is 1.0 in every row, so register 15 of the last accumulator block in
+            // the lanes h = 1 (component 32 (KT - 1) + 31, feature column r) grew by the sum of this stage's 64 ratio bytes of that
+            // column: a byte >= 32 (ratio >= 256) cannot hide in a growth below 32 (64 ordinary ratios summing to 256 trip it too:
+            // harmless, the fix-up looks at the bytes).  Branch-free and sticky: any control flow here splits the stage into
+            // blocks, and hipcc then sinks the products out of their place between the reads (12 % of the kernel).
+            if constexpr (PROBE != 0) {
+                const float now = acc[KTW - 1][15];
+                probe_max = fmaxf(probe_max, now - probe_prev);
+                probe_prev = now;
+            } else {
+                // without a spare component for the probe (k a multiple of 32; the image written by the W rule) the bytes themselves
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q8_flag |= q8_sat_mask((unsigned)bo[e]);
+            }
+        }
+#endif
     };
     auto fence = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -346,6 +408,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!active) return;
+    if (a.q8_list != nullptr && kh == KSPLIT - 1) {           // suspects of this (row chunk, column tile): one report per physical column
+        bool mine;
+        if (PROBE != 0) mine = h == 1 && probe_max >= 31.5f;
+        else mine = h == 0 && (q8_flag | (unsigned)__shfl_xor((int)q8_flag, 32, 64)) != 0u;
+        if (mine) q8_suspect_append(a.st_rw, a.q8_list, chunk, ct, r);
+    }
     // acc[m] reg (g,t): component 32m + 8g + 4h + t; lane's column: the LOGICAL column of physical column r (colq.hip.h);
     // the operands were W image / w8s[component] and ratio / 8
     const int rcol = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);

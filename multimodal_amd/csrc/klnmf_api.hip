@@ -486,6 +486,10 @@ void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
     HIPCHK(hipGetLastError());
 }
 
+// the probe column of the e4m3 W image (colq8x.hip.h): the last padded component, if neither a real component nor the eps
+// carrier lives there
+int w8_probe_col(const klnmf_ctx *c) { return (c->KP - 1 >= c->k && c->KP - 1 != c->kc) ? c->KP - 1 : -1; }
+
 void w8_make_scales(klnmf_ctx *c, int64_t entries) {
     const int per_block = entries > 4096 ? 64 : 8;      // (128 rows per block left 8 blocks walking 1024 rows one by one: 58 us)
     hipLaunchKernelGGL(k_w8_reduce, dim3((unsigned)((entries + per_block - 1) / per_block)), dim3(512), 0, c->stream,
@@ -630,13 +634,15 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     a.q8_list = c->q8() ? c->q8_list : nullptr;       // fp8 tiles: the column pass lists saturated ratio bytes for k_q8_fixup
     const int grid = c->ncb * c->nchunks;
     EventPair ev{};
+    bool col8_ran = false;             // this iteration's product was launched on the e4m3 W image
     auto q8_fixup = [&]() {            // behind the slab sum, before the H rule: the excess of ratios beyond the tiles' 3584
         if (!a.q8_list) return;
         const bool off = std::getenv("KLNMF_Q8_FIXUP") && std::atoi(std::getenv("KLNMF_Q8_FIXUP")) == 0;      // (tests: the control run)
         if (off) { HIPCHK(hipMemsetAsync(&c->st->q8_list_n, 0, sizeof(int), c->stream)); return; }
-        Q8FixArgs fa{c->st, c->q8_list, (const _Float16 *)c->VtA, (const float *)c->W32[c->cur], (const float *)c->H32,
-                     (const opnd_t *)c->Wb[c->cur ^ 1], c->numerF, c->nct, c->KP, (int)c->k, (int)w_ld(c->KP), c->f_pad,
-                     (float)(kEpsRatio * c->v_scale)};
+        Q8FixArgs fa{c->st, c->q8_list, c->Qt, (const _Float16 *)c->VtA, (const float *)c->W32[c->cur], (const float *)c->H32,
+                     (const opnd_t *)c->Wb[c->cur ^ 1], c->numerF, c->nrt, c->nct, c->KP, (int)c->k, (int)w_ld(c->KP),
+                     c->stages_per_chunk, c->f_pad, (float)(kEpsRatio * c->v_scale), col8_ran ? c->W8 : nullptr, c->w8s,
+                     (int)w8_ld(c->KP)};
         hipLaunchKernelGGL(k_q8_fixup, dim3(kQ8FixBlocks), dim3(512), 0, c->stream, fa);
         HIPCHK(hipGetLastError());
     };
@@ -665,7 +671,8 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
         c->w8_blocks = blocks;
         hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
-                           c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st, &c->st->w8_sat);
+                           c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st, &c->st->w8_sat,
+                           w8_probe_col(c));
         HIPCHK(hipGetLastError());
     };
     if (c->W8 && c->q8_loop && !c->w8_tail && c->iter_in_loop == 1 && !c->w8_meas) {
@@ -686,28 +693,24 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         if (!c->w8_tail) c->w8_meas = true;
         if (use8) {
         c->stat_col8 += 1;
+        col8_ran = true;
         if (c->profiling) ev = begin_event(c, c->ev_col);
         a.guard = c->w8_tail ? 0 : 1;      // (KLNMF_COL8=2: the W rule writes the image itself and does not count: no guard)
-        ColPass8Args a8{a, c->W8, c->w8s};
+        ColPass8Args a8{a, c->W8, c->w8s, (!c->w8_tail && w8_probe_col(c) >= 0) ? 1 : 0};
+#define KL_Q8X(KTV, NBV, KSV) case KTV:                                                                                              \
+            if (a8.probe) hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a8);        \
+            else hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a8);                 \
+            break;
+        if (c->KT == 8 && !c->big) fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: KT = 8 only on the component-split path");
         switch (c->KT) {
 #ifdef KL_DEV_BUILD
-            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 16: hipLaunchKernelGGL((k_colpass_q8x<16, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            KL_Q8X(7, KL_COL8_NB, 1) KL_Q8X(16, 3, 2)
 #else
-            case 1: hipLaunchKernelGGL((k_colpass_q8x<1, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 2: hipLaunchKernelGGL((k_colpass_q8x<2, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 3: hipLaunchKernelGGL((k_colpass_q8x<3, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 4: hipLaunchKernelGGL((k_colpass_q8x<4, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 5: hipLaunchKernelGGL((k_colpass_q8x<5, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 6: hipLaunchKernelGGL((k_colpass_q8x<6, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 7: hipLaunchKernelGGL((k_colpass_q8x<7, KL_COL8_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 8: if (c->big) { hipLaunchKernelGGL((k_colpass_q8x<8, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break; }
-                    fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: KT = 8 only on the component-split path");
-            case 10: hipLaunchKernelGGL((k_colpass_q8x<10, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 12: hipLaunchKernelGGL((k_colpass_q8x<12, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 14: hipLaunchKernelGGL((k_colpass_q8x<14, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
-            case 16: hipLaunchKernelGGL((k_colpass_q8x<16, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a8); break;
+            KL_Q8X(1, KL_COL8_NB, 1) KL_Q8X(2, KL_COL8_NB, 1) KL_Q8X(3, KL_COL8_NB, 1) KL_Q8X(4, KL_COL8_NB, 1)
+            KL_Q8X(5, KL_COL8_NB, 1) KL_Q8X(6, KL_COL8_NB, 1) KL_Q8X(7, KL_COL8_NB, 1)
+            KL_Q8X(8, 3, 2) KL_Q8X(10, 3, 2) KL_Q8X(12, 3, 2) KL_Q8X(14, 3, 2) KL_Q8X(16, 3, 2)
 #endif
+#undef KL_Q8X
             default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: k <= 224 or 256 < k <= 512");
         }
         HIPCHK(hipGetLastError());

@@ -619,23 +619,36 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #ifdef KL_STAMPS
         { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
 #endif
-#ifndef KL_QSTORE_EARLY   // the previous tile's ratios (still in b0 / b1) leave here, a whole tile interval before the next wait
-        if (tg > ct0) store_q(tg - 1);
+        // the segment's memory instructions: the previous tile's ratios (still in b0 / b1: a whole tile interval before the next
+        // wait), V of the next tile, this wave's slices of the dictionary copy
+        auto vmem_block = [&]() {
+#ifndef KL_QSTORE_EARLY
+            if (tg > ct0) store_q(tg - 1);
 #endif
-        if constexpr (VL) {
-            v_dma((ts + VP - 1) % VP, tg + VP - 1);           // into the slot E(tg - 1) consumed
-        } else {
+            if constexpr (VL) {
+                v_dma((ts + VP - 1) % VP, tg + VP - 1);           // into the slot E(tg - 1) consumed
+            } else {
 #ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
-        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)((tg + 1) & 3) * TB, vl32);
+            v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)((tg + 1) & 3) * TB, vl32);
 #else
-        // (these stay compiler loads: as asm statements with register outputs -- scalar base + lane offset, one VALU
-        // instruction less per tile -- they gave wrong results at 70 000 rows: nothing keeps the compiler from touching an
-        // asm output before the data lands; and a pointer passed through an asm statement comes back as a FLAT one)
-        v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)min(tg + 1, a.nct - 1) * TB, vl32);
+            // (these stay compiler loads: as asm statements with register outputs -- scalar base + lane offset, one VALU
+            // instruction less per tile -- they gave wrong results at 70 000 rows: nothing keeps the compiler from touching an
+            // asm output before the data lands; and a pointer passed through an asm statement comes back as a FLAT one)
+            v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)min(tg + 1, a.nct - 1) * TB, vl32);
 #endif
-        }
-        if (grpY) dma((ts + 3) % 4, tg + 3);
-        else dma((ts + 2) % 4, tg + 2);
+            }
+            if (grpY) dma((ts + 3) % 4, tg + 3);
+            else dma((ts + 2) % 4, tg + 2);
+        };
+        // KL_VMEM_STAGGER: the four waves of a group leave their barrier together and would all queue their five memory
+        // instructions at the CU's one address unit at once -- the last of them then runs its whole epilogue a queue's length
+        // behind, and the next barrier waits for it.  Wave w & 3 = q issues its block in front of element 4 q instead.
+#ifndef KL_VMEM_STAGGER
+#define KL_VMEM_STAGGER 0
+#endif
+        constexpr bool STG = KL_VMEM_STAGGER != 0 && NW == 8 && !VL;
+        const int wq = wave & 3;                                  // scalar
+        if constexpr (!STG) vmem_block();
         if constexpr (VL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb));      // the two slot reads (nothing else of this wave is in flight in LDS)
         float q[16];
 #ifdef KL_NO_NUM_EPS
@@ -644,6 +657,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #endif
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+            if constexpr (STG) {
+                if ((e & 3) == 0 && wq == (e >> 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    vmem_block();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             const float x = (float)(e < 8 ? va[e & 7] : vb[e & 7]);
 #ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
             if (true) {

@@ -942,14 +942,15 @@ def test_w_column_growing_fivefold_between_updates_falls_back_to_f16_operands():
     assert abs(orc.kl_error(X, W, H) - fo) <= 1e-4 * fo
 
 
-def test_ratios_beyond_the_fp8_tiles_range_are_corrected_exactly(monkeypatch):
+@pytest.mark.parametrize('k', [40, 200])          # k = 40: f16-operand column pass on the fp8 tiles (byte test); 200: fp8 x fp8 pass (probe)
+def test_ratios_beyond_the_fp8_tiles_range_are_corrected_exactly(monkeypatch, k):
     """fp8 ratio tiles hold ratio / 8 in e4m3: 3584 is their largest value, the conversion saturates.  A few entries of V
     the low-rank model cannot follow (spikes in columns where everything else is ~0: the ratio stays in the tens of
     thousands for the whole fit) would lose most of their weight in the H numerator.  The column pass lists the saturated
     bytes, k_q8_fixup recomputes those ratios from V and the masters and adds the excess: counted (klnmf_query), none
     left unfixed, and the run keeps the oracle's 1e-4 -- while the same run WITHOUT the correction (KLNMF_Q8_FIXUP=0)
     misses the spikes' dictionary columns by far more.  Reference behaviour: nmf.py:345-351."""
-    n, f, k, iters = 70000, 256, 40, 10
+    n, f, iters = 70000, 256, 10
     rs = np.random.RandomState(5)
     X = orc.synthetic_V(13, n, f, 12)
     X[:, f // 2:] = 1e-4 * rs.random_sample((n, f - f // 2))                         # columns the model learns to be ~0 at once
@@ -969,7 +970,7 @@ def test_ratios_beyond_the_fp8_tiles_range_are_corrected_exactly(monkeypatch):
         out[fix] = (m.last_fp8_report, np.asarray(e), W, m.components_.copy())
     assert out['16-bit tiles'][0]['tile_iterations'] == 0
     rep, e, W, H = out['1']
-    assert rep['tile_iterations'] == iters - 2, rep
+    assert rep['tile_iterations'] == iters - 2 and (rep['column_pass_iterations'] > 0) == (k == 200), rep
     assert rep['ratio_saturated'] >= len(spikes) and rep['ratio_unfixed'] == 0, rep
     assert len(e) == iters
     assert_allclose(e[3:], eo[3:], rtol=1e-4)
