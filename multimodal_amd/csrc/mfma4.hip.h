@@ -655,6 +655,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         float zero_f = 0.f;
         asm volatile("" : "+v"(zero_f));
 #endif
+#if defined(KL_E_PIPE)     // experiment: the epilogue as a hand-ordered 3-stage software pipeline (rcp two elements ahead, ratio one
+        // ahead, log of the current, loss term of the previous): every result is consumed at least four instructions after
+        // the one that produces it; order pinned with empty asm statements
+        if constexpr (MODE == ROW_UPDATE && !STG) {
+            float R[16], L[16];
+            auto xe = [&](int e) { return (float)(e < 8 ? va[e & 7] : vb[e & 7]); };
+#pragma unroll
+            for (int i = -2; i < 17; ++i) {
+                if (i + 2 < 16) { R[i + 2] = __builtin_amdgcn_rcpf(EP ? d[i + 2] : d[i + 2] + eps); asm volatile("" : "+v"(R[i + 2])); }
+                float m_ = 0.f;
+                if (i + 1 >= 0 && i + 1 < 16) { m_ = eps * R[i + 1]; asm volatile("" : "+v"(m_)); }
+                if (i >= 0 && i < 16) { L[i] = __builtin_amdgcn_logf(q[i]); asm volatile("" : "+v"(L[i])); }
+                if (i + 1 >= 0 && i + 1 < 16) { q[i + 1] = fmaf(xe(i + 1), R[i + 1], m_); asm volatile("" : "+v"(q[i + 1])); }
+                if (i - 1 >= 0 && i - 1 < 16) { s1 = fmaf(xe(i - 1), L[i - 1], s1); asm volatile("" : "+v"(s1)); }
+            }
+        } else
+#endif
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             if constexpr (STG) {
@@ -682,7 +699,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
                 q[e] = fmaf(x, rinv, eps * rinv);
 #endif
+#ifdef KL_ABL_LOGD        // timing-only experiment: the loss term from log2(W.H) (independent of the reciprocal) -- the loss VALUE is then another sum
+                s1 = fmaf(x, __builtin_amdgcn_logf(EP ? d[e] : d[e] + eps), s1);
+#else
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
+#endif
             }
         }
         b0 = pack8(q);

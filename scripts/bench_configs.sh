@@ -13,10 +13,10 @@ try:
     r, c = d['roofline'], [v for k, v in d['kernels'].items() if k.startswith('k_colpass')][0]
     sec = d['kernels'].get('row_pass_section', {})
     tail = (' + split tail %.3f ms' % sec['tail_avg_ms']) if sec.get('tail_avg_ms') else ''
-    print("  %.1f it/s  %.3f ms/iter  valid %s | row %.3f ms%s (%s roof: %.0f%% of peak, algorithmic; schedule %.0f GB/s) col %.3f ms (%.0f GB/s, %.0f TF) | iter %.0f TF = %.0f%% of peak" % (
+    print("  %.1f it/s  %.3f ms/iter  valid %s | row %.3f ms%s (%s roof: %.0f%% of peak, algorithmic; schedule %.0f GB/s) col %.3f ms (%.0f GB/s, %.0f TF) | iter %.0f TF = %.0f%% of its dtype-true t_min" % (
         d['value'], d['ms_per_step'], d['valid'], r['avg_launch_ms'], tail, r['bound'], 100 * r['frac'], r['schedule_hbm_gbs'],
         c['avg_launch_ms'], c['schedule_hbm_gbs'], c['algorithmic_tflops'], d['kernels']['iteration_algorithmic_tflops'],
-        100 * d['kernels']['iteration_frac_of_bf16_peak']))
+        100 * d['kernels']['iteration_frac']))
 except Exception as e:
     print("  (no result: %s)" % e)
 PY

@@ -8,7 +8,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 G = os.path.join(R, 'gpurun_out', tag)
 P = os.path.join(R, 'profiles')
@@ -45,7 +45,12 @@ if os.path.exists(os.path.join(G, 'pmc_c4', 'traffic.json')):
     if slabs:
         kern['k_wrule_slabs'] = t4[slabs[0]]
     n_row = 983040 if split in t4 else 1000000
+    sys.path.insert(0, R)
+    import bench
     out = {
+        # the state of multimodal_amd/csrc/ these figures were measured at: bench.py prints it beside `roofline.traffic` and says
+        # whether it is the state that ran (counters cannot be read in-process; the constants go stale when the kernels change)
+        'source_hash': bench.kernel_source_hash(),
         'correction': 'bytes = 1024*(2*FETCH_SIZE + WRITE_SIZE): gfx950 FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)',
         'command': 'bash scripts/final_run_b.sh %s  (scripts/pmc_profile.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE '
                    'TCC_HIT_sum TCC_MISS_sum ... -- python3 bench.py --steps 6 --warmup 2 --repeats 1 --data device --no-cpu-baseline; '
@@ -70,5 +75,5 @@ d = json.loads(open(os.path.join(G, 'bench_default.json')).read().strip().splitl
 r, k = d['roofline'], d['kernels']
 print('bench: %.1f it/s  %.3f ms  row launch %.3f ms frac %.3f (%.0f TF)  section %.3f ms  col %.3f ms  iteration frac %.3f  cpu %.4f / %.4f' % (
     d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], r['achieved'], k['row_pass_section']['avg_ms'],
-    [v for kk, v in k.items() if kk.startswith('k_colpass')][0]['avg_launch_ms'], k['iteration_frac_of_bf16_peak'],
+    [v for kk, v in k.items() if kk.startswith('k_colpass')][0]['avg_launch_ms'], k['iteration_frac'],
     d['cpu_baseline']['value'], d['cpu_baseline']['optimised_cpu']['value']))

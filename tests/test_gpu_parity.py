@@ -331,10 +331,11 @@ def test_bf16_fit_matches_oracle(n, f, k, iters, prec):
     assert_allclose(errors, eo, rtol=1e-3)
     final_o = orc.kl_error(X, Wo, Ho)
     final_g = m.error(X, W)                                # as the bf16 mode reports it
-    # 1e-4 (the north star's tolerance): measured <= 3e-5 on every case but 500 x 1000, k = 10 after 50 iterations, where
-    # the trajectory has drifted by 7e-5 ('f16') / 1.05e-4 ('f16_v32', generation-1 kernels) -- 2e-4 there
-    # (scripts/tolerance_survey.py; bf16 operands needed 5e-4 on the two smallest cases)
-    tol_final = 2e-4 if (n, f, k) == (500, 1000, 10) else 1e-4
+    # 1e-4 (the north star's tolerance): measured <= 3e-5 on every case but 500 x 1000, k = 10 (BASELINE config 1's shape)
+    # after 50 iterations, where the trajectory has drifted by 7e-5 in 'f16' -- inside 1e-4 -- and by 1.05e-4 in 'f16_v32'
+    # (the generation-1 kernels): 2e-4 for THAT mode there only (scripts/tolerance_survey.py; bf16 operands needed 5e-4 on
+    # the two smallest cases)
+    tol_final = 2e-4 if ((n, f, k) == (500, 1000, 10) and prec == 'bf16_v32') else 1e-4
     assert abs(final_g - final_o) <= tol_final * abs(final_o), (final_g, final_o)
     # quality of the trained model itself: exact fp64 loss on the exact data
     m64 = nmf.KLdivNMF(n_components=k, precision='f64')
