@@ -1277,6 +1277,12 @@ int klnmf_destroy(klnmf_ctx *c) {
                 std::fprintf(stderr, "[stamps4] epilogue: loss sums %.0f | old W loads landed %.0f | W rule, stores, drain %.0f\n",
                              sum[2] / c->nrt, sum[5] / c->nrt, epi / c->nrt - sum[2] / c->nrt - sum[5] / c->nrt);
 #endif
+                for (int w = 0; w < 8; ++w) {          // per wave of the workgroup (waves 0-3 = X, 4-7 = Y): who waits for whom
+                    double sw[8] = {0}; int cnt = 0;
+                    for (int i = w; i < c->nrt; i += 8) { for (int j = 0; j < 8; ++j) sw[j] += (double)hs[(size_t)i * 8 + j]; ++cnt; }
+                    if (cnt) std::fprintf(stderr, "[stamps4] wave %d: M %.0f | E %.0f | V wait %.0f | barrier after M %.0f | after E %.0f | kernel %.0f\n", w,
+                                          sw[0] / cnt / tiles, sw[1] / cnt / tiles, sw[2] / cnt / tiles, sw[3] / cnt / tiles, sw[4] / cnt / tiles, sw[6] / cnt);
+                }
                 std::fprintf(stderr, "[stamps4] per tile per wave (cycles): M segment %.0f | E segment %.0f | V wait %.0f | copy wait %.0f | barrier after M %.0f | barrier after E %.0f || kernel %.0f cycles, %d tiles\n",
                              sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[5] / c->nrt / tiles,
                              sum[3] / c->nrt / tiles, sum[4] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
