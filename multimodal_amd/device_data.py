@@ -41,8 +41,8 @@ class DeviceDataset(object):
         """(device matrix, is_float64) the fits and transforms read modality `which` from: the float64 copy when the NMF runs
         in the reference's own arithmetic (KLNMF_PRECISION=f64: results then agree with the reference to summation order),
         the float32 one otherwise (the 16-bit modes store V in 16 bits anyway)."""
-        if _native.PRECISIONS[_default_precision()] == _native.PREC_F64:
-            return self.block64(which), True
+        if _default_precision() == 'auto' or _native.PRECISIONS[_default_precision()] == _native.PREC_F64:
+            return self.block64(which), True           # ('auto' decides per fit: the float64 copy serves either outcome)
         return self.blocks[which], False
 
     def block64(self, which):

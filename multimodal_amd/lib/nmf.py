@@ -41,6 +41,19 @@ def _default_precision():
     return os.environ.get('KLNMF_PRECISION', 'f64')
 
 
+# precision='auto' (KLNMF_PRECISION=auto): the reference's own arithmetic (f64: results equal to the reference's) where a
+# fit is cheap anyway, the fp16-operand MFMA path (final KL within 1e-4) from this many multiply-adds per W.H on -- 2e9 is
+# 10 000 x 4096 at k = 50: below it an f64 iteration is well under a millisecond.  The default stays 'f64' (SURVEY section 5:
+# defaults must reproduce the reference's results).
+AUTO_F16_WORK = 2e9
+
+
+def resolve_precision(precision, n, f, k):
+    if precision != 'auto':
+        return precision
+    return 'f16' if float(n) * float(f) * float(k) >= AUTO_F16_WORK else 'f64'
+
+
 def _default_device():
     return int(os.environ.get('KLNMF_DEVICE', '0'))
 
@@ -128,11 +141,14 @@ class KLdivNMF(object):
     def _sparse_route(self, *blocks):
         """CSR input runs the reference's sparse branch (ratio on the stored entries only, nmf.py:52-70,
         301-308, 331-334) in the exact modes; the bf16 modes densify (Q off the non-zeros ~1e-8/WH)."""
+        # ('auto': sparse input takes the reference's sparse branch, i.e. the exact mode)
         return (any(sp.issparse(b) for b in blocks) and
-                _native.PRECISIONS[self.precision] in (_native.PREC_F64, _native.PREC_F32))
+                (self.precision == 'auto' or _native.PRECISIONS[self.precision] in (_native.PREC_F64, _native.PREC_F32)))
 
-    def _context(self, exact=False):
+    def _context(self, exact=False, shape=None):
         prec = self.precision
+        if prec == 'auto':             # decided per problem (shape = (n, f, k)); single steps and loss evaluations: exact
+            prec = resolve_precision(prec, *shape) if shape is not None else 'f64'
         if exact and _native.PRECISIONS[prec] not in (_native.PREC_F64, _native.PREC_F32):
             prec = 'f64'
         return _native.Context(precision=prec, device=self.device, pooled=True)
@@ -188,7 +204,7 @@ class KLdivNMF(object):
         max_iter = int(self.max_iter)
         out_dtype = out_dtype_of(H_init)
 
-        with self._context() as ctx:
+        with self._context(shape=None if sparse_X is not None else (n_samples, n_features, k)) as ctx:
             if sparse_X is not None:
                 ctx.set_problem_sparse(sparse_X, k, max_iter)
             else:
@@ -239,7 +255,7 @@ class KLdivNMF(object):
         if scale_W:
             # dead from every caller in the reference (nmf.py:246-250), kept
             W = _scale(normalize_sum(W, axis=1), np.asarray(X.sum(axis=1)).ravel(), axis=1)
-        if eps != 1.e-8 and _native.PRECISIONS[self.precision] >= _native.PREC_BF16:
+        if eps != 1.e-8 and self.precision != 'auto' and _native.PRECISIONS[self.precision] >= _native.PREC_BF16:
             raise ValueError("the bf16 kernels use the reference's fixed eps = 1e-8")
         H = self.components_
         with self._context() as ctx:

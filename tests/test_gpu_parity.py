@@ -983,3 +983,23 @@ def test_ratios_beyond_the_fp8_tiles_range_are_corrected_exactly(monkeypatch, k)
     # these columns are ~1e-6 of the others except for what the spikes put there: the 16-bit-tile run shows what the
     # mode's own operand rounding does to them; the corrected fp8 run must be as good, the uncorrected one is far off
     assert dev_on <= 1.5 * dev_16 + 2e-3 and dev_off > 10 * dev_on, (dev_on, dev_off, dev_16)
+
+
+def test_auto_precision_runs_f64_when_small_and_the_mfma_path_when_large():
+    """precision='auto': the reference's own arithmetic below 2e9 multiply-adds per W.H (bit-equal to precision='f64'), the
+    fp16-operand MFMA path above (within the north star's 1e-4 of the oracle)."""
+    X = orc.synthetic_V(3, 300, 200, 12)
+    H0 = orc.synthetic_H0(3, 200, 12)
+    ma, Wa, ea, _ = fit_gpu(X, H0, 12, 8, 0, precision='auto')
+    m6, W6, e6, _ = fit_gpu(X, H0, 12, 8, 0, precision='f64')
+    np.testing.assert_array_equal(Wa, W6)
+    np.testing.assert_array_equal(ea, e6)
+    n, f, k, iters = 12000, 4096, 50, 5                       # 2.46e9
+    X = orc.synthetic_V(4, n, f, 16)
+    H0 = orc.synthetic_H0(4, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    ma, Wa, ea, _ = fit_gpu(X, H0, k, iters, 0, precision='auto')
+    assert np.abs(ea - eo).max() > 0                          # not the exact mode ...
+    assert_allclose(ea, eo, rtol=1e-3)
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(orc.kl_error(X, Wa.astype(np.float64), ma.components_.astype(np.float64)) - fo) <= 1e-4 * fo      # ... and inside the budget

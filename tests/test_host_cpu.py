@@ -266,3 +266,16 @@ def test_bench_watchdog_exits_nonzero_with_a_diagnostic():
     ok = subprocess.run([sys.executable, '-c', "import sys; sys.path.insert(0, %r); import bench\nwith bench.Watchdog(30, 'x', 0):\n    pass\n" % root],
                         capture_output=True, text=True, timeout=60)
     assert ok.returncode == 0
+
+
+def test_auto_precision_picks_the_exact_mode_for_small_problems_and_f16_for_large_ones():
+    """precision='auto' (KLNMF_PRECISION=auto): f64 = the reference's results where a fit is cheap, the MFMA path from 2e9
+    multiply-adds per W.H on; the default stays 'f64' (defaults must reproduce the reference's results)."""
+    assert nmf.resolve_precision('auto', 500, 1000, 10) == 'f64'            # BASELINE config 1
+    assert nmf.resolve_precision('auto', 1000, 2450, 50) == 'f64'           # the reference's own experiment scale
+    assert nmf.resolve_precision('auto', 50000, 4096, 50) == 'f16'          # config 2
+    assert nmf.resolve_precision('auto', 1000000, 4096, 200) == 'f16'       # config 4
+    assert nmf.resolve_precision('f32', 1000000, 4096, 200) == 'f32'
+    assert nmf._default_precision() in ('f64', os.environ.get('KLNMF_PRECISION'))
+    m = nmf.KLdivNMF(n_components=3, precision='auto')
+    assert m._sparse_route(sp.csr_matrix(np.eye(3)))                        # sparse input: the exact sparse branch
