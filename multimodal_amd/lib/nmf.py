@@ -48,10 +48,18 @@ def _default_precision():
 AUTO_F16_WORK = 2e9
 
 
+MAX_K_MFMA = 512          # the 16-bit MFMA kernels hold a wave's accumulators of all components in registers: k <= 512
+
+
 def resolve_precision(precision, n, f, k):
-    if precision != 'auto':
-        return precision
-    return 'f16' if float(n) * float(f) * float(k) >= AUTO_F16_WORK else 'f64'
+    """The arithmetic one problem runs in.  'auto' by size (above); the 16-bit modes hand k > 512 to the fp32 kernels of the
+    same library (LDS-tiled VALU GEMMs: any k, at least the 16-bit mode's accuracy) instead of refusing the problem."""
+    if precision == 'auto':
+        precision = 'f16' if float(n) * float(f) * float(k) >= AUTO_F16_WORK else 'f64'
+    code = _native.PRECISIONS[precision]
+    if (code == _native.PREC_BF16 and k > MAX_K_MFMA) or (code == _native.PREC_BF16_V32 and k > 256):      # (fp32-stored V: generation-1 kernels)
+        return 'f32'
+    return precision
 
 
 def _default_device():
@@ -147,8 +155,10 @@ class KLdivNMF(object):
 
     def _context(self, exact=False, shape=None):
         prec = self.precision
-        if prec == 'auto':             # decided per problem (shape = (n, f, k)); single steps and loss evaluations: exact
-            prec = resolve_precision(prec, *shape) if shape is not None else 'f64'
+        if prec == 'auto' and shape is None:      # single steps and loss evaluations: exact
+            prec = 'f64'
+        elif shape is not None:                   # decided per problem (shape = (n, f, k)): 'auto' by size, k > 512 -> fp32 kernels
+            prec = resolve_precision(prec, *shape)
         if exact and _native.PRECISIONS[prec] not in (_native.PREC_F64, _native.PREC_F32):
             prec = 'f64'
         return _native.Context(precision=prec, device=self.device, pooled=True)
