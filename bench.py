@@ -373,13 +373,11 @@ def main():
                     n_done, stopped = n_done + wd, stopped or wstop
                 else:
                     model.begin()
-                    for _ in range(args.warmup):
-                        model.iterate(fit=True, tol=args.tol)
+                    model.iterate_many(args.warmup, fit=True, tol=args.tol)
                     model.ctx.profile_enable(True)
                     fence()
                     t0 = time.perf_counter()
-                    for _ in range(args.steps):
-                        model.iterate(fit=True, tol=args.tol)
+                    model.iterate_many(args.steps, fit=True, tol=args.tol)      # (one process: klnmf_run_more, the loop klnmf_run runs)
                     fence()
                     elapsed = time.perf_counter() - t0
                     prof = model.ctx.profile_read(reset=True)

@@ -147,6 +147,9 @@ int klnmf_loop_begin(klnmf_ctx *ctx);
  * ALL shards -- sum of V (klnmf_query_f64 KLNMF_QF_SUM_V, all-reduced) and its element count -- so that every rank runs
  * the same kernels and the result does not depend on the partition beyond summation order. */
 int klnmf_loop_begin_sharded(klnmf_ctx *ctx, double sum_v_all, double cells_all);
+/* `iters` whole iterations of the open loop at once, enqueued exactly as klnmf_run enqueues them (callers that fence between
+ * two parts of one loop: warm-up | timed iterations of bench.py) */
+int klnmf_run_more(klnmf_ctx *ctx, int64_t iters, int fit, double tol_abs);
 int klnmf_iter_rowpass(klnmf_ctx *ctx, int fit);
 int klnmf_iter_decide(klnmf_ctx *ctx, double tol_abs);
 int klnmf_iter_colpass(klnmf_ctx *ctx);

@@ -56,6 +56,7 @@ SIGNATURES = {
                              _c.POINTER(_c.c_int)]),
     'klnmf_loop_begin': (_c.c_int, [_ctx_p]),
     'klnmf_loop_begin_sharded': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double]),
+    'klnmf_run_more': (_c.c_int, [_ctx_p, _i64, _c.c_int, _c.c_double]),
     'klnmf_iter_rowpass': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_iter_decide': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_iter_colpass': (_c.c_int, [_ctx_p]),
@@ -476,6 +477,10 @@ class Context(object):
         v = _c.c_double(0.0)
         _check(self._lib.klnmf_query_f64(self._h, 0, ctypes.byref(v)))
         return float(v.value)
+
+    def run_more(self, iters, fit=True, tol_abs=0.0):
+        """`iters` whole iterations of the open loop, enqueued as klnmf_run does (klnmf_run_more)."""
+        _check(self._lib.klnmf_run_more(self._h, int(iters), 1 if fit else 0, float(tol_abs)))
 
     def iter_rowpass(self, fit=True):
         _check(self._lib.klnmf_iter_rowpass(self._h, 1 if fit else 0))

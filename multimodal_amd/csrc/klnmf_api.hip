@@ -1887,6 +1887,33 @@ int klnmf_loop_begin_sharded(klnmf_ctx *c, double sum_x_all, double cells_all) {
     });
 }
 
+/* `iters` more iterations of the loop klnmf_loop_begin opened, enqueued as klnmf_run enqueues them (the loss reduction and
+ * the stop rule riding in the slab-sum launch of a fit): the loop in bulk, for callers that want to fence between two parts
+ * of ONE loop (bench.py: warm-up iterations | timed iterations).  Results by klnmf_loop_end. */
+int klnmf_run_more(klnmf_ctx *c, int64_t iters, int fit, double tol_abs) {
+    return guarded([&] {
+        need_problem(c);
+        if (iters < 0) fail(KLNMF_ERR_ARG, "iters < 0");
+        const bool fused = !c->is_exact();
+        for (int64_t it = 0; it < iters; ++it) {
+            if (fused) {
+                piece_rowpass(c, fit, &tol_abs);
+            } else {
+                piece_rowpass(c, fit);
+                piece_decide(c, tol_abs);
+            }
+            if (fit) {
+                piece_colpass(c);
+                piece_update_H(c);
+            }
+            c->cur ^= 1;
+            c->loop_iters += 1;
+            c->iter_in_loop += 1;
+            if (fit) poll_fp8_overflow(c);
+        }
+    });
+}
+
 int klnmf_iter_rowpass(klnmf_ctx *c, int fit) {
     return guarded([&] {
         need_problem(c);

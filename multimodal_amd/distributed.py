@@ -183,6 +183,16 @@ class ShardedKLNMF(object):
         self.ctx.iter_advance()
         self.iterations_enqueued += 1
 
+    def iterate_many(self, count, fit=True, tol=0.0):
+        """`count` iterations of the open loop.  One process: the library enqueues them itself (klnmf_run_more -- the loss
+        reduction and the stop rule then ride in the column pass's slab-sum launch, as in klnmf_run); several: `iterate`."""
+        if (self.dist is None or self.world_size == 1) and hasattr(self.ctx, 'run_more'):
+            self.ctx.run_more(count, fit, tol * self.n_total * self.f)
+            self.iterations_enqueued += int(count)
+            return
+        for _ in range(int(count)):
+            self.iterate(fit=fit, tol=tol)
+
     def end(self):
         """Synchronise; returns (errors, n_done, stopped) -- identical on every rank."""
         return self.ctx.loop_end(max(1, self.iterations_enqueued))

@@ -1012,3 +1012,36 @@ def test_auto_precision_runs_f64_when_small_and_the_mfma_path_when_large():
     assert_allclose(ea, eo, rtol=1e-3)
     fo = orc.kl_error(X, Wo, Ho)
     assert abs(orc.kl_error(X, Wa.astype(np.float64), ma.components_.astype(np.float64)) - fo) <= 1e-4 * fo      # ... and inside the budget
+
+
+@pytest.mark.parametrize('precision,n,f,k', [('f64', 300, 200, 12), ('f16', 3000, 512, 40), ('f16', 70000, 256, 200)])
+def test_run_more_is_the_loop_of_klnmf_run(precision, n, f, k):
+    """klnmf_run_more (bench.py's single-process loop: warm-up | timed iterations of ONE loop, fenced in between) enqueues
+    the iterations exactly as klnmf_run does -- loss reduction and stop rule in the slab-sum launch of a fit, fp8 from the
+    loop's third iteration: same losses, same factors, bit for bit, however the loop is cut."""
+    iters = 7
+    X = orc.synthetic_V(9, n, f, 12)
+    H0 = orc.synthetic_H0(9, f, k)
+    out = []
+    for cut in (None, (3, 4), (1, 6)):
+        with _native.Context(precision, device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            if cut is None:
+                e, nd, st = ctx.run(iters, True, 0.0)
+            else:
+                ctx.loop_begin()
+                for part in cut:
+                    ctx.run_more(part, True, 0.0)
+                    ctx.synchronize()
+                e, nd, st = ctx.loop_end(iters)
+            out.append((np.asarray(e), nd, st, ctx.get_W(), ctx.get_H(), ctx.fp8_report()['tile_iterations']))
+    for o in out[1:]:
+        assert o[1] == out[0][1] == iters and not o[2]
+        np.testing.assert_array_equal(o[0], out[0][0])
+        np.testing.assert_array_equal(o[3], out[0][3])
+        np.testing.assert_array_equal(o[4], out[0][4])
+        assert o[5] == out[0][5]
+    assert out[0][5] == (iters - 2 if n > 32768 else 0)

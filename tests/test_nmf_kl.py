@@ -130,13 +130,17 @@ def test_config4_k500_three_modalities():
     blocks = [orc.synthetic_V(41 + i, n, d, 16) for i, d in enumerate(dims)]
     V = orc.stack_modalities(blocks, [1.0, 1.0, 1.0])
     H0 = orc.synthetic_H0(41, sum(dims), k)
-    with pytest.raises(_native.NativeError) as ei:
-        _fit(V, H0, k, iters, 'bf16_v32')
-    assert 'k > 256' in str(ei.value)
-    with pytest.raises(_native.NativeError):
-        _fit(V, orc.synthetic_H0(41, sum(dims), 513), 513, iters, 'bf16')
+    # the C-ABI refuses what its 16-bit kernels cannot hold (fp32-stored V: k > 256; fp16-stored: k > 512) ...
+    for prec, kk in (('bf16_v32', k), ('bf16', 513)):
+        with _native.Context(prec, device=0) as ctx:
+            with pytest.raises(_native.NativeError) as ei:
+                ctx.set_problem(n, sum(dims), kk, iters)
+            assert 'k > 256' in str(ei.value)
     Wo, Ho, eo = orc.fit_transform(V, k=k, H0=H0, max_iter=iters, tol=0)
     fo = orc.kl_error(V, Wo, Ho)
+    # ... and KLdivNMF then runs such a problem on the fp32 kernels of the library (round 3: resolve_precision) instead of raising
+    m, W, e = _fit(V, H0, k, iters, 'bf16_v32')
+    assert_allclose(e, eo, rtol=2e-5)
     m, W, e = _fit(V.astype(np.float32), H0, k, iters, 'f32')
     assert_allclose(e, eo, rtol=2e-4)
     assert abs(m.error(V, W) - fo) <= KL_TOL * fo
