@@ -141,15 +141,31 @@ class ShardedKLNMF(object):
         return None
 
     def begin(self):
-        # every rank must take the same fp8 decision (16-bit modes): it is made from the sums over ALL shards, as
-        # klnmf_run_sharded does on the native path
-        if self.dist is not None and self.world_size > 1 and hasattr(self.ctx, 'sum_V'):
-            t = self.torch.tensor([self.ctx.sum_V(), float(self.n_local) * float(self.f)], dtype=self.torch.float64,
-                                  device=self.tensor_device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.ctx.loop_begin(float(t[0].item()), float(t[1].item()))
-        else:
-            self.ctx.loop_begin()
+        """Open the loop on every rank -- or on none: a rank whose own shard is refused at the loop's entry (V beyond the
+        announced maximum, factors beyond the fp16 operand range) must not leave the others waiting in their first
+        all-reduce, so the outcome of the local entry is agreed (max) before anybody enqueues a collective."""
+        multi = self.dist is not None and self.world_size > 1
+        err = None
+        try:
+            # every rank must take the same fp8 decision (16-bit modes): it is made from the sums over ALL shards, as
+            # klnmf_run_sharded does on the native path
+            if multi and hasattr(self.ctx, 'sum_V'):
+                t = self.torch.tensor([self.ctx.sum_V(), float(self.n_local) * float(self.f)], dtype=self.torch.float64,
+                                      device=self.tensor_device)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.ctx.loop_begin(float(t[0].item()), float(t[1].item()))
+            else:
+                self.ctx.loop_begin()
+        except Exception as e:             # (reported below, on every rank)
+            err = e
+        if multi:
+            flag = self.torch.tensor([1.0 if err is not None else 0.0], dtype=self.torch.float64, device=self.tensor_device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
+            if float(flag.item()) != 0.0:
+                raise err if err is not None else RuntimeError(
+                    "another rank's shard was refused at the loop's entry: the sharded loop is not started on any rank")
+        elif err is not None:
+            raise err
         self.iterations_enqueued = 0
 
     def rccl_ranks(self):

@@ -192,3 +192,43 @@ def test_fewer_row_tiles_than_ranks_is_refused_on_every_rank(tmp_path):
     mp.spawn(_tiny_worker, args=(2, port, 20, str(tmp_path)), nprocs=2, join=True)
     msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
     assert msgs[0] == msgs[1] and 'cannot shard 20 rows' in msgs[0]
+
+
+class RefusingContext(OracleContext):
+    """A shard whose loop entry fails (as klnmf_loop_begin does for a V beyond the announced maximum)."""
+
+    def loop_begin(self):
+        raise RuntimeError("klnmf error -1: uploaded V exceeds the maximum given to klnmf_set_v_max")
+
+
+def _refusal_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n, f, k = 75, 40, 6
+        X = orc.synthetic_V(77, n, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=3, backend=RefusingContext() if rank == 1 else OracleContext())
+        m.set_v_max(X[r0:r1].max()); m.upload_V(X[r0:r1]); m.set_H(orc.synthetic_H0(77, f, k)); m.init_W()
+        try:
+            m.run(3, fit=True, tol=0.0)
+            msg = 'no error'
+        except RuntimeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, 'r%d.txt' % rank), 'w') as fh:
+            fh.write(msg)
+        dist.barrier()                       # nobody is left waiting in a collective
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_refusal_on_one_rank_stops_every_rank(tmp_path):
+    """a rank-local refusal at the loop's entry (here rank 1) must fail the loop on EVERY rank instead of
+    leaving the others in their first all-reduce for ever (torch-sequenced path; klnmf_run_sharded does the same natively)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_refusal_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
+    assert 'exceeds the maximum' in msgs[1]                  # the rank that was refused says why
+    assert "another rank's shard was refused" in msgs[0]     # the other one stops too, and says so
