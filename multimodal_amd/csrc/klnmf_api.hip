@@ -2080,11 +2080,19 @@ int klnmf_comm_destroy(klnmf_ctx *c) {
     });
 }
 
+// KLNMF_COMM_SINGLE=1 (tests): a ONE-rank communicator takes the collective path too -- the same agreement block, grouped
+// all-reduces (in place, on the loop's own buffers, counts and types) and decision kernel that N ranks execute; RCCL refuses
+// two ranks on one device, so this is the only way a one-GPU box ever runs these lines.
+static bool comm_single_collectives() {
+    const char *g = std::getenv("KLNMF_COMM_SINGLE");
+    return g && std::atoi(g) != 0;
+}
+
 int klnmf_comm_max(klnmf_ctx *c, double *value) {
     return guarded([&] {
         use(c);
         if (!value) fail(KLNMF_ERR_ARG, "null value");
-        if (!c->comm || c->comm_size == 1) return;
+        if (!c->comm || (c->comm_size == 1 && !comm_single_collectives())) return;
         HIPCHK(hipMemcpyAsync(c->comm_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
         RCCLCHK(rccl().AllReduce(c->comm_scratch, c->comm_scratch, 1, ncclDouble, ncclMax, c->comm, c->stream));
         HIPCHK(hipMemcpyAsync(value, c->comm_scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2099,7 +2107,7 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         if (max_iter < 0 || max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter out of range");
         if (n_total < c->n) fail(KLNMF_ERR_ARG, "n_total smaller than this rank's rows");
         if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_run_sharded: dense problems only");
-        const bool multi = c->comm != nullptr && c->comm_size > 1;
+        const bool multi = c->comm != nullptr && (c->comm_size > 1 || comm_single_collectives());
         // Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
         // (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8
         // decision is taken from the all-reduced sums, so that all ranks run the same kernels and N = 1 / N = 8 differ by

@@ -100,6 +100,68 @@ def test_native_collective_path_single_rank_communicator(precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('precision,n,f,k,iters', [('f16', 700, 384, 24, 5), ('f64', 700, 384, 24, 5), ('f32', 900, 200, 10, 4),
+                                                   ('f16', 66048, 256, 128, 6)])
+def test_collective_branch_of_run_sharded_on_a_one_rank_communicator(monkeypatch, precision, n, f, k, iters):
+    """The lines of klnmf_run_sharded that only N > 1 ranks execute -- the agreement block (refusal flags max, sums of V and
+    cells sum), ONE grouped RCCL launch per iteration on the loop's own buffers (numerator: k x f_pad floats or k x f doubles,
+    loss: 2 doubles), the separate decision kernel -- forced onto a one-rank communicator by KLNMF_COMM_SINGLE=1 (RCCL refuses
+    two ranks on one device).  A one-rank all-reduce is the identity, so W and H must equal klnmf_run's bit for bit (the losses to fp64 summation order);
+    the last case runs them with fp8 ratio tiles and the fp8 x fp8 column pass (the decision taken from the all-reduced sums)."""
+    from multimodal_amd import _native
+    X = orc.synthetic_V(5, n, f, k)
+    H0 = orc.synthetic_H0(5, f, k)
+    out = []
+    for native in (False, True):
+        if native:
+            monkeypatch.setenv('KLNMF_COMM_SINGLE', '1')
+        with _native.Context(precision, device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            if native:
+                ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
+                assert ctx.comm_max(3.25) == 3.25                    # a real ncclAllReduce(max) this time
+            if precision == 'f16':
+                ctx.set_v_max(float(X.max()))
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            errs, n_done, stopped = (ctx.run_sharded(n, iters, True, 0.0) if native else ctx.run(iters, True, 0.0))
+            rep = ctx.fp8_report() if precision == 'f16' else None
+            out.append((np.array(errs), n_done, stopped, ctx.get_W(), ctx.get_H(), rep))
+            if native:
+                ctx.comm_destroy()
+    assert out[0][1] == out[1][1] == iters and not out[1][2]
+    # the loss: the same partial sums, added in fp64 by the slab-sum kernel's last block (klnmf_run defers it there) or by the
+    # loss kernel in front of the exchange -- another order of a few hundred fp64 additions (6e-14 measured at 66 048 rows)
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(out[0][3], out[1][3])
+    np.testing.assert_array_equal(out[0][4], out[1][4])
+    if n > 65536:
+        assert out[1][5]['allowed'] and out[1][5]['column_pass_iterations'] == iters - 2 == out[0][5]['column_pass_iterations']
+
+
+@pytest.mark.gpu
+def test_collective_branch_refuses_together(monkeypatch):
+    """The agreement block's refusal: a shard whose V exceeds the announced maximum fails klnmf_run_sharded with the rank's
+    own message after the flags went through the all-reduce (KLNMF_COMM_SINGLE: the collective branch on one rank)."""
+    from multimodal_amd import _native
+    monkeypatch.setenv('KLNMF_COMM_SINGLE', '1')
+    n, f, k = 512, 256, 16
+    X = orc.synthetic_V(9, n, f, k)
+    with _native.Context('f16', device=0) as ctx:
+        ctx.set_problem(n, f, k, 3)
+        ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
+        ctx.set_v_max(float(X.max()) / 64.0)                         # the announced maximum is too small: storage factor too large
+        Xb = X.copy(); Xb[3, 5] = X.max() * 4000.0
+        ctx.upload_V(Xb)
+        ctx.set_H(orc.synthetic_H0(9, f, k))
+        ctx.init_W()
+        with pytest.raises(_native.NativeError, match='exceeds the maximum given to klnmf_set_v_max'):
+            ctx.run_sharded(n, 3, True, 0.0)
+        ctx.comm_destroy()
+
+
+@pytest.mark.gpu
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 code path end to end on one GPU (KLNMF_BENCH_REHEARSAL: both ranks on device 0, gloo): shard
     generation from the seeded blocks, the common storage factor, the sharded loop, max-over-ranks timing, one JSON line."""
