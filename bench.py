@@ -310,7 +310,10 @@ def main():
     n_local = r1 - r0
     iters_per_fit = args.warmup + args.steps
     t_setup = time.perf_counter()
-    collective = args.collective if (world > 1 and not rehearsal) else 'torch'
+    # (KLNMF_COMM_SINGLE=1: one process rehearses the native path on a one-rank communicator -- the library then runs the
+    # collective branch, all-reduces included: tests/test_distributed_gpu.py)
+    comm_single = world == 1 and os.environ.get('KLNMF_COMM_SINGLE') == '1'
+    collective = args.collective if ((world > 1 and not rehearsal) or comm_single) else 'torch'
     native_error = None
     model = None
     with Watchdog(args.segment_timeout, 'set-up of the model and its communicator', rank):
@@ -360,29 +363,20 @@ def main():
                           % (rep, args.warmup, args.steps, collective), rank):
                 model.set_H(H0)
                 model.init_W()
-                if collective == 'native':       # each call runs its iterations, collectives included, inside the C-ABI
-                    _, wd, wstop = model.run(args.warmup, fit=True, tol=args.tol) if args.warmup else ([], 0, False)
-                    model.ctx.profile_enable(True)
-                    fence()
-                    t0 = time.perf_counter()
-                    errors, n_done, stopped = model.run(args.steps, fit=True, tol=args.tol)
-                    fence()
-                    elapsed = time.perf_counter() - t0
-                    prof = model.ctx.profile_read(reset=True)
-                    model.ctx.profile_enable(False)
-                    n_done, stopped = n_done + wd, stopped or wstop
-                else:
-                    model.begin()
-                    model.iterate_many(args.warmup, fit=True, tol=args.tol)
-                    model.ctx.profile_enable(True)
-                    fence()
-                    t0 = time.perf_counter()
-                    model.iterate_many(args.steps, fit=True, tol=args.tol)      # (one process: klnmf_run_more, the loop klnmf_run runs)
-                    fence()
-                    elapsed = time.perf_counter() - t0
-                    prof = model.ctx.profile_read(reset=True)
-                    model.ctx.profile_enable(False)
-                    errors, n_done, stopped = model.end()
+                # ONE loop on every path: warm-up iterations | fence | timed iterations | fence.  One process and the native
+                # collective path: klnmf_run_more (the launches klnmf_run / klnmf_run_sharded enqueue, the grouped RCCL
+                # all-reduce of every iteration included); torch path: the loop's pieces around torch.distributed.
+                model.begin()
+                model.iterate_many(args.warmup, fit=True, tol=args.tol)
+                model.ctx.profile_enable(True)
+                fence()
+                t0 = time.perf_counter()
+                model.iterate_many(args.steps, fit=True, tol=args.tol)
+                fence()
+                elapsed = time.perf_counter() - t0
+                prof = model.ctx.profile_read(reset=True)
+                model.ctx.profile_enable(False)
+                errors, n_done, stopped = model.end()
                 t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
                 if world > 1:
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -429,12 +423,10 @@ def main():
         pingpong = fast16 and k <= 512 and os.environ.get('KLNMF_ROWPASS', '4') == '4'      # (224 < k <= 256 joined in round 3)
         stored_q = pingpong and (k > 224 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
         # what the timed loop ran, as the LIBRARY reports it (klnmf_query), not a host-side copy of its rules: the loop's
-        # first two iterations keep 16-bit tiles (the torch path's warm-up absorbs them when --warmup >= 2; the native
-        # path's timed call is a loop of its own and starts with them)
-        timed_loop_only = collective == 'native'
-        fp8_iters = min(args.steps, fp8['tile_iterations']) if (fp8 and stored_q) else 0
-        col8_iters = min(args.steps, fp8['column_pass_iterations']) if (fp8 and stored_q) else 0
-        if not timed_loop_only and fp8 and stored_q:      # one loop = warm-up + timed: the 16-bit iterations come first
+        # first two iterations keep 16-bit tiles; warm-up and timed iterations are ONE loop on every path, so the warm-up
+        # absorbs them when --warmup >= 2
+        fp8_iters = col8_iters = 0
+        if fp8 and stored_q:      # the 16-bit iterations come first
             fp8_iters = max(0, min(args.steps, fp8['tile_iterations'] - max(0, args.warmup - (iters_per_fit - fp8['tile_iterations']))))
             col8_iters = max(0, min(args.steps, fp8['column_pass_iterations'] - max(0, args.warmup - (iters_per_fit - fp8['column_pass_iterations']))))
         frac8 = fp8_iters / float(args.steps)
@@ -526,8 +518,8 @@ def main():
                                'ratio_entries_saturated': fp8['ratio_saturated'] if fp8 else None,
                                'ratio_entries_unfixed': fp8['ratio_unfixed'] if fp8 else None,
                                'source': 'klnmf_query'},
-                       'rccl_ranks': model.rccl_ranks() if n_gpus > 1 else None,
-                       'collective_path': collective if n_gpus > 1 else None,
+                       'rccl_ranks': model.rccl_ranks() if (n_gpus > 1 or comm_single) else None,
+                       'collective_path': collective if (n_gpus > 1 or comm_single) else None,
                        'collective': ('one grouped RCCL all-reduce of the k x f numerator + the loss per iteration, issued inside '
                                       'the C-ABI (klnmf_run_sharded)' if collective == 'native' else
                                       'torch.distributed all-reduce of the k x f numerator + async all-reduce of the loss')

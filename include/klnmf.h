@@ -148,7 +148,11 @@ int klnmf_loop_begin(klnmf_ctx *ctx);
  * the same kernels and the result does not depend on the partition beyond summation order. */
 int klnmf_loop_begin_sharded(klnmf_ctx *ctx, double sum_v_all, double cells_all);
 /* `iters` whole iterations of the open loop at once, enqueued exactly as klnmf_run enqueues them (callers that fence between
- * two parts of one loop: warm-up | timed iterations of bench.py) */
+ * two parts of one loop: warm-up | timed iterations of bench.py).
+ * On a context that holds an RCCL communicator of more than one rank (klnmf_comm_init below) klnmf_loop_begin and
+ * klnmf_run_more are klnmf_run_sharded in parts: the entry agrees the refusals and the fp8 decision over the communicator,
+ * every iteration carries the ONE grouped all-reduce (numerator + loss) between column pass and stop rule; tol_abs is then
+ * tol x n_total x f of the GLOBAL shape (nmf.py:207). */
 int klnmf_run_more(klnmf_ctx *ctx, int64_t iters, int fit, double tol_abs);
 int klnmf_iter_rowpass(klnmf_ctx *ctx, int fit);
 int klnmf_iter_decide(klnmf_ctx *ctx, double tol_abs);

@@ -1864,11 +1864,76 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     c->q8_loop = c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean;
 }
 
+// ---- a loop on this context's RCCL communicator (klnmf_comm_init): entry and iteration, shared by klnmf_run_sharded (the
+// whole loop in one call) and by klnmf_loop_begin / klnmf_run_more (the same loop in parts) ---------------------------------
+// KLNMF_COMM_SINGLE=1 (tests): a ONE-rank communicator takes the collective path too -- the same agreement block, grouped
+// all-reduces (in place, on the loop's own buffers, counts and types) and decision kernel that N ranks execute; RCCL refuses
+// two ranks on one device, so this is the only way a one-GPU box ever runs these lines.
+static bool comm_single_collectives() {
+    const char *g = std::getenv("KLNMF_COMM_SINGLE");
+    return g && std::atoi(g) != 0;
+}
+static bool comm_multi(const klnmf_ctx *c) { return c->comm != nullptr && (c->comm_size > 1 || comm_single_collectives()); }
+
+// Loop entry.  Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
+// (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8 decision
+// is taken from the all-reduced sums, so that all ranks run the same kernels and N = 1 / N = 8 differ by summation order only.
+static void comm_loop_entry(klnmf_ctx *c) {
+    if (c->sparse) fail(KLNMF_ERR_UNSUPP, "loops on a communicator: dense problems only");
+    c->refusals_dirty = true;
+    const Refusals mine = read_refusals(c);
+    DevState ds{};
+    HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double h[4] = {(double)(mine.v_overflow != 0), (double)(mine.op_range != 0), ds.sum_x, (double)c->n * (double)c->f};
+    HIPCHK(hipMemcpyAsync(c->comm_scratch, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(rccl().GroupStart());
+    ncclResult_t r1 = rccl().AllReduce(c->comm_scratch, c->comm_scratch, 2, ncclDouble, ncclMax, c->comm, c->stream);
+    ncclResult_t r2 = rccl().AllReduce(c->comm_scratch + 2, c->comm_scratch + 2, 2, ncclDouble, ncclSum, c->comm, c->stream);
+    ncclResult_t r3 = rccl().GroupEnd();            // always closed, whatever the calls inside returned
+    RCCLCHK(r1); RCCLCHK(r2); RCCLCHK(r3);
+    HIPCHK(hipMemcpyAsync(h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h[0] != 0 || h[1] != 0) {
+        if (mine.v_overflow || mine.op_range) raise_refusals(c, mine);       // this rank's own message
+        fail(h[1] != 0 ? KLNMF_ERR_UNSUPP : KLNMF_ERR_ARG,
+             h[1] != 0 ? "another rank's factors exceed the fp16 operand range: the sharded loop is refused on every rank"
+                       : "another rank's shard of V exceeds the maximum given to klnmf_set_v_max: the sharded loop is refused on every rank");
+    }
+    c->refusals_dirty = false;
+    begin_fp8_loop(c, h[2], h[3]);
+}
+
+// One iteration: row pass -> column pass (it does not depend on the stop decision) -> ONE grouped RCCL launch on the
+// context's stream (the k real rows of the numerator -- the 16-bit modes lay it out [KP][f_pad], rows beyond k are padding --
+// and the two doubles of the loss) -> stop rule on identical inputs -> H rule.
+static void comm_iteration(klnmf_ctx *c, int fit, double tol_abs) {
+    const size_t ncount = c->is_exact() ? (size_t)(c->k * c->f) : (size_t)c->k * (size_t)c->f_pad;
+    void *nbuf = c->is_exact() ? c->numer : (void *)c->numerF;
+    const ncclDataType_t ntype = c->prec == KLNMF_PREC_F64 ? ncclDouble : ncclFloat;
+    piece_rowpass(c, fit);                     // leaves this rank's part of the loss in loss_xchg
+    if (fit) piece_colpass(c);                 // ... and of the numerator
+    RCCLCHK(rccl().GroupStart());
+    ncclResult_t ra = fit ? rccl().AllReduce(nbuf, nbuf, ncount, ntype, ncclSum, c->comm, c->stream) : ncclSuccess;
+    ncclResult_t rb = rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream);
+    ncclResult_t rc = rccl().GroupEnd();       // closed on the error path too
+    RCCLCHK(ra); RCCLCHK(rb); RCCLCHK(rc);
+    piece_decide(c, tol_abs);                  // identical inputs on every rank -> identical decisions
+    if (fit) piece_update_H(c);
+    c->cur ^= 1;
+    c->iter_in_loop += 1;
+    if (fit) poll_fp8_overflow(c);
+}
+
 int klnmf_loop_begin(klnmf_ctx *c) {
     return guarded([&] {
         need_problem(c);
-        check_v_overflow(c);
-        begin_fp8_loop(c);
+        if (comm_multi(c)) {
+            comm_loop_entry(c);                // the entry of klnmf_run_sharded: agreed refusals, agreed fp8 decision
+        } else {
+            check_v_overflow(c);
+            begin_fp8_loop(c);
+        }
         reset_state(c);
         c->loop_start_cur = c->cur;
         c->loop_iters = 0;
@@ -1894,6 +1959,13 @@ int klnmf_run_more(klnmf_ctx *c, int64_t iters, int fit, double tol_abs) {
     return guarded([&] {
         need_problem(c);
         if (iters < 0) fail(KLNMF_ERR_ARG, "iters < 0");
+        if (comm_multi(c)) {                   // the loop of klnmf_run_sharded, continued
+            for (int64_t it = 0; it < iters; ++it) {
+                comm_iteration(c, fit, tol_abs);
+                c->loop_iters += 1;
+            }
+            return;
+        }
         const bool fused = !c->is_exact();
         for (int64_t it = 0; it < iters; ++it) {
             if (fused) {
@@ -2080,19 +2152,11 @@ int klnmf_comm_destroy(klnmf_ctx *c) {
     });
 }
 
-// KLNMF_COMM_SINGLE=1 (tests): a ONE-rank communicator takes the collective path too -- the same agreement block, grouped
-// all-reduces (in place, on the loop's own buffers, counts and types) and decision kernel that N ranks execute; RCCL refuses
-// two ranks on one device, so this is the only way a one-GPU box ever runs these lines.
-static bool comm_single_collectives() {
-    const char *g = std::getenv("KLNMF_COMM_SINGLE");
-    return g && std::atoi(g) != 0;
-}
-
 int klnmf_comm_max(klnmf_ctx *c, double *value) {
     return guarded([&] {
         use(c);
         if (!value) fail(KLNMF_ERR_ARG, "null value");
-        if (!c->comm || (c->comm_size == 1 && !comm_single_collectives())) return;
+        if (!comm_multi(c)) return;
         HIPCHK(hipMemcpyAsync(c->comm_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
         RCCLCHK(rccl().AllReduce(c->comm_scratch, c->comm_scratch, 1, ncclDouble, ncclMax, c->comm, c->stream));
         HIPCHK(hipMemcpyAsync(value, c->comm_scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2107,67 +2171,30 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         if (max_iter < 0 || max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter out of range");
         if (n_total < c->n) fail(KLNMF_ERR_ARG, "n_total smaller than this rank's rows");
         if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_run_sharded: dense problems only");
-        const bool multi = c->comm != nullptr && (c->comm_size > 1 || comm_single_collectives());
-        // Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
-        // (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8
-        // decision is taken from the all-reduced sums, so that all ranks run the same kernels and N = 1 / N = 8 differ by
-        // summation order only.
-        Refusals mine;
-        std::string local_msg;
-        double sum_x_all = -1.0, cells_all = -1.0;
+        const bool multi = comm_multi(c);
         if (multi) {
-            c->refusals_dirty = true;
-            mine = read_refusals(c);
-            DevState ds{};
-            HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            double h[4] = {(double)(mine.v_overflow != 0), (double)(mine.op_range != 0), ds.sum_x, (double)c->n * (double)c->f};
-            HIPCHK(hipMemcpyAsync(c->comm_scratch, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-            RCCLCHK(rccl().GroupStart());
-            ncclResult_t r1 = rccl().AllReduce(c->comm_scratch, c->comm_scratch, 2, ncclDouble, ncclMax, c->comm, c->stream);
-            ncclResult_t r2 = rccl().AllReduce(c->comm_scratch + 2, c->comm_scratch + 2, 2, ncclDouble, ncclSum, c->comm, c->stream);
-            ncclResult_t r3 = rccl().GroupEnd();            // always closed, whatever the calls inside returned
-            RCCLCHK(r1); RCCLCHK(r2); RCCLCHK(r3);
-            HIPCHK(hipMemcpyAsync(h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            if (h[0] != 0 || h[1] != 0) {
-                if (mine.v_overflow || mine.op_range) raise_refusals(c, mine);       // this rank's own message
-                fail(h[1] != 0 ? KLNMF_ERR_UNSUPP : KLNMF_ERR_ARG,
-                     h[1] != 0 ? "another rank's factors exceed the fp16 operand range: the sharded loop is refused on every rank"
-                               : "another rank's shard of V exceeds the maximum given to klnmf_set_v_max: the sharded loop is refused on every rank");
-            }
-            c->refusals_dirty = false;
-            sum_x_all = h[2];
-            cells_all = h[3];
+            comm_loop_entry(c);
         } else {
             check_v_overflow(c);
+            begin_fp8_loop(c);
         }
-        begin_fp8_loop(c, sum_x_all, cells_all);
         reset_state(c);
         c->loop_start_cur = c->cur;
         const double tol_abs = tol * (double)n_total * (double)c->f;          // nmf.py:207 on the GLOBAL shape
-        // what travels: the k real rows of the numerator (the 16-bit modes lay it out [KP][f_pad], rows beyond k are
-        // padding) and the two doubles of the loss -- ONE grouped RCCL launch per iteration, on the context's stream
-        const size_t ncount = c->is_exact() ? (size_t)(c->k * c->f) : (size_t)c->k * (size_t)c->f_pad;
-        void *nbuf = c->is_exact() ? c->numer : (void *)c->numerF;
-        const ncclDataType_t ntype = c->prec == KLNMF_PREC_F64 ? ncclDouble : ncclFloat;
         for (int64_t it = 0; it < max_iter; ++it) {
-            // one rank: the stop decision rides in the loss kernel, as in klnmf_run (one launch less per iteration)
-            if (multi || c->is_exact()) piece_rowpass(c, fit);      // leaves this rank's part of the loss in loss_xchg
-            else piece_rowpass(c, fit, &tol_abs);
-            if (fit) piece_colpass(c);                 // ... and of the numerator (it does not depend on the stop decision)
             if (multi) {
-                RCCLCHK(rccl().GroupStart());
-                ncclResult_t ra = fit ? rccl().AllReduce(nbuf, nbuf, ncount, ntype, ncclSum, c->comm, c->stream) : ncclSuccess;
-                ncclResult_t rb = rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream);
-                ncclResult_t rc = rccl().GroupEnd();        // closed on the error path too
-                RCCLCHK(ra); RCCLCHK(rb); RCCLCHK(rc);
+                comm_iteration(c, fit, tol_abs);
+            } else {
+                // one rank: the stop decision rides in the loss kernel, as in klnmf_run (one launch less per iteration)
+                if (c->is_exact()) piece_rowpass(c, fit);
+                else piece_rowpass(c, fit, &tol_abs);
+                if (fit) piece_colpass(c);
+                if (c->is_exact()) piece_decide(c, tol_abs);
+                if (fit) piece_update_H(c);
+                c->cur ^= 1;
+                c->iter_in_loop += 1;
+                if (fit) poll_fp8_overflow(c);
             }
-            if (multi || c->is_exact()) piece_decide(c, tol_abs);      // identical inputs on every rank -> identical decisions
-            if (fit) piece_update_H(c);
-            c->cur ^= 1;
-            c->iter_in_loop += 1;
-            if (fit) poll_fp8_overflow(c);
             if (tol_abs > 0 && (it & 15) == 15) {
                 DevState hs{};
                 HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));

@@ -20,6 +20,8 @@ pieces of `include/klnmf.h` (klnmf_iter_*) around the collectives.  `backend` ma
 be any object with the same methods (the CPU tests drive the sequencing with an
 oracle-backed double over gloo).
 """
+import os
+
 import numpy as np
 
 
@@ -98,6 +100,9 @@ class ShardedKLNMF(object):
             box = [self.ctx.comm_unique_id() if rank == 0 else None]
             self.dist.broadcast_object_list(box, src=0, group=group)
             self.ctx.comm_init(box[0], rank, self.world_size)
+        elif collective == 'native' and self.world_size == 1 and os.environ.get('KLNMF_COMM_SINGLE') == '1':
+            # rehearsal on one GPU: a one-rank communicator takes the collective branch of the library (tests, bench.py)
+            self.ctx.comm_init(self.ctx.comm_unique_id(), 0, 1)
         self.iterations_enqueued = 0
 
     # ---- data ----
@@ -144,6 +149,12 @@ class ShardedKLNMF(object):
         """Open the loop on every rank -- or on none: a rank whose own shard is refused at the loop's entry (V beyond the
         announced maximum, factors beyond the fp16 operand range) must not leave the others waiting in their first
         all-reduce, so the outcome of the local entry is agreed (max) before anybody enqueues a collective."""
+        if self.collective == 'native':
+            # the agreement (refusal flags max, sums of V and cells) travels over the context's own RCCL communicator
+            # inside klnmf_loop_begin: every rank raises together there
+            self.ctx.loop_begin()
+            self.iterations_enqueued = 0
+            return
         multi = self.dist is not None and self.world_size > 1
         err = None
         try:
@@ -178,6 +189,10 @@ class ShardedKLNMF(object):
     def iterate(self, fit=True, tol=0.0):
         """Enqueue one iteration (no host synchronisation)."""
         tol_abs = tol * self.n_total * self.f          # nmf.py:207 on the GLOBAL shape
+        if self.collective == 'native':
+            self.ctx.run_more(1, fit, tol_abs)
+            self.iterations_enqueued += 1
+            return
         self.ctx.iter_rowpass(fit)
         if fit:
             # The column pass does not depend on the stop decision (it needs W_new and the old ratio only), so
@@ -202,7 +217,9 @@ class ShardedKLNMF(object):
     def iterate_many(self, count, fit=True, tol=0.0):
         """`count` iterations of the open loop.  One process: the library enqueues them itself (klnmf_run_more -- the loss
         reduction and the stop rule then ride in the column pass's slab-sum launch, as in klnmf_run); several: `iterate`."""
-        if (self.dist is None or self.world_size == 1) and hasattr(self.ctx, 'run_more'):
+        if (self.collective == 'native' or self.dist is None or self.world_size == 1) and hasattr(self.ctx, 'run_more'):
+            # (native path, several ranks: klnmf_run_more carries the grouped RCCL all-reduce of every iteration itself --
+            # klnmf_run_sharded in parts)
             self.ctx.run_more(count, fit, tol * self.n_total * self.f)
             self.iterations_enqueued += int(count)
             return

@@ -141,6 +141,64 @@ def test_collective_branch_of_run_sharded_on_a_one_rank_communicator(monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['f16', 'f64'])
+def test_loop_in_parts_on_a_communicator_is_run_sharded(monkeypatch, precision):
+    """klnmf_loop_begin + klnmf_run_more + klnmf_loop_end on a context with a communicator = klnmf_run_sharded in parts (what
+    bench.py's native path times: warm-up | fence | timed iterations of ONE loop): bit-identical losses, W and H."""
+    from multimodal_amd import _native
+    monkeypatch.setenv('KLNMF_COMM_SINGLE', '1')
+    n, f, k, iters = 40000, 256, 64, 7               # (fp8 ratio tiles from the loop's third iteration on in f16)
+    X = orc.synthetic_V(11, n, f, k)
+    H0 = orc.synthetic_H0(11, f, k)
+    out = []
+    for parts in (False, True):
+        with _native.Context(precision, device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            if parts:
+                ctx.loop_begin()
+                ctx.run_more(3, True, 0.0)
+                ctx.synchronize()
+                ctx.run_more(iters - 3, True, 0.0)
+                errs, n_done, stopped = ctx.loop_end(iters)
+            else:
+                errs, n_done, stopped = ctx.run_sharded(n, iters, True, 0.0)
+            rep = ctx.fp8_report() if precision == 'f16' else None
+            out.append((np.array(errs), n_done, stopped, ctx.get_W(), ctx.get_H(), rep))
+            ctx.comm_destroy()
+    assert out[0][1] == out[1][1] == iters
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][3], out[1][3])
+    np.testing.assert_array_equal(out[0][4], out[1][4])
+    if precision == 'f16':
+        assert out[0][5]['tile_iterations'] == out[1][5]['tile_iterations'] == iters - 2
+
+
+@pytest.mark.gpu
+def test_bench_native_path_on_a_one_rank_communicator():
+    """bench.py's NATIVE collective path end to end on one GPU (KLNMF_COMM_SINGLE=1: a one-rank RCCL communicator, the
+    library's collective branch with its all-reduces): the line says which path ran and how many ranks RCCL saw, and the timed
+    iterations are the tail of ONE loop (every one of them on fp8 tiles after a warm-up of 2 or more)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KLNMF_COMM_SINGLE='1')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '3', '--repeats', '2', '--rows', '40000',
+           '--features', '512', '--components', '40', '--no-cpu-baseline', '--no-16bit-segment', '--collective', 'native']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    cfg = d['config']
+    assert cfg['collective_path'] == 'native' and cfg['rccl_ranks'] == 1
+    assert d['valid'] and d['n_gpus'] == 1 and d['loss_finite_and_decreasing']
+    assert cfg['fp8']['timed_iterations_with_fp8_ratio_tiles'] == 5
+
+
+@pytest.mark.gpu
 def test_collective_branch_refuses_together(monkeypatch):
     """The agreement block's refusal: a shard whose V exceeds the announced maximum fails klnmf_run_sharded with the rank's
     own message after the flags went through the all-reduce (KLNMF_COMM_SINGLE: the collective branch on one rank)."""
