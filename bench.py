@@ -82,6 +82,53 @@ class Watchdog(object):
         return False
 
 
+class PowerClockSampler(object):
+    """Socket power and shader clock of this rank's card while the timed segments run (rocm-smi from a
+    helper thread, back to back: sysfs reads, no GPU context of its own).  The 2.5 PFLOP/s the roofline divides by assume 2.4 GHz; under this
+    workload the part sits at its board power limit and holds 1.5-1.6 GHz, so the line also says what the kernel reaches of the
+    peak AT THE HELD CLOCK.  Purely informative: any failure (no rocm-smi, unreadable fields) leaves the fields None."""
+    NOMINAL_MHZ = 2400.0
+
+    def __init__(self, card):
+        import threading
+        self.card, self.samples, self.stop_flag = 'card%d' % card, [], threading.Event()
+        self.thread = threading.Thread(target=self.loop)
+        self.thread.daemon = True
+
+    def loop(self):
+        import subprocess
+        while not self.stop_flag.is_set():
+            try:
+                out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showuse', '--json'], capture_output=True,
+                                     text=True, timeout=5).stdout
+                c = json.loads(out[out.index('{'):]).get(self.card, {})
+                num = lambda v: float(str(v).strip('()').lower().replace('mhz', ''))
+                power = [num(v) for kk, v in c.items() if 'power' in kk.lower()]
+                self.samples.append((power[0] if power else None, num(c.get('sclk clock speed:')), num(c.get('GPU use (%)', 0))))
+            except Exception:
+                pass
+            self.stop_flag.wait(0.05)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop_flag.set()
+        self.thread.join(timeout=10)
+        return False
+
+    def summary(self):
+        busy = [(p, c) for p, c, u in self.samples if u >= 50 and p is not None and c is not None]
+        if not busy:
+            return None
+        ps, cs = sorted(p for p, _ in busy), sorted(c for _, c in busy)
+        return {'samples_used': len(busy), 'socket_power_w_median': ps[len(ps) // 2], 'socket_power_w_max': ps[-1],
+                'sclk_mhz_median': cs[len(cs) // 2], 'sclk_mhz_min': cs[0], 'sclk_mhz_max': cs[-1],
+                'nominal_sclk_mhz': self.NOMINAL_MHZ, 'samples_total': len(self.samples),
+                'source': 'rocm-smi --showpower --showclocks --showuse, back to back during the timed segments (samples at >= 50 % use)'}
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -388,7 +435,9 @@ def main():
             fp8 = model.ctx.fp8_report()
         return segments, fits, prof_tot, tail_rows, fp8
 
-    segments, fits, prof_tot, tail_rows, fp8 = run_segments(args.repeats)
+    with PowerClockSampler(local_rank) as sampler:
+        segments, fits, prof_tot, tail_rows, fp8 = run_segments(args.repeats)
+    power_clock = sampler.summary() if rank == 0 else None
     # The same workload with 16-bit ratio tiles and the f16-operand column pass (KLNMF_QTILE=16 is read at every loop's
     # entry): the number the north star's "bf16/16-bit MFMA contractions" wording describes, beside the headline one.
     value_16bit = None
@@ -484,6 +533,10 @@ def main():
                            'frac': (row_gbs / PEAK_HBM_GBS if mfma_bound else row_tflops / PEAK_BF16_TFLOPS) if row_s > 0 else None},
             'schedule_hbm_gbs': sched_bytes_row / row_s / 1e9 if row_s > 0 else None,
         }
+        if power_clock and mfma_bound and roofline['frac']:
+            # `frac` divides by the nominal peak (2.4 GHz); this is the same kernel against the MFMA peak at the clock the card
+            # actually held under its power limit during the timed segments (informative; the contract's number is `frac`)
+            roofline['frac_at_held_clock'] = roofline['frac'] * PowerClockSampler.NOMINAL_MHZ / power_clock['sclk_mhz_median']
         errors, n_done, stopped = fits[-1]
         all_full = all(nd == iters_per_fit and not st for _, nd, st in fits)
         out = {
@@ -542,6 +595,7 @@ def main():
                                                and all(b < a for a, b in zip(errors, errors[1:]))),
             'device': info,
             'roofline': roofline,
+            'power_clock': power_clock,
             'kernels': {
                 'row_pass_section': {
                     'what': ('whole-row k_rowpass4 over %d rows (the roofline entry) + column-split k_rowpass4 over the last %d '
