@@ -435,9 +435,13 @@ def main():
             fp8 = model.ctx.fp8_report()
         return segments, fits, prof_tot, tail_rows, fp8
 
-    with PowerClockSampler(local_rank) as sampler:
+    if rank == 0:          # (one sampler per job: rank 0's card)
+        with PowerClockSampler(local_rank) as sampler:
+            segments, fits, prof_tot, tail_rows, fp8 = run_segments(args.repeats)
+        power_clock = sampler.summary()
+    else:
         segments, fits, prof_tot, tail_rows, fp8 = run_segments(args.repeats)
-    power_clock = sampler.summary() if rank == 0 else None
+        power_clock = None
     # The same workload with 16-bit ratio tiles and the f16-operand column pass (KLNMF_QTILE=16 is read at every loop's
     # entry): the number the north star's "bf16/16-bit MFMA contractions" wording describes, beside the headline one.
     value_16bit = None
