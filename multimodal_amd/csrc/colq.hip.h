@@ -28,6 +28,17 @@
 #pragma once
 #include "mfma4.hip.h"
 
+// the ratio tiles are written once by the row pass and read once here; as non-temporal copies (-DKL_Q_NT=1) the fp8 x fp8 column
+// pass ran 7 % SLOWER (0.92 vs 0.86 ms; the row pass behind it 2 % faster, the iteration equal): off (profiles/r03_ab_nontemporal.txt)
+#ifndef KL_Q_NT
+#define KL_Q_NT 0
+#endif
+#if KL_Q_NT
+#define KL_Q_NT_MOD " nt"
+#else
+#define KL_Q_NT_MOD ""
+#endif
+
 namespace klnmf {
 
 __host__ __device__ constexpr int colq_w_area(int kp) { return round_up(32 * w_ld(kp) * 2, kGldsRound); }
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
 #pragma unroll
         for (int pp = 0; pp < QP; ++pp) {
             const int p = Q8 ? pp : kh * QP + pp;  // KSPLIT = 2: the two waves of a column tile copy one piece each (Q8: the same tile)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + ctl * QTB + 1024 * p), "v"(ql32), "s"(qbase + p * 256) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KL_Q_NT_MOD ::"s"(lds_addr(obj(o)) + WA + ctl * QTB + 1024 * p), "v"(ql32), "s"(qbase + p * 256) : "memory");
         }
 #endif
     };

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
 #pragma unroll
         for (int pp = 0; pp < QPW; ++pp) {
             const int p = kh * QPW + pp;               // KSPLIT = 2: the two waves of a column tile copy one tile each
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + (2 * ctl + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KL_Q_NT_MOD ::"s"(lds_addr(obj(o)) + WA + (2 * ctl + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
         }
     };
     const int rcol_of_r = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);      // logical column of this lane's physical column

@@ -109,9 +109,17 @@ __device__ __forceinline__ void lds_read_tr_pair(opx8 &dst, unsigned addr0, unsi
 // therefore waits vmcnt(0) once per E segment and lets the compiler place the waits of these loads.
 // p: wave-uniform (scalar) address of the tile, off: this lane's byte offset -- the form the compiler turns into
 // `global_load_dwordx4 v, v_off, s[base]` (no 64-bit VALU address arithmetic in the epilogue segment)
+#ifndef KL_V_NT
+#define KL_V_NT 1
+#endif
 __device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p, unsigned off) {
+#if KL_V_NT            // V is read once per iteration: non-temporal loads (round 3: row pass -0.7 %, iteration -0.5 % in two interleaved
+    a = __builtin_nontemporal_load((const f16x8 *)(p + off));          // A/Bs, bit-identical: profiles/r03_ab_nontemporal.txt; -DKL_V_NT=0: default policy)
+    b = __builtin_nontemporal_load((const f16x8 *)(p + off + 1024));
+#else
     a = *(const f16x8 *)(p + off);              // tiles are piece-major (k_tile_V): each instruction = 1 KiB of contiguous memory
     b = *(const f16x8 *)(p + off + 1024);
+#endif
 }
 // global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
 template <int BYTES, int NW = kWaves4>
