@@ -112,6 +112,9 @@ __device__ __forceinline__ void lds_read_tr_pair(opx8 &dst, unsigned addr0, unsi
 #ifndef KL_V_NT
 #define KL_V_NT 1
 #endif
+#ifndef KL_W_NT            // the fp32 master of W: read once (old) and written once (new) per iteration by the row pass's tail --
+#define KL_W_NT 1          // non-temporal too (iteration -0.3 %, bit-identical; the conversion kernel's reads of the f16 image as
+#endif                     // non-temporal loads made the column pass behind it 2 % slower: not adopted.  profiles/r03_ab_nontemporal.txt)
 __device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p, unsigned off) {
 #if KL_V_NT            // V is read once per iteration: non-temporal loads (round 3: row pass -0.7 %, iteration -0.5 % in two interleaved
     a = __builtin_nontemporal_load((const f16x8 *)(p + off));          // A/Bs, bit-identical: profiles/r03_ab_nontemporal.txt; -DKL_V_NT=0: default policy)
@@ -979,7 +982,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         for (int mm = 0; mm < MB1; ++mm)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                wold_e[mm][j] = *(const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e);
+                wold_e[mm][j] = KL_W_NT ? __builtin_nontemporal_load((const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e))
+                                        : *(const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE != ROW_INIT) {
@@ -1033,7 +1037,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     if (MODE == ROW_UPDATE && m0 + mm < MB1) {
                         wold[mm][j] = wold_e[mm][j];                 // requested before the loss sums
                     } else if (MODE == ROW_UPDATE && m0 + mm < KT) {
-                        wold[mm][j] = *(const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4);
+                        wold[mm][j] = KL_W_NT ? __builtin_nontemporal_load((const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4))
+                                              : *(const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4);
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) wold[mm][j][t] = 1.f;
@@ -1078,7 +1083,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #endif
                         wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);      // eps carrier
                     }
-                    *(f32x4 *)(a.W32_new + (row0 + rl) * KP + comp) = w;
+                    if (KL_W_NT) __builtin_nontemporal_store(w, (f32x4 *)(a.W32_new + (row0 + rl) * KP + comp));
+                    else *(f32x4 *)(a.W32_new + (row0 + rl) * KP + comp) = w;
                     *(opx4 *)(a.Wb_new + (row0 + rl) * WLD + wb_col(rl, comp)) = wb;
 #ifndef KL_OPND_BF16
                     if (w8on) {                                             // the e4m3 image, the operations of k_w8_from_wb
