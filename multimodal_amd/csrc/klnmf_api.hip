@@ -530,6 +530,8 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
         a.W8 = c->W8;
         a.w8s = c->w8s;
         a.w8max = c->w8max;
+        a.w8_sat = &c->st->w8_sat;
+        a.w8_probe = w8_probe_col(c);
     }
     const int grid = (c->nrt + kWavesPerWG - 1) / kWavesPerWG;
     if (mode == ROW_UPDATE && a.Qt && c->pingpong() && c->q8()) c->stat_q8_tiles += 1;      // this update leaves fp8 ratio tiles
@@ -578,7 +580,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                 const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
                 hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
                                    c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
-                                   c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st);
+                                   c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st, &c->st->w8_sat, w8_probe_col(c));
                 HIPCHK(hipGetLastError());
                 c->w8_entries = t4.base.rt0 + blocks;
                 c->w8_meas = true;
@@ -695,8 +697,8 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
         c->stat_col8 += 1;
         col8_ran = true;
         if (c->profiling) ev = begin_event(c, c->ev_col);
-        a.guard = c->w8_tail ? 0 : 1;      // (KLNMF_COL8=2: the W rule writes the image itself and does not count: no guard)
-        ColPass8Args a8{a, c->W8, c->w8s, (!c->w8_tail && w8_probe_col(c) >= 0) ? 1 : 0};
+        a.guard = 1;                       // (the image's clipped entries are counted by whoever wrote it: conversion kernel or W rule)
+        ColPass8Args a8{a, c->W8, c->w8s, w8_probe_col(c) >= 0 ? 1 : 0};
 #define KL_Q8X(KTV, NBV, KSV) case KTV:                                                                                              \
             if (a8.probe) hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a8);        \
             else hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a8);                 \
@@ -1422,6 +1424,10 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             if (c->q8_ok && !col8_off && col8_size) {
                 c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * w8_ld(c->KP) + 65536);
                 c->w8max = (unsigned *)c->dalloc(((size_t)c->nrt + kW8Blocks) * c->KP * 4);
+                // who writes the e4m3 image: the conversion kernel behind the row pass (default) or the row pass's W rule itself
+                // (KLNMF_COL8=2, k <= 224: one pass over W less and no conversion launch, counted and probed like the kernel's
+                // image since round 3 -- +0.6 % at n = 10^6, -0.8 % on a 125 000-row shard where the tail weighs more:
+                // profiles/r03_ab_w8_from_w_rule.txt; not the default)
                 c->w8_tail = !c->big && std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
                 c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
                 c->w8fin = (unsigned *)c->dalloc((size_t)c->KP * 4);      // (dalloc hands out zero-filled blocks)

@@ -277,6 +277,8 @@ struct RowPassArgs {
     unsigned char *W8;
     const float *w8s;         // [KP]
     unsigned *w8max;          // [nrt][KP] float bit patterns
+    int *w8_sat;              // entries of this image beyond e4m3's 448 (stored as 448) are counted here, as k_w8_from_wb does
+    int w8_probe;             // the image's probe column (colq8x.hip.h; e4m3 1.0 in every row): KP - 1 or -1 (none)
 };
 
 // LDS per stage buffer: [dictionary image | V tiles of the 8 waves (16-bit V only)]

@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         typedef __attribute__((ext_vector_type(2))) short s16x2w;
         const bool w8on = MODE == ROW_UPDATE && KT <= 8 && a.W8 != nullptr;      // scalar
         f16x2w mx8[KT <= 8 ? KT : 1][2];                                         // running column maxima of the f16 image (packed)
+        int nsat8 = 0;                                                           // entries of the e4m3 image that clipped at 448 (wave-uniform: a scalar)
         if (w8on) {
 #pragma unroll
             for (int m = 0; m < (KT <= 8 ? KT : 1); ++m) { mx8[m][0] = f16x2w{(_Float16)0.f, (_Float16)0.f}; mx8[m][1] = mx8[m][0]; }
@@ -1093,9 +1094,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                         mx8[mm][1] = __builtin_elementwise_max(mx8[mm][1], hi);
                         s16x2w w8;
                         asm volatile("" : "=v"(w8));
-                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, lo * inv8[0], 1.f, false);
-                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, hi * inv8[1], 1.f, true);
-                        *(unsigned *)(a.W8 + (row0 + rl) * (KP + ((KP / 32) % 2 == 0 ? 32 : 0)) + comp) = __builtin_bit_cast(unsigned, w8);      // row stride: w8_ld(KP), colq8x.hip.h
+                        const f16x2w p0 = lo * inv8[0], p1 = hi * inv8[1];
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, p0, 1.f, false);
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, p1, 1.f, true);
+                        const f16x2w top = __builtin_elementwise_max(p0, p1);                  // (448 is an f16 number)
+                        if (__builtin_amdgcn_ballot_w64(top[0] > (_Float16)448.f || top[1] > (_Float16)448.f) != 0ull)      // rare, wave-uniform:
+                            nsat8 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p0[0] > (_Float16)448.f))                // a column that more than doubled
+                                   + __builtin_popcountll(__builtin_amdgcn_ballot_w64(p0[1] > (_Float16)448.f))
+                                   + __builtin_popcountll(__builtin_amdgcn_ballot_w64(p1[0] > (_Float16)448.f))
+                                   + __builtin_popcountll(__builtin_amdgcn_ballot_w64(p1[1] > (_Float16)448.f));
+                        unsigned w8u = __builtin_bit_cast(unsigned, w8);
+                        // the probe column (always the image's last one, KP - 1 = byte 3 of the last block's last word): e4m3 1.0 in every row
+                        if (m == KT - 1 && a.w8_probe >= 0 && c4 == 28) w8u = (w8u & 0x00ffffffu) | 0x38000000u;
+                        *(unsigned *)(a.W8 + (row0 + rl) * (KP + ((KP / 32) % 2 == 0 ? 32 : 0)) + comp) = w8u;      // row stride: w8_ld(KP), colq8x.hip.h
                     }
 #endif
                 }
@@ -1103,6 +1114,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             }
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
         }
+        if (w8on && nsat8 != 0 && a.w8_sat != nullptr && lane == 0) atomicAdd(a.w8_sat, nsat8);
         if (w8on) {
             // maxima over the wave's 32 rows: the eight lanes with the same components differ in lane bits 3..5
 #pragma unroll
