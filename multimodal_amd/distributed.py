@@ -97,7 +97,18 @@ class ShardedKLNMF(object):
         self.collective = collective
         if collective == 'native' and self.dist is not None and self.world_size > 1:
             rank = self.dist.get_rank(group)
-            box = [self.ctx.comm_unique_id() if rank == 0 else None]
+            # pre-flight: every rank opens librccl (klnmf_comm_unique_id does) and the outcome is agreed BEFORE anybody enters
+            # ncclCommInitRank -- a rank that cannot load the library would otherwise leave the others waiting there for ever
+            err, my_id = None, None
+            try:
+                my_id = self.ctx.comm_unique_id()
+            except Exception as e:
+                err = e
+            ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=self.tensor_device)
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=group)
+            if float(ok.item()) == 0.0:
+                raise err if err is not None else RuntimeError('librccl is not usable on another rank: no native communicator on any rank')
+            box = [my_id if rank == 0 else None]
             self.dist.broadcast_object_list(box, src=0, group=group)
             self.ctx.comm_init(box[0], rank, self.world_size)
         elif collective == 'native' and self.world_size == 1 and os.environ.get('KLNMF_COMM_SINGLE') == '1':

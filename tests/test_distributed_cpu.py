@@ -232,3 +232,46 @@ def test_a_refusal_on_one_rank_stops_every_rank(tmp_path):
     msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
     assert 'exceeds the maximum' in msgs[1]                  # the rank that was refused says why
     assert "another rank's shard was refused" in msgs[0]     # the other one stops too, and says so
+
+
+class NoRcclContext(OracleContext):
+    """A rank on which librccl cannot be opened (klnmf_comm_unique_id fails with KLNMF_ERR_RCCL)."""
+    def __init__(self, broken):
+        OracleContext.__init__(self)
+        self.broken = broken
+
+    def comm_unique_id(self):
+        if self.broken:
+            raise RuntimeError("klnmf error -6: librccl not found")
+        return b'\0' * 128
+
+    def comm_init(self, uid, rank, nranks):
+        raise AssertionError("ncclCommInitRank must not be entered when a rank cannot load librccl")
+
+
+def _preflight_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        try:
+            ShardedKLNMF(64, 32, 16, 4, max_iter=2, backend=NoRcclContext(broken=(rank == 1)), collective='native')
+            msg = 'constructed'
+        except RuntimeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, 'r%d.txt' % rank), 'w') as fh:
+            fh.write(msg)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_communicator_preflight_is_agreed(tmp_path):
+    """A rank that cannot open librccl says so before anybody enters ncclCommInitRank: every rank raises (bench.py then falls
+    back to the torch path on all of them together) instead of the healthy ranks waiting for the missing one for ever."""
+    import torch.multiprocessing as mp
+    mp.spawn(_preflight_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
+    assert 'librccl not found' in msgs[1]
+    assert 'not usable on another rank' in msgs[0]
