@@ -570,6 +570,7 @@ def main():
                                'timed_iterations_with_fp8_ratio_tiles': fp8_iters,
                                'timed_iterations_with_fp8_x_fp8_column_pass': col8_iters,
                                # e4m3 saturation of the last timed loop: counted and kept out of the result (include/klnmf.h)
+                               'ratio_without_numerator_eps': fp8.get('no_numerator_eps') if fp8 else None,
                                'w_image_saturated_entries': fp8['w_image_saturated'] if fp8 else None,
                                'w_image_fallback_iterations': fp8['w_image_fallback_iterations'] if fp8 else None,
                                'ratio_entries_saturated': fp8['ratio_saturated'] if fp8 else None,

@@ -273,6 +273,10 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
 #define KLNMF_Q_W8_FALLBACKS      6
 #define KLNMF_Q_RATIO_SATURATED   7
 #define KLNMF_Q_RATIO_UNFIXED     8
+/*   KLNMF_Q_NO_NUM_EPS       1 if that loop's update passes on fp8 tiles formed the ratio as x / (W.H + eps) instead of the
+ *                            reference's (x + eps) / (W.H + eps) (nmf.py:332-336): taken at the loop's entry where eps / mean(V)
+ *                            <= 1e-5 (k <= 224), zeros stored as 2^-24, the loss corrected exactly; KLNMF_NE=0 turns it off */
+#define KLNMF_Q_NO_NUM_EPS        9
 int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 /*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */
 #define KLNMF_QF_SUM_V            0

@@ -229,6 +229,7 @@ def all_distances_device(dA, lda, dB, ldb, dout, na, nb, d, metric, f64=True, de
 
 Q_FP8_LOOP, Q_FP8_TILE_ITERS, Q_FP8_COL_ITERS, Q_RATIO_TILE_BYTES, Q_COMM_RANKS = 0, 1, 2, 3, 4
 Q_W8_SATURATED, Q_W8_FALLBACKS, Q_RATIO_SATURATED, Q_RATIO_UNFIXED = 5, 6, 7, 8
+Q_NO_NUM_EPS = 9
 
 
 def selftest(device=0):
@@ -607,4 +608,6 @@ class Context(object):
                 'column_pass_iterations': self.query(Q_FP8_COL_ITERS),
                 # e4m3 saturation: counted and kept out of the result (see include/klnmf.h)
                 'w_image_saturated': self.query(Q_W8_SATURATED), 'w_image_fallback_iterations': self.query(Q_W8_FALLBACKS),
-                'ratio_saturated': self.query(Q_RATIO_SATURATED), 'ratio_unfixed': self.query(Q_RATIO_UNFIXED)}
+                'ratio_saturated': self.query(Q_RATIO_SATURATED), 'ratio_unfixed': self.query(Q_RATIO_UNFIXED),
+                # the loop's update passes formed the ratio without the numerator's eps (large-mean data; loss corrected exactly)
+                'no_numerator_eps': bool(self.query(Q_NO_NUM_EPS))}

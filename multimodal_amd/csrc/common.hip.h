@@ -19,6 +19,8 @@ struct DevState {
     double prev_err;   // prev_error of nmf.py:206 (starts at +inf)
     double sum_x;      // sum of V as stored (bf16 modes: the loss is assembled from partial sums)
     double corr_c;     // storage-rounding correction of the loss (0 when V is stored exactly)
+    double corr_eps;   // sum over the stored V of x ln(1 + eps/x): what the loss of an update pass WITHOUT the numerator's eps
+                       // (ratio x / (W.H + eps): mfma4.hip.h, NE) lacks against the reference's x ln((x + eps) / (W.H + eps))
     int stop;          // stop rule fired (the `break` of nmf.py:216)
     int n_done;        // updates executed == len(errors)
     int v_overflow;    // uploaded values that exceeded the fp16 range announced with klnmf_set_v_max (saturated)

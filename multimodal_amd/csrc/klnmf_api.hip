@@ -241,6 +241,9 @@ struct klnmf_ctx {
     // what the last loop actually ran (klnmf_query): iterations whose ratio tiles were fp8, whose column pass was fp8 x fp8
     int64_t stat_q8_tiles = 0, stat_col8 = 0;
     uint2 *q8_list = nullptr;                 // [kQ8ListCap] saturated ratio entries of the current iteration (colq.hip.h)
+    bool zero_class = false;                  // fp16 V tiles hold 2^-24 where the data (and the padding) is zero: problems whose loops may run NE kernels
+    bool ne_loop = false;                     // this loop's fp8-tile update passes drop the numerator's eps (NE kernels; begin_fp8_loop)
+    bool last_row_ne = false;                 // ... and the update pass just launched was one of them (its loss needs DevState.corr_eps)
     bool in_capture = false;                  // a hipGraph capture is recording this context's launches (no synchronising polls)
     // the saturation counters of the last loop as its end found them (DevState is reset by the next entry point)
     int64_t stat_w8_sat = 0, stat_w8_fallbacks = 0, stat_q8_sat = 0, stat_q8_unfixed = 0;
@@ -388,10 +391,22 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
     const dim3 grid(grid_x, grid_y);
     const int odd = 2 * c->KT - c->ks;
     const bool ep = c->kc >= 0;
+    const bool ne = MODE == ROW_UPDATE && c->ne_loop && !c->big && c->q8() && a.base.Qt != nullptr;      // (NE kernels: Q8 = 2)
+    if (MODE == ROW_UPDATE) c->last_row_ne = ne;
 #define KL_ROW4_CASE(KTV)                                                                                       \
     case KTV:                                                                                                   \
         if constexpr (MODE == ROW_UPDATE) {                                                                     \
             if (grid_y > 1 && c->q8() && a.base.Qt) {      /* column-split pass leaving fp8 ratio tiles */      \
+                if (ne) {      /* ... and the ratio without the numerator's eps */                              \
+                    if (ep) {                                                                                   \
+                        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 1, 2>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 1, 2>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                    } else {                                                                                    \
+                        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0, 8, 1, 2>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 8, 1, 2>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                    }                                                                                           \
+                    break;                                                                                      \
+                }                                                                                               \
                 if (ep) {                                                                                       \
                     if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 1, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
                     else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 1, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
@@ -414,6 +429,16 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
         }                                                                                                       \
         if constexpr (MODE == ROW_UPDATE) {                                                                     \
             if (c->q8() && a.base.Qt) {     /* fp8 ratio tiles for the column pass */                             \
+                if (ne) {                                                                                       \
+                    if (ep) {                                                                                   \
+                        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 0, 2>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 0, 2>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                    } else {                                                                                    \
+                        if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 0, 8, 0, 2>), grid, dim3(kThreads4), 0, c->stream, a);  \
+                        else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 8, 0, 2>), grid, dim3(kThreads4), 0, c->stream, a);      \
+                    }                                                                                           \
+                    break;                                                                                      \
+                }                                                                                               \
                 if (ep) {                                                                                       \
                     if (odd) hipLaunchKernelGGL((k_rowpass4<KTV, 1, MODE, 1, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);  \
                     else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 1, 8, 0, 1>), grid, dim3(kThreads4), 0, c->stream, a);      \
@@ -952,6 +977,15 @@ void exact_H(klnmf_ctx *c) {
     } while (0)
 
 // ------------------------------------------------------------- loop pieces ---
+// Empty V tile buffers.  fp16 storage of a problem that may run the NE kernels (zero_class): every element is the zero class of
+// k_tile_V (the smallest positive fp16 number, bit pattern 1) -- padding rows and columns included, so that an update pass
+// without the numerator's eps never sees a zero.  Other problems keep true zeros (an all-zero row of V then gives an exactly
+// zero row of W, as in the reference; with the zero class it is ~1e-12 of the matrix maximum).
+void fill_v_tiles(klnmf_ctx *c, void *tiles, size_t bytes) {
+    if (c->vsize() == 2 && c->zero_class) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)tiles, (unsigned short)1, bytes / 2, c->stream));
+    else HIPCHK(hipMemsetAsync(tiles, 0, bytes, c->stream));
+}
+
 void reset_state(klnmf_ctx *c) {
     hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(1), 0, c->stream, c->st);
     HIPCHK(hipGetLastError());
@@ -974,13 +1008,13 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
             // a fit in one context: nothing needs the loss before the H rule -- it is reduced (and the stop rule applied) by
             // one extra block of the slab-sum launch behind the column pass (launch_sum_partials)
             c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 1, c->st,
-                                       *fused_tol, c->errors, c->cap};
+                                       *fused_tol, c->errors, c->cap, c->last_row_ne ? 1 : 0};
             return;
         }
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const double2 *)c->loss_part2, c->loss_parts(),
                            (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
-                           fused_tol ? *fused_tol : 0.0, c->errors, c->cap);
+                           fused_tol ? *fused_tol : 0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
 }
@@ -1040,7 +1074,7 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
         case KLNMF_PREC_BF16:
             hipLaunchKernelGGL((k_tile_V<_Float16, S>), dim3(grid), dim3(256), 0, c->stream,
                                (_Float16 *)c->VtA, (_Float16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
-                               ld, row0, col0, scale * c->v_scale, c->st, row_idx);
+                               ld, row0, col0, scale * c->v_scale, c->st, row_idx, kEpsRatio * c->v_scale, c->zero_class ? 1 : 0);
             break;
         default:
             hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
@@ -1412,8 +1446,11 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->q8_loop = false;
             c->iter_in_loop = 0;
             c->v_max = 0.0;
-            c->VtA = c->dalloc(vbytes);
-            c->VtB = stored_q ? nullptr : c->dalloc(vbytes);
+            c->zero_class = c->q8_ok && !c->big && c->vsize() == 2;      // (q8_ok: enough rows for fp8 ratio tiles -- where the NE kernels exist)
+            c->VtA = c->dalloc(vbytes, false);
+            c->VtB = stored_q ? nullptr : c->dalloc(vbytes, false);
+            fill_v_tiles(c, c->VtA, vbytes);
+            if (c->VtB) fill_v_tiles(c, c->VtB, vbytes);
             c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
             c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8fin = nullptr; c->w8_meas = false;
             c->q8_list = c->q8_ok ? (uint2 *)c->dalloc(sizeof(uint2) * kQ8ListCap) : nullptr;
@@ -1637,10 +1674,10 @@ int klnmf_reset_V(klnmf_ctx *c) {
             HIPCHK(hipMemsetAsync(c->V, 0, (size_t)c->n * c->f * c->esize(), c->stream));
         } else {
             const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * c->vsize();
-            HIPCHK(hipMemsetAsync(c->VtA, 0, vbytes, c->stream));
-            if (c->VtB) HIPCHK(hipMemsetAsync(c->VtB, 0, vbytes, c->stream));
+            fill_v_tiles(c, c->VtA, vbytes);
+            if (c->VtB) fill_v_tiles(c, c->VtB, vbytes);
         }
-        HIPCHK(hipMemsetAsync(&c->st->sum_x, 0, sizeof(double) * 2, c->stream));         // sum_x, corr_c
+        HIPCHK(hipMemsetAsync(&c->st->sum_x, 0, sizeof(double) * 3, c->stream));         // sum_x, corr_c, corr_eps
         HIPCHK(hipMemsetAsync(&c->st->v_overflow, 0, sizeof(int), c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->v_uploaded = false;
@@ -1855,9 +1892,16 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     c->w8_use = false;
     c->stat_q8_tiles = 0;
     c->stat_col8 = 0;
+    c->ne_loop = false;
+    c->last_row_ne = false;
     if (c->is_exact() || !c->q8_ok) return;
+    const char *ne_env = std::getenv("KLNMF_NE");          // 0: never, 1: in every loop on fp8 tiles (tests), unset: by the data's mean (below)
     const char *g = std::getenv("KLNMF_QTILE");
-    if (g) { c->q8_loop = std::atoi(g) == 8; return; }
+    if (g) {
+        c->q8_loop = std::atoi(g) == 8;
+        c->ne_loop = c->q8_loop && c->zero_class && ne_env && std::atoi(ne_env) == 1;
+        return;
+    }
     double sum_x = sum_x_global, cells = cells_global;
     if (sum_x < 0) {
         DevState ds{};
@@ -1868,6 +1912,12 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     }
     const double mean = sum_x / c->v_scale / cells;
     c->q8_loop = c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean;
+    // The ratio without the numerator's eps (NE kernels, k <= 224): x / (W.H + eps) differs from the reference's
+    // (x + eps) / (W.H + eps) by a relative eps / x per element.  Simulated in fp64 over 50 iterations
+    // the loss record moves by 0.06 .. 0.15 x eps / mean(V) and the factors by 0.5 .. 2.3 x eps / mean(V) of their maxima:
+    // taken where eps / mean(V) <= 1e-5, i.e. 1.5e-6 and 2.5e-5 -- below the fp8 tiles' own floor (h29).
+    c->ne_loop = c->q8_loop && c->zero_class && mean >= 1.0e5 * kEpsRatio;
+    if (ne_env) c->ne_loop = c->q8_loop && c->zero_class && std::atoi(ne_env) == 1;
 }
 
 // ---- a loop on this context's RCCL communicator (klnmf_comm_init): entry and iteration, shared by klnmf_run_sharded (the
@@ -2484,6 +2534,7 @@ int klnmf_query(klnmf_ctx *c, int what, int64_t *value) {
             case KLNMF_Q_W8_FALLBACKS: *value = c->stat_w8_fallbacks; break;
             case KLNMF_Q_RATIO_SATURATED: *value = c->stat_q8_sat; break;
             case KLNMF_Q_RATIO_UNFIXED: *value = c->stat_q8_unfixed; break;
+            case KLNMF_Q_NO_NUM_EPS: *value = c->ne_loop ? 1 : 0; break;
             case KLNMF_Q_COMM_RANKS: {
                 int cnt = 1;
                 if (c->comm) RCCLCHK(rccl().CommCount(c->comm, &cnt));

@@ -1005,10 +1005,10 @@ template <typename VT, typename S>
 __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int nct, const S *src,
                                                 int64_t rows, int64_t cols, int64_t ld, int64_t row0,
                                                 int64_t col0, double scale, DevState *st,
-                                                const int64_t *row_idx = nullptr) {
+                                                const int64_t *row_idx = nullptr, double eps_s = 0.0, int zero_class = 0) {
     __shared__ double red[16];
     const int64_t total = rows * cols;
-    double sx = 0, cc = 0;
+    double sx = 0, cc = 0, ce = 0;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ii = e / cols, jj = e % cols;
@@ -1019,6 +1019,13 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
             atomicAdd(&st->v_overflow, 1);
         }
         const double xt = (double)xs;
+        // zero_class (fp16 storage of a problem whose loops may run the NE kernels: klnmf_set_problem): a zero is stored as the
+        // smallest positive number (2^-24 in storage units, ~1e-12 of the maximum) and the tile buffers are pre-filled with it
+        // -- the update pass that drops the numerator's eps (ratio x / (W.H + eps), NE in mfma4.hip.h) then never takes the
+        // logarithm of a zero ratio; every sum below sees the true zero
+        if constexpr (sizeof(VT) == 2) {
+            if (zero_class && xs == (VT)0) xs = __builtin_bit_cast(VT, (unsigned short)1);
+        }
         const int64_t row = row0 + ii, col = col0 + jj;
         const int64_t rt = row >> 5, ctile = col >> 5;
         const int i = row & 31, c = col & 31;
@@ -1030,12 +1037,15 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
         if (VtB) VtB[(ctile * nrt + rt) * 1024 + (eB / EPP) * (64 * EPP) + laneB * EPP + (eB % EPP)] = xs;      // only the recomputing column pass reads it
         sx += xt;
         cc += (xt > 0 && xv > 0) ? xt * log(xt / xv) - (xt - xv) : (xv - xt);
+        if (sizeof(VT) == 2 && xt > 0) ce += xt * log1p(eps_s / xt);
     }
     const double tsx = block_sum(sx, red);
     const double tcc = block_sum(cc, red);
+    const double tce = block_sum(ce, red);
     if (threadIdx.x == 0) {
         atomicAdd(&st->sum_x, tsx);
         atomicAdd(&st->corr_c, tcc);
+        if (sizeof(VT) == 2) atomicAdd(&st->corr_eps, tce);
     }
 }
 
@@ -1052,6 +1062,7 @@ struct LossArgs {
     double tol_abs;
     double *errors;
     int64_t cap;
+    int ne;                   // the partials come from an update pass without the numerator's eps: add DevState.corr_eps
 };
 // one block: fixed-order fp64 reduction of the row pass's loss partials, then (decide) the stop rule of nmf.py:214-220
 __device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const DevState *st, double *red) {
@@ -1080,7 +1091,7 @@ __device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const 
     const double ta = block_sum(a, red);
     const double tb = block_sum(b, red);
     if (threadIdx.x == 0) {
-        const double err = (kLn2 * ta + tb - st->sum_x - st->corr_c) * la.inv_c;
+        const double err = (kLn2 * ta + (la.ne ? st->corr_eps : 0.0) + tb - st->sum_x - st->corr_c) * la.inv_c;
         la.out[0] = err;
         la.out[1] = 0;
         if (la.decide) {
@@ -1098,10 +1109,10 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, i
                                                           const DevState *st, double inv_c,
                                                           double *out, int decide = 0, DevState *st_rw = nullptr,
                                                           double tol_abs = 0.0, double *errors = nullptr,
-                                                          int64_t cap = 0) {
+                                                          int64_t cap = 0, int ne = 0) {
     if (st->stop) return;
     __shared__ double red[16];
-    const LossArgs la{part, count, inv_c, out, decide, st_rw, tol_abs, errors, cap};
+    const LossArgs la{part, count, inv_c, out, decide, st_rw, tol_abs, errors, cap, ne};
     loss_from_parts_block(la, st, red);
 }
 
@@ -1111,7 +1122,7 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, i
 // C2 iteration, 15 % of one at the reference's own data sizes).  If the rule fires, this iteration's column pass has run
 // for nothing and k_update_pack_H (next on the stream) does not apply it.
 __global__ void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
-                                   const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0}) {
+                                   const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0}) {
     if (st && st->stop) return;
     if (la.part != nullptr && blockIdx.x == gridDim.x - 1) {
         __shared__ double red[16];

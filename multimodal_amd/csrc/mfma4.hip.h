@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // was (a runtime branch cost 2 % at the headline shape and spilled at KT = 16)
     static_assert(SPLIT == 0 || (NW == 8 && MODE == ROW_UPDATE), "column-split pass: 8-wave update kernels only");
     static_assert(Q8 == 0 || (MODE == ROW_UPDATE && sizeof(opnd_t) == 2), "fp8 ratio tiles: update kernels");
+    static_assert(Q8 >= 0 && Q8 <= 2, "Q8: 0 = 16-bit ratio tiles, 1 = fp8 tiles, 2 = fp8 tiles and the ratio without the numerator's eps (NE)");
     constexpr bool split = SPLIT != 0;
     const int ct0 = split ? (int)blockIdx.y * a.ct_chunk : 0;
     const int ct1 = split ? min(a.nct, ct0 + a.ct_chunk) : a.nct;
@@ -663,9 +664,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         if constexpr (VL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb));      // the two slot reads (nothing else of this wave is in flight in LDS)
         float q[16];
 #ifdef KL_NO_NUM_EPS
-        float zero_f = 0.f;
-        asm volatile("" : "+v"(zero_f));
+        constexpr bool NE = true;
+#else
+        constexpr bool NE = Q8 == 2;       // ratio x / (W.H + eps): the numerator's eps dropped (16 multiplications per tile), see below
 #endif
+        float zero_f = 0.f;
+        if constexpr (NE) asm volatile("" : "+v"(zero_f));      // (an opaque zero keeps the v_fma_mix form: x stays in its fp16 storage form)
 #if defined(KL_E_PIPE)     // experiment: the epilogue as a hand-ordered 3-stage software pipeline (rcp two elements ahead, ratio one
         // ahead, log of the current, loss term of the previous): every result is consumed at least four instructions after
         // the one that produces it; order pinned with empty asm statements
@@ -705,11 +709,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
                 // adds to the matrix time of the SIMD, every instruction counts
                 const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps came in through MFMA-1
-#ifdef KL_NO_NUM_EPS
-                q[e] = fmaf(x, rinv, zero_f);
-#else
-                q[e] = fmaf(x, rinv, eps * rinv);
-#endif
+                // NE (Q8 = 2; klnmf_api.hip chooses it per loop from the data's mean): the ratio as x * r.  Against the reference's
+                // (x + eps) * r that is a relative eps / x per element -- chosen only where eps / mean(V) <= 1e-5 (loss record within
+                // 1.5e-6, factors within 2.5e-5 of their maxima over 50 iterations: DESIGN.md section 8, h33) --, zeros are stored as
+                // 2^-24 (k_tile_V) so that no logarithm sees a zero ratio, and the loss gets the exact constant
+                // sum x ln(1 + eps/x) back (DevState.corr_eps).  Row pass -1.8 %, iteration -1.4 % at the headline shape.
+                if constexpr (NE) q[e] = fmaf(x, rinv, zero_f);
+                else q[e] = fmaf(x, rinv, eps * rinv);
 #ifdef KL_ABL_LOGD        // timing-only experiment: the loss term from log2(W.H) (independent of the reciprocal) -- the loss VALUE is then another sum
                 s1 = fmaf(x, __builtin_amdgcn_logf(EP ? d[e] : d[e] + eps), s1);
 #else

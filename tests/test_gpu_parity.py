@@ -625,6 +625,52 @@ def test_fp8_column_pass_agrees_with_f16_operands_and_oracle(monkeypatch, n, f, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k,iters,zero_frac', [(70000, 256, 200, 8, 0.3), (40000, 384, 40, 7, 0.0), (66000, 256, 72, 7, 0.6)])
+def test_ratio_without_the_numerator_eps_keeps_the_reference_results(monkeypatch, n, f, k, iters, zero_frac):
+    """Loops on fp8 ratio tiles over data whose mean is >= 1e5 eps form the ratio as x / (W.H + eps) (16 multiplications per
+    tile fewer; NE kernels, mfma4.hip.h) instead of the reference's (x + eps) / (W.H + eps) (nmf.py:332-336): a relative eps / x
+    per element.  Zeros are stored as 2^-24 (no logarithm of a zero ratio: the loss stays finite with 30-60 % exact zeros) and
+    the loss gets sum x ln(1 + eps/x) back exactly.  Against the same loop WITH the numerator's eps (KLNMF_NE=0): losses within
+    2e-6, factors within 1e-3 of their maxima (fp8 tiles on both sides); against the oracle: the usual 1e-4."""
+    X = orc.synthetic_V(21, n, f, min(k, 24))
+    if zero_frac > 0:
+        X = X.copy()
+        X[np.random.RandomState(5).rand(n, f) < zero_frac] = 0.0
+    H0 = orc.synthetic_H0(21, f, k)
+    out = {}
+    for ne in ('0', None):
+        monkeypatch.delenv('KLNMF_NE', raising=False)
+        if ne is not None:
+            monkeypatch.setenv('KLNMF_NE', ne)
+        m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+        out[ne] = (W, m.components_.copy(), np.asarray(errors), m.last_fp8_report)
+    a, b = out['0'], out[None]
+    assert not a[3]['no_numerator_eps'] and b[3]['no_numerator_eps'], (a[3], b[3])
+    assert b[3]['tile_iterations'] == iters - 2
+    assert len(a[2]) == len(b[2]) == iters and np.all(np.isfinite(b[2]))
+    assert_allclose(b[2], a[2], rtol=2e-6)
+    for i in (0, 1):
+        assert np.abs(b[i] - a[i]).max() <= 1e-3 * np.abs(a[i]).max()
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    assert_allclose(b[2], eo, rtol=1e-4)
+    assert abs(orc.kl_error(X, b[0].astype(np.float64), b[1].astype(np.float64)) / orc.kl_error(X, Wo, Ho) - 1) < 1e-4
+
+
+@pytest.mark.gpu
+def test_small_magnitude_data_keeps_the_numerator_eps():
+    """eps / mean(V) > 1e-5 (here data of magnitude 1e-4): the eps of the numerator is part of the result (it regularises the
+    ratio of small entries) -- such loops run the kernels with the reference's formula; klnmf_query says which ran."""
+    n, f, k, iters = 40000, 256, 40, 5
+    X = orc.synthetic_V(22, n, f, 24) * 1e-4
+    H0 = orc.synthetic_H0(22, f, k)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    rep = m.last_fp8_report
+    assert rep['allowed'] and rep['tile_iterations'] == iters - 2 and not rep['no_numerator_eps'], rep
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    assert_allclose(errors, eo, rtol=1e-4)
+
+
+@pytest.mark.gpu
 def test_rowpass_generations_agree_full_chip(monkeypatch):
     """Same comparison with enough row tiles to occupy every CU several times over
     (memory latencies under load are what exposed the ordering bugs of the counted-wait
