@@ -19,7 +19,7 @@ def short(name):
         mm = re.search(r'k_rowpass4?<([\d, ]+)>', name)
         if mm:
             a = [x.strip() for x in mm.group(1).split(',')]
-            base += '<KT=%s,odd=%s,mode=%s%s%s>' % (a[0], a[1], a[2], ',fp8 tiles' if len(a) > 6 and a[6] == '1' else '',
+            base += '<KT=%s,odd=%s,mode=%s%s%s>' % (a[0], a[1], a[2], ',fp8 tiles' if len(a) > 6 and a[6] in ('1', '2') else '',
                                                      ',column-split' if len(a) > 5 and a[5] == '1' else '')
         else:
             mm = re.search(r'k_rowpass4?ILi(\d+)ELi(\d+)ELi(\d+)', name)
