@@ -625,7 +625,8 @@ def test_fp8_column_pass_agrees_with_f16_operands_and_oracle(monkeypatch, n, f, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,f,k,iters,zero_frac', [(70000, 256, 200, 8, 0.3), (40000, 384, 40, 7, 0.0), (66000, 256, 72, 7, 0.6)])
+@pytest.mark.parametrize('n,f,k,iters,zero_frac', [(70000, 256, 200, 8, 0.3), (40000, 384, 40, 7, 0.0), (66000, 256, 72, 7, 0.6),
+                                                   (40000, 256, 64, 6, 0.2), (40000, 256, 50, 6, 0.0), (33000, 128, 224, 6, 0.1)])      # (every odd / eps-carrier variant of the NE kernels)
 def test_ratio_without_the_numerator_eps_keeps_the_reference_results(monkeypatch, n, f, k, iters, zero_frac):
     """Loops on fp8 ratio tiles over data whose mean is >= 1e5 eps form the ratio as x / (W.H + eps) (16 multiplications per
     tile fewer; NE kernels, mfma4.hip.h) instead of the reference's (x + eps) / (W.H + eps) (nmf.py:332-336): a relative eps / x
