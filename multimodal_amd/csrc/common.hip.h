@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Non-template kernels defined in these headers: external linkage in the library's main translation unit, internal (and
+// dropped as unused) in the translation units that only instantiate k_rowpass4 (rowpass4_inst_*.hip, built in parallel).
+#ifdef KL_INST_TU
+#define KL_GLOBAL static __global__
+#else
+#define KL_GLOBAL __global__
+#endif
+
 namespace klnmf {
 
 // eps of the ratio / loss: the reference hard-codes 1e-8 in _Q / error /
@@ -65,7 +73,7 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 }
 
 // The stop rule of nmf.py:214-220, one thread.
-__global__ void k_decide(DevState *st, const double *loss_xchg, double tol_abs,
+KL_GLOBAL void k_decide(DevState *st, const double *loss_xchg, double tol_abs,
                          double *errors, int64_t cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->stop) return;
@@ -79,7 +87,7 @@ __global__ void k_decide(DevState *st, const double *loss_xchg, double tol_abs,
     st->n_done += 1;
 }
 
-__global__ void k_reset_state(DevState *st) {
+KL_GLOBAL void k_reset_state(DevState *st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         st->prev_err = __longlong_as_double(0x7ff0000000000000LL);
         st->stop = 0;

@@ -22,6 +22,13 @@
 #include "sparse.hip.h"
 #include "mfma.hip.h"
 #include "mfma4.hip.h"
+#if defined(KL_SPLIT_TU) && !defined(KL_DEV_BUILD)
+// the k_rowpass4 instantiations live in rowpass4_inst_{1,2,3}.hip (built in parallel); here they are only declared
+#include "rowpass4_list.hip.h"
+namespace klnmf {
+KL_RP4_LIST_1(KL_RP4_DECLARE) KL_RP4_LIST_2(KL_RP4_DECLARE) KL_RP4_LIST_3(KL_RP4_DECLARE)
+}  // namespace klnmf
+#endif
 #include "colq.hip.h"
 #include "colq8x.hip.h"
 #include "probe.hip.h"

@@ -846,7 +846,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 // matrix product: row kc of the dictionary images holds eps in every column, column kc of the bf16 W
 // images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
 // loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
-__global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
+KL_GLOBAL __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
                                                        opnd_t *Ht4, opnd_t *HTb, double *hsum, float *tcur, float *t_hs,
                                                        const unsigned *wmax, int *op_range, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
@@ -940,14 +940,14 @@ __global__ __launch_bounds__(256) void k_update_pack_H(float *H32, const float *
 
 // Column maxima of a W master (all entries >= 0: the bit pattern of a non-negative float orders like the integer), for the
 // measured image scales k_update_pack_H derives from them.
-__global__ void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
+KL_GLOBAL void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= kp) return;
     float m = 0.f;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) m = fmaxf(m, W32[i * kp + c]);
     atomicMax(wmax + c, __float_as_uint(m));
 }
-__global__ void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *tcur) {
+KL_GLOBAL void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *tcur) {
     KL_FP16_SATURATE();
     const int64_t total = n * kp;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const 
         }
     }
 }
-__global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, int64_t count,
+KL_GLOBAL __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, int64_t count,
                                                           const DevState *st, double inv_c,
                                                           double *out, int decide = 0, DevState *st_rw = nullptr,
                                                           double tol_abs = 0.0, double *errors = nullptr,
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, i
 // this launch instead of one of its own between the two passes (a launch + a dependent boundary per iteration: 2 % of a
 // C2 iteration, 15 % of one at the reference's own data sizes).  If the rule fires, this iteration's column pass has run
 // for nothing and k_update_pack_H (next on the stream) does not apply it.
-__global__ void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
+KL_GLOBAL void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
                                    const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0}) {
     if (st && st->stop) return;
     if (la.part != nullptr && blockIdx.x == gridDim.x - 1) {

@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 
 // W rule of the column-split update pass: G = sum over the chunks' slabs, W_new = W_old * G (fp32 master + swizzled bf16
 // image with the eps carrier column, exactly as the tail of k_rowpass4 writes them).  One thread per 4 components.
-__global__ __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nchunk, int64_t slab, const float *W32_old,
+KL_GLOBAL __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nchunk, int64_t slab, const float *W32_old,
                                                      float *W32_new, opnd_t *Wb_new, int64_t rows, int kp, int wld, int kc,
                                                      const DevState *st, const float *tcur, const float *tnext) {
     if (st->stop) return;

@@ -1,0 +1,9 @@
+// Explicit instantiations of k_rowpass4, part 1 of 3 (rowpass4_list.hip.h): compiled in parallel with klnmf_api.hip
+// (-DKL_SPLIT_TU) and linked into libklnmf.so by __graft_entry__.build() / scripts/build_lib.py.
+#define KL_INST_TU
+#include "mfma4.hip.h"
+#include "rowpass4_list.hip.h"
+
+namespace klnmf {
+KL_RP4_LIST_1(KL_RP4_DEFINE)
+}  // namespace klnmf
