@@ -811,7 +811,11 @@ void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false, const uns
     // ping-pong row pass + stored-ratio column pass read only the Ht4 tile images (KLNMF_ROWPASS / KLNMF_COLPASS are read
     // once, in klnmf_set_problem, so the choice cannot change under a context)
     const bool lean = c->pingpong() && c->Qt != nullptr;
-    hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(256), 0, c->stream, c->H32,
+    // one block per component row; its three passes over the row are a chain of memory round trips, so a long row gets more
+    // threads (fewer elements per thread and pass): KLNMF_HRULE_THREADS overrides
+    int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
+    if (const char *g = std::getenv("KLNMF_HRULE_THREADS")) hthreads = std::min(1024, std::max(64, (std::atoi(g) / 64) * 64));
+    hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(hthreads), 0, c->stream, c->H32,
                        (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (opnd_t *)nullptr : c->Ht, c->Ht4,
                        lean ? (opnd_t *)nullptr : c->HTb, c->hsum, c->tcur, c->t_hs, wmax, &c->st->op_range, c->f, c->f_pad,
                        c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,

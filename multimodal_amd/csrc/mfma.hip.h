@@ -846,7 +846,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
 // matrix product: row kc of the dictionary images holds eps in every column, column kc of the bf16 W
 // images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
 // loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
-KL_GLOBAL __launch_bounds__(256) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
+KL_GLOBAL __launch_bounds__(1024) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
                                                        opnd_t *Ht4, opnd_t *HTb, double *hsum, float *tcur, float *t_hs,
                                                        const unsigned *wmax, int *op_range, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
