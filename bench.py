@@ -39,7 +39,8 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_FP8_TFLOPS = 5000.0
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r03_pmc_traffic.json'), os.path.join('profiles', 'r02_pmc_traffic.json')]
+PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r04_pmc_traffic.json'), os.path.join('profiles', 'r03_pmc_traffic.json'),
+                     os.path.join('profiles', 'r02_pmc_traffic.json')]
 
 
 def kernel_source_hash():
@@ -142,12 +143,13 @@ def parse_args(argv=None):
     p.add_argument('--precision', default='f16', choices=['f16', 'f16_v32', 'bf16', 'bf16_v32', 'f32', 'f64'],
                    help="f16: fp16 MFMA operands (scaled images), fp32 accumulate; 'bf16' is the round-1 name of the same mode")
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-rows', type=int, default=65536,
-                   help='rows of the same V the CPU baseline is timed on (BASELINE.md 3); 65 536 = the smallest context that '
-                        'runs fp8 ratio tiles, so the parity leg on the same sample exercises them')
-    p.add_argument('--cpu-iters', type=int, default=7,
-                   help='timed CPU iterations after one warm-up; the parity leg runs the same 1 + N iterations on the GPU '
-                        '(8 by default: 6 of them on fp8 ratio tiles)')
+    p.add_argument('--cpu-rows', type=int, default=100000,
+                   help='rows of the same V the CPU baseline is timed on (SURVEY 8d: n = 100 000 at the same f, k, scaled '
+                        'linearly in n); more than 65 536, so the parity leg on the same sample runs fp8 ratio tiles and the '
+                        'fp8 x fp8 column pass')
+    p.add_argument('--cpu-iters', type=int, default=5,
+                   help='timed CPU iterations after one warm-up (about 25 s of fp64 work at the default sample); the parity leg '
+                        'runs the same 1 + N iterations on the GPU (6 by default: 4 of them on fp8 ratio tiles)')
     p.add_argument('--no-16bit-segment', action='store_true',
                    help='skip the extra segment that measures value_16bit (16-bit ratio tiles, f16 column pass)')
     p.add_argument('--segment-timeout', type=float, default=float(os.environ.get('KLNMF_BENCH_SEGMENT_TIMEOUT', '300')),
@@ -232,6 +234,22 @@ def measured_traffic(args, n_local):
     return None, None, None, None
 
 
+def measured_clock(args, n_local):
+    """Shader clock the dominant kernel held in the committed PMC pass of this workload: GRBM_GUI_ACTIVE / 8 / duration (MHz)."""
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, name)))
+        except Exception:
+            continue
+        for entry in d.get('workloads', []):
+            w = entry.get('workload', {})
+            if (w.get('n_local'), w.get('f'), w.get('k'), w.get('precision')) == (n_local, args.f, args.k, args.precision.replace('bf16', 'f16')):
+                for kname, v in entry.get('kernels', {}).items():
+                    if 'k_rowpass' in kname and 'column-split' not in kname and v.get('sclk_mhz_from_grbm_gui_active'):
+                        return v['sclk_mhz_from_grbm_gui_active']
+    return None
+
+
 def host_info():
     info = {'cpu_model': platform.processor() or 'unknown', 'numpy': np.__version__}
     try:
@@ -267,6 +285,15 @@ def cpu_baseline(args):
     from oracle import klnmf_oracle as orc
     from multimodal_amd import synthetic
     host = host_info()
+    # BLAS threads: all the library allows.  The numpy wheel's OpenBLAS is BUILT for at most 64 threads (NUM_THREADS=64): on the
+    # GPU box's 2 x 64-core host that is half the physical cores -- said in the line (`blas_threads_note`), not hidden.
+    physical = host.get('cores')
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or physical
+    except Exception:
+        pass
+    blas_threads = max([t.get('num_threads', 0) for t in (host.get('blas') or [])] + [0]) or None
     rows, f, k = min(args.cpu_rows, args.n), args.f, args.k
     # the faithful restatement holds ~6 n x f float64 arrays: shrink the sample rather than risk the box
     need_gb = 7 * rows * f * 8 / 1e9
@@ -296,7 +323,12 @@ def cpu_baseline(args):
     base = {
         'value': (1.0 / per_iter) * rows / args.n,
         'unit': 'it/s',
-        'cores': host.get('cores'),
+        'cores': blas_threads or host.get('cores'),
+        'cores_what': 'BLAS threads the timed run used (numpy element-wise passes: 1 thread); the host shows %s hardware threads, '
+                      '%s physical cores' % (host.get('cores'), physical),
+        'blas_threads_note': (None if not blas_threads or not physical or blas_threads >= physical else
+                              'OpenBLAS of this numpy build caps at %d threads (its compile-time NUM_THREADS); the host has %d '
+                              'physical cores' % (blas_threads, physical)),
         'kind': 'port',
         'sample': 'rows [0, %d) of the same seeded %d x %d V, k=%d: 1 warm-up + %d timed fp64 iterations of the numpy '
                   'restatement of nmf.py:212-222 (median %.2f s/iteration on the sample), scaled linearly in n (extrapolated)'
@@ -461,6 +493,7 @@ def main():
             'what': 'one extra segment of the same run with KLNMF_QTILE=16: 16-bit (fp16) ratio tiles and f16 operands in '
                     'every product, no e4m3 anywhere',
             'row_pass_ms': prof16['rowpass_ms'] / max(1, prof16['rowpass_launches']),
+            'tail_ms': (prof16['tail_ms'] / prof16['tail_launches']) if prof16['tail_launches'] else 0.0,
             'col_pass_ms': prof16['colpass_ms'] / max(1, prof16['colpass_launches']),
             'fp8_tile_iterations': fp8_16['tile_iterations'],
             'valid': all(nd == iters_per_fit and not st for _, nd, st in fits16)}
@@ -537,10 +570,29 @@ def main():
                            'frac': (row_gbs / PEAK_HBM_GBS if mfma_bound else row_tflops / PEAK_BF16_TFLOPS) if row_s > 0 else None},
             'schedule_hbm_gbs': sched_bytes_row / row_s / 1e9 if row_s > 0 else None,
         }
+        # `frac` divides by the nominal peak (2.4 GHz) and is the contract's number.  Informative, and kept OUT of `roofline`: the
+        # same kernel against the MFMA peak at the clock the card held under its power limit -- (a) from the committed PMC pass of
+        # this workload (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration: an in-run cycle count, what the microarchitecture guide
+        # accepts), (b) from rocm-smi samples taken during the timed segments (sysfs clocks read up to 10 % high)
+        held = {'nominal_sclk_mhz': PowerClockSampler.NOMINAL_MHZ}
+        pmc_mhz = measured_clock(args, n_local)
+        if pmc_mhz and mfma_bound and roofline['frac']:
+            held['sclk_mhz_from_pmc_GRBM_GUI_ACTIVE'] = pmc_mhz
+            held['row_pass_frac_at_pmc_clock'] = roofline['frac'] * PowerClockSampler.NOMINAL_MHZ / pmc_mhz
         if power_clock and mfma_bound and roofline['frac']:
-            # `frac` divides by the nominal peak (2.4 GHz); this is the same kernel against the MFMA peak at the clock the card
-            # actually held under its power limit during the timed segments (informative; the contract's number is `frac`)
-            roofline['frac_at_held_clock'] = roofline['frac'] * PowerClockSampler.NOMINAL_MHZ / power_clock['sclk_mhz_median']
+            held['sclk_mhz_rocm_smi_median'] = power_clock['sclk_mhz_median']
+            held['rocm_smi_samples'] = power_clock['samples_used']
+            held['row_pass_frac_at_rocm_smi_clock'] = roofline['frac'] * PowerClockSampler.NOMINAL_MHZ / power_clock['sclk_mhz_median']
+        if value_16bit is not None and value_16bit.get('row_pass_ms'):
+            # the all-16-bit run's own roofline entry (its whole-row launch writes 2 B instead of 1 B per element of V and keeps
+            # the numerator's eps): the figure that goes with `value_16bit`
+            r16 = value_16bit['row_pass_ms'] - (value_16bit.get('tail_ms') or 0.0)
+            value_16bit['roofline'] = {'bound': 'mfma' if mfma_bound else 'hbm', 'avg_launch_ms': r16, 'rows_per_launch': n_row,
+                                       'achieved': (flops_row / (r16 * 1e-3) / 1e12) if mfma_bound else (alg_bytes_row / (r16 * 1e-3) / 1e9),
+                                       'peak': PEAK_BF16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+                                       'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+                                       'frac': ((flops_row / (r16 * 1e-3) / 1e12) / PEAK_BF16_TFLOPS) if mfma_bound
+                                               else ((alg_bytes_row / (r16 * 1e-3) / 1e9) / PEAK_HBM_GBS)}
         errors, n_done, stopped = fits[-1]
         all_full = all(nd == iters_per_fit and not st for _, nd, st in fits)
         out = {
@@ -601,6 +653,7 @@ def main():
             'device': info,
             'roofline': roofline,
             'power_clock': power_clock,
+            'held_clock': held,
             'kernels': {
                 'row_pass_section': {
                     'what': ('whole-row k_rowpass4 over %d rows (the roofline entry) + column-split k_rowpass4 over the last %d '

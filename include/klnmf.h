@@ -187,14 +187,29 @@ int klnmf_run_sharded(klnmf_ctx *ctx, int64_t n_total, int64_t max_iter, int fit
                       double *errors_out, int64_t *n_done, int *stopped);
 
 /* Device pointers of the two exchange buffers (what the collective sums):
- * loss: 2 doubles; numerator: *numer_count elements of fp32 (BF16 modes, F32)
- * or fp64 (F64).  The buffers are owned by the context. */
+ * loss: 2 doubles ([0] the loss partial, [1] this rank's count of fp8 ratio entries beyond the exact fix-up's list: the
+ * summed value tells every rank when a loop gives fp8 tiles up); numerator: *numer_count elements of fp32 (BF16 modes,
+ * F32) or fp64 (F64).  The buffers are owned by the context. */
 int klnmf_exchange_buffers(klnmf_ctx *ctx, void **loss_ptr, void **numer_ptr,
                            int64_t *numer_count, int *numer_is_f64);
 /* Layout of the numerator buffer: component rows of *row_stride elements, of which the first k rows
  * (*valid_count elements from the start) carry data -- what a collective has to move; the rest is padding. */
 int klnmf_exchange_layout(klnmf_ctx *ctx, int64_t *row_stride, int64_t *valid_count);
-/* Use caller-owned device buffers as the exchange buffers instead (e.g. torch
+/* Column-range form of the numerator exchange (round 4): with KLNMF_COMM_PARTS = P > 1 (read by klnmf_set_problem; 16-bit
+ * modes, fused tail) the H numerator of nmf.py:349 can be produced and exchanged in P column parts, so that the all-reduce of
+ * part p runs while the column pass of part p + 1 computes.  Part p = columns [col0[p], col0[p] + ncols[p]) of all k
+ * components, stored as ONE contiguous block of counts[p] = k x (padded part width) elements at element offset offsets[p]
+ * of the numerator buffer (klnmf_exchange_buffers: *numer_count covers this layout too).  Arrays of KLNMF_MAX_PARTS entries;
+ * *nparts = 1 when the problem is not split: the one part is the whole-matrix layout of klnmf_exchange_layout.
+ *   per iteration:  klnmf_iter_rowpass | for p in 0 .. P-1: klnmf_iter_colpass_part(p) -> [all-reduce part p] |
+ *                   klnmf_iter_decide | klnmf_iter_update_H (applies the parts) | klnmf_iter_advance
+ * klnmf_run_sharded / klnmf_run_more on a communicator do the same natively (part all-reduces on a second stream). */
+#define KLNMF_MAX_PARTS 4
+int klnmf_exchange_parts(klnmf_ctx *ctx, int *nparts, int64_t *offsets, int64_t *counts, int64_t *col0, int64_t *ncols);
+int klnmf_iter_colpass_part(klnmf_ctx *ctx, int part);
+/* (Round 4: the collective of the native path -- klnmf_run_sharded -- is issued INSIDE the library; these entry points serve
+ * callers that sequence the loop's pieces around their own collective, e.g. torch.distributed.)
+ * Use caller-owned device buffers as the exchange buffers instead (e.g. torch
  * tensors handed to torch.distributed.all_reduce): loss_ptr >= 2 doubles,
  * numer_ptr >= numer_count elements.  NULL keeps the current buffer. */
 int klnmf_bind_exchange(klnmf_ctx *ctx, void *loss_ptr, void *numer_ptr);
@@ -275,7 +290,7 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
 #define KLNMF_Q_RATIO_UNFIXED     8
 /*   KLNMF_Q_NO_NUM_EPS       1 if that loop's update passes on fp8 tiles formed the ratio as x / (W.H + eps) instead of the
  *                            reference's (x + eps) / (W.H + eps) (nmf.py:332-336): taken at the loop's entry where eps / mean(V)
- *                            <= 1e-5 (k <= 224), zeros stored as 2^-24, the loss corrected exactly; KLNMF_NE=0 turns it off */
+ *                            <= 1e-5 (k <= 224), V keeps true zeros (2^-100 addend in the ratio), the loss corrected exactly; KLNMF_NE=0 turns it off */
 #define KLNMF_Q_NO_NUM_EPS        9
 int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 /*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */

@@ -60,6 +60,9 @@ SIGNATURES = {
     'klnmf_iter_rowpass': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_iter_decide': (_c.c_int, [_ctx_p, _c.c_double]),
     'klnmf_iter_colpass': (_c.c_int, [_ctx_p]),
+    'klnmf_iter_colpass_part': (_c.c_int, [_ctx_p, _c.c_int]),
+    'klnmf_exchange_parts': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_int), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64),
+                                        _c.POINTER(_i64)]),
     'klnmf_iter_update_H': (_c.c_int, [_ctx_p]),
     'klnmf_iter_advance': (_c.c_int, [_ctx_p]),
     'klnmf_loop_end': (_c.c_int, [_ctx_p, _c.POINTER(_c.c_double), _c.POINTER(_i64),
@@ -256,6 +259,8 @@ class Context(object):
         if isinstance(precision, str):
             precision = PRECISIONS[precision]
         self.precision = precision
+        # the mode's canonical name (what device_data picks the fp32 / fp64 source copies by)
+        self.precision_name = {PREC_F64: 'f64', PREC_F32: 'f32', PREC_BF16: 'f16', PREC_BF16_V32: 'f16_v32'}[precision]
         self.n = self.f = self.k = 0
         self.cap = 0
         self._pool_key = (precision, int(device)) if (pooled and stream is None and os.environ.get('KLNMF_NO_POOL') != '1') else None
@@ -491,6 +496,20 @@ class Context(object):
 
     def iter_colpass(self):
         _check(self._lib.klnmf_iter_colpass(self._h))
+
+    def iter_colpass_part(self, part):
+        """Column pass + numerator of ONE column part of the split layout (`exchange_parts`): the caller exchanges the part
+        while the next one computes."""
+        _check(self._lib.klnmf_iter_colpass_part(self._h, int(part)))
+
+    def exchange_parts(self):
+        """[(element offset, element count, first column, columns)] of the numerator's column parts (one whole-matrix part
+        unless KLNMF_COMM_PARTS split the problem)."""
+        n = _c.c_int(0)
+        arr = lambda: (_i64 * 4)()
+        off, cnt, c0, nc = arr(), arr(), arr(), arr()
+        _check(self._lib.klnmf_exchange_parts(self._h, ctypes.byref(n), off, cnt, c0, nc))
+        return [(int(off[p]), int(cnt[p]), int(c0[p]), int(nc[p])) for p in range(n.value)]
 
     def iter_update_H(self):
         _check(self._lib.klnmf_iter_update_H(self._h))

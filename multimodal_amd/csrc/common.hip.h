@@ -42,8 +42,11 @@ struct DevState {
     int q8_sat_total;  // ratio-tile entries found saturated (ratio > 3584) by the column passes, over the loop
     int q8_list_n;     // entries appended to the fix-up list in this iteration (k_q8_fixup recomputes them exactly and resets it)
     int q8_unfixed;    // saturated ratio entries beyond the list's capacity: their excess over 3584 is missing from an H numerator
-    int q8_fix_done;   // blocks of the running k_q8_fixup launch that have finished (the last one resets the list)
+    int q8_fix_done;   // blocks of the running fix-up launch that have finished (the last one resets the list)
     int pad_;
+    // prev_error as a two-entry ring for stop rules evaluated inside a multi-block launch (post.hip.h): iteration `it` reads
+    // prev2[(it - 1) & 1] -- which no block of its launch writes -- and records its loss in prev2[it & 1]
+    double prev2[2];
 };
 constexpr int kQ8ListCap = 8192;      // (row, column) pairs of saturated ratio entries per iteration that are corrected exactly
 
@@ -83,6 +86,7 @@ KL_GLOBAL void k_decide(DevState *st, const double *loss_xchg, double tol_abs,
         return;
     }
     st->prev_err = err;
+    st->prev2[0] = err; st->prev2[1] = err;
     if (st->n_done < cap) errors[st->n_done] = err;
     st->n_done += 1;
 }
@@ -90,6 +94,7 @@ KL_GLOBAL void k_decide(DevState *st, const double *loss_xchg, double tol_abs,
 KL_GLOBAL void k_reset_state(DevState *st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         st->prev_err = __longlong_as_double(0x7ff0000000000000LL);
+        st->prev2[0] = st->prev_err; st->prev2[1] = st->prev_err;
         st->stop = 0;
         st->n_done = 0;
         st->w8_sat = 0; st->w8_sat_total = 0; st->w8_fallbacks = 0;

@@ -31,6 +31,7 @@ KL_RP4_LIST_1(KL_RP4_DECLARE) KL_RP4_LIST_2(KL_RP4_DECLARE) KL_RP4_LIST_3(KL_RP4
 #endif
 #include "colq.hip.h"
 #include "colq8x.hip.h"
+#include "post.hip.h"
 #include "probe.hip.h"
 
 using namespace klnmf;
@@ -248,7 +249,7 @@ struct klnmf_ctx {
     // what the last loop actually ran (klnmf_query): iterations whose ratio tiles were fp8, whose column pass was fp8 x fp8
     int64_t stat_q8_tiles = 0, stat_col8 = 0;
     uint2 *q8_list = nullptr;                 // [kQ8ListCap] saturated ratio entries of the current iteration (colq.hip.h)
-    bool zero_class = false;                  // fp16 V tiles hold 2^-24 where the data (and the padding) is zero: problems whose loops may run NE kernels
+    bool ne_ok = false;                       // the problem's shape has NE kernels (fp16 V, k <= 224, enough rows for fp8 ratio tiles)
     bool ne_loop = false;                     // this loop's fp8-tile update passes drop the numerator's eps (NE kernels; begin_fp8_loop)
     bool last_row_ne = false;                 // ... and the update pass just launched was one of them (its loss needs DevState.corr_eps)
     bool in_capture = false;                  // a hipGraph capture is recording this context's launches (no synchronising polls)
@@ -268,6 +269,25 @@ struct klnmf_ctx {
     float *W32[2] = {nullptr, nullptr};
     opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
+    // ---- one launch behind the column pass (post.hip.h; KLNMF_FUSE=0: the separate launches of rounds 1-3) ----
+    bool fused = false;                       // this problem runs k_post (ping-pong row pass + stored-ratio column pass)
+    float *H32alt = nullptr;                  // the dictionary master is ping-pong there: k_post reads H32, writes H32alt, then they swap
+    int64_t loop_hswaps = 0;                  // H rules enqueued since the loop's entry (how many the device executed: n_done -- fetch_results)
+    float *loop_h0 = nullptr, *loop_h1 = nullptr;      // H32 / H32alt as the loop found them
+    unsigned *w8tab = nullptr;                // [kW8TabRows][KP] maxima of the conversion kernel (k_post: -> w8s_next, emptied)
+    float *w8s_next = nullptr;                // [KP] scales the NEXT conversion uses
+    bool conv_ran = false;                    // this iteration's conversion ran: k_post derives the next scales
+
+    // Column parts of the H numerator.  `whole`: all columns as one part (layout [KP][f_pad], what every single-context loop
+    // and the exchange API use).  `parts[0 .. nparts_cfg)`: the split layout of loops on a communicator -- part p = a range of
+    // column blocks with its own slabs [nchunks][KP][ld] and numerator [KP][ld] (contiguous: one ncclAllReduce each), so that
+    // the all-reduce of part p overlaps the column pass of part p + 1 (KLNMF_COMM_PARTS, default 1 = no split)
+    struct PartCfg { int cb0, ncb, ct0, nct, col0, ncols, ld, nchunks, spc; int64_t numer_off, slab_off; };
+    PartCfg whole{}, parts[kPostMaxParts]{};
+    int nparts_cfg = 1;
+    bool piece_split = false, piece_use8 = false;      // loop in pieces: the numerator was produced in parts (klnmf_iter_colpass_part)
+    hipStream_t comm_stream = nullptr;        // all-reduces of the parts before the last one (overlap)
+    hipEvent_t ev_part[kPostMaxParts] = {}, ev_ar[kPostMaxParts] = {};
     opnd_t *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
     int row_gen = 4;
     int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
@@ -348,6 +368,11 @@ void use(klnmf_ctx *c) {
 }
 void comm_release(klnmf_ctx *c) {
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    for (int p = 0; p < kPostMaxParts; ++p) {
+        if (c->ev_part[p]) { (void)hipEventDestroy(c->ev_part[p]); c->ev_part[p] = nullptr; }
+        if (c->ev_ar[p]) { (void)hipEventDestroy(c->ev_ar[p]); c->ev_ar[p] = nullptr; }
+    }
     if (c->comm_scratch) { (void)hipFree(c->comm_scratch); c->comm_scratch = nullptr; }
     c->comm_rank = 0; c->comm_size = 1;
 }
@@ -782,6 +807,152 @@ void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
     q8_fixup();
 }
 
+// ---- the fused iteration tail (post.hip.h): column pass of one column part, then k_post -----------------------------------
+ColPassQArgs colq_part_args(klnmf_ctx *c, const klnmf_ctx::PartCfg &p) {
+    ColPassQArgs a{};
+    a.Qt = c->Qt + (int64_t)p.ct0 * c->nrt * (c->q8() ? kQTile8 : kQTile);
+    a.Wb_new = c->Wb[c->cur ^ 1];
+    a.Npart = c->NpartF + p.slab_off;
+    a.st = c->st;
+    a.nrt = c->nrt;
+    a.nct = p.nct;
+    a.ncb = p.ncb;
+    a.nchunks = p.nchunks;
+    a.stages_per_chunk = p.spc;
+    a.f_pad = p.ld;
+    a.guard = 0;
+    a.st_rw = c->st;
+    a.q8_list = c->q8() ? c->q8_list : nullptr;
+    return a;
+}
+
+// the e4m3 image of W_new for this iteration's fp8 x fp8 column pass (once per iteration, before the first part's pass):
+// converted with the scales k_post derived from the PREVIOUS conversion's maxima; returns whether the fp8 x fp8 pass may run
+bool fused_w8_stage(klnmf_ctx *c) {
+    c->conv_ran = false;
+    if (!c->W8 || !c->q8_loop) return false;
+    const bool measure_only = c->iter_in_loop == 1 && !c->w8_meas;      // the loop's second iteration (16-bit tiles still)
+    if (!measure_only && !c->q8()) return false;
+    const bool use8 = !measure_only && c->w8_meas;
+    const int groups = c->KP / 8, rpb = std::max(1, 256 / groups);
+    const int64_t rows = c->n_pad;
+    const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
+    hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
+                       c->KP, (int)w_ld(c->KP), (const float *)c->w8s_next, (unsigned *)nullptr, (const DevState *)c->st,
+                       &c->st->w8_sat, w8_probe_col(c), c->w8tab, c->w8s);
+    HIPCHK(hipGetLastError());
+    c->w8_meas = true;
+    c->conv_ran = true;
+    return use8;
+}
+
+void fused_colpass_part(klnmf_ctx *c, const klnmf_ctx::PartCfg &p, bool use8) {
+    ColPassQArgs a = colq_part_args(c, p);
+    const int grid = p.ncb * p.nchunks;
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_col);
+    auto launch_q2 = [&](const ColPassQArgs &g, bool fp8_tiles) {
+        switch (c->KT) {
+#define KL_PQ2(KTV) case KTV:                                                                                                    \
+            if (fp8_tiles) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ8_NB, 1, 1, KL_COLQ8_PAIR>), dim3(grid), dim3(kThreads), 0, c->stream, g); \
+            else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, g);                \
+            break;
+#define KL_PQ2_BIG(KTV) case KTV:                                                                                                \
+            if (fp8_tiles) hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, g);      \
+            else hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, g);                      \
+            break;
+#ifdef KL_DEV_BUILD
+            KL_PQ2(7) KL_PQ2_BIG(16)
+#else
+            KL_PQ2(1) KL_PQ2(2) KL_PQ2(3) KL_PQ2(4) KL_PQ2(5) KL_PQ2(6) KL_PQ2(7)
+            KL_PQ2_BIG(8) KL_PQ2_BIG(10) KL_PQ2_BIG(12) KL_PQ2_BIG(14) KL_PQ2_BIG(16)
+#endif
+#undef KL_PQ2
+#undef KL_PQ2_BIG
+            default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: k <= 224 or 256 < k <= 512");
+        }
+        HIPCHK(hipGetLastError());
+    };
+    if (use8) {
+        a.guard = 1;                       // returns at once if this iteration's e4m3 image clipped; the f16-operand pass behind runs then
+        ColPass8Args a8{a, c->W8, c->w8s, w8_probe_col(c) >= 0 ? 1 : 0};
+        if (c->KT == 8 && !c->big) fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: KT = 8 only on the component-split path");
+        switch (c->KT) {
+#define KL_PQ8X(KTV, NBV, KSV) case KTV:                                                                                          \
+            if (a8.probe) hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a8);     \
+            else hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a8);              \
+            break;
+#ifdef KL_DEV_BUILD
+            KL_PQ8X(7, KL_COL8_NB, 1) KL_PQ8X(16, 3, 2)
+#else
+            KL_PQ8X(1, KL_COL8_NB, 1) KL_PQ8X(2, KL_COL8_NB, 1) KL_PQ8X(3, KL_COL8_NB, 1) KL_PQ8X(4, KL_COL8_NB, 1)
+            KL_PQ8X(5, KL_COL8_NB, 1) KL_PQ8X(6, KL_COL8_NB, 1) KL_PQ8X(7, KL_COL8_NB, 1)
+            KL_PQ8X(8, 3, 2) KL_PQ8X(10, 3, 2) KL_PQ8X(12, 3, 2) KL_PQ8X(14, 3, 2) KL_PQ8X(16, 3, 2)
+#endif
+#undef KL_PQ8X
+            default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: k <= 224 or 256 < k <= 512");
+        }
+        HIPCHK(hipGetLastError());
+        ColPassQArgs g = a;
+        g.guard = 2;
+        launch_q2(g, true);
+    } else {
+        launch_q2(a, c->q8());
+    }
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+}
+
+enum PostMode { POST_FULL = 0, POST_SUM = 1, POST_RULE = 2 };
+// POST_FULL: everything behind the column pass of a single-context fit iteration (`la`: the row pass's loss partials and the
+// stop rule's tolerance); POST_SUM: slabs -> numerator of ONE part (+ fix-ups; `la.part` set: one extra block leaves the loss
+// in loss_xchg); POST_RULE: the H rule on the numerator as it stands (decide: with the stop rule on loss_xchg[0])
+void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, int nparts, const LossArgs &la, bool decide,
+                 bool use8, bool last_sum) {
+    PostArgs a{};
+    a.nparts = nparts;
+    for (int p = 0; p < nparts; ++p) {
+        const klnmf_ctx::PartCfg &q = parts[p];
+        a.part[p] = PostPart{c->NpartF + q.slab_off, c->numerF + q.numer_off, (int64_t)c->KP * q.ld, q.ld, q.col0, q.ncols,
+                             q.nchunks, q.ct0};
+    }
+    a.do_sum = mode != POST_RULE;
+    a.do_rule = mode != POST_SUM;
+    a.do_decide = decide ? 1 : 0;
+    a.loss_from_parts = (mode == POST_FULL && la.part != nullptr) ? 1 : 0;
+    a.loss_block = (mode == POST_SUM && la.part != nullptr) ? 1 : 0;
+    a.w8_block = (a.do_sum && last_sum && c->conv_ran && c->w8tab != nullptr) ? 1 : 0;
+    a.last_sum = (a.do_sum && last_sum) ? 1 : 0;
+    a.it = (int)(c->iter_in_loop & 1);
+    a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne;
+    a.tol_abs = la.tol_abs; a.errors = c->errors; a.cap = c->cap;
+    a.st = c->st;
+    a.H_old = c->H32; a.H_new = c->H32alt;
+    a.Ht4 = c->Ht4; a.hsum = c->hsum; a.tcur = c->tcur; a.t_hs = c->t_hs;
+    a.f = c->f; a.f_pad = c->f_pad; a.kp = c->KP; a.k = (int)c->k; a.kc = c->kc;
+    a.eps_pad = (float)(kEpsRatio * c->v_scale);
+    const bool fix = a.do_sum && c->q8() && c->q8_list != nullptr &&
+                     !(std::getenv("KLNMF_Q8_FIXUP") && std::atoi(std::getenv("KLNMF_Q8_FIXUP")) == 0);      // (tests: the control run)
+    a.list = fix ? c->q8_list : nullptr;
+    a.Qt = c->Qt; a.VtA = (const _Float16 *)c->VtA; a.W32_old = c->W32[c->cur]; a.Wb_new = c->Wb[c->cur ^ 1];
+    a.W8 = use8 ? c->W8 : nullptr; a.w8s = c->w8s; a.w8ld = (int)w8_ld(c->KP); a.wld = (int)w_ld(c->KP);
+    a.nrt = c->nrt; a.nct = c->nct; a.stages_per_chunk = nparts == 1 ? parts[0].spc : 0; a.eps = (float)(kEpsRatio * c->v_scale);
+    a.w8tab = c->w8tab; a.w8s_next = c->w8s_next;
+    if (a.do_sum && !fix && c->q8() && c->q8_list != nullptr)      // fix-ups switched off: the list must still be emptied
+        HIPCHK(hipMemsetAsync(&c->st->q8_list_n, 0, sizeof(int), c->stream));
+    // one block per component row, one float4 per thread and trip: 1024 threads for rows of 4096 columns and more
+    int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
+    if (const char *g = std::getenv("KLNMF_HRULE_THREADS")) hthreads = std::min(1024, std::max(64, (std::atoi(g) / 64) * 64));
+    const int blocks = (int)c->k + a.w8_block + a.loss_block;
+    hipLaunchKernelGGL(k_post, dim3((unsigned)blocks), dim3(hthreads), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    if (a.do_rule) {
+        std::swap(c->H32, c->H32alt);
+        c->loop_hswaps += 1;
+        c->images_measured = false;
+    }
+    if (a.w8_block) c->conv_ran = false;
+}
+
 void fast_colpass(klnmf_ctx *c) {
     if (c->Qt) { fast_colpass_q(c); return; }
     ColPassArgs a{};
@@ -850,10 +1021,20 @@ void measure_and_pack(klnmf_ctx *c) {
 // loop's entry normally excludes such matrices): the loop gives the tiles up for its remaining iterations.  Polled at fp8
 // iterations 1, 2, 4, 8 and then every 16th (one DevState read-back each) -- bulk saturation is a property of the data and
 // the first updates, not something that develops late.
-void poll_fp8_overflow(klnmf_ctx *c) {
+// Row shards: every rank must drop the tiles in the SAME iteration (they would run different kernels otherwise, and the
+// replicas of H would drift apart): the count travels as the second double of the loss exchange -- every loss launch leaves
+// this rank's q8_unfixed in loss_xchg[1], the all-reduce (native or torch) sums it -- and `agreed` polls read that sum.
+void poll_fp8_overflow(klnmf_ctx *c, bool agreed = false) {
     if (!c->q8_loop || !c->q8() || c->in_capture) return;
     const int64_t n8 = c->stat_q8_tiles;
     if (!(n8 == 1 || n8 == 2 || n8 == 4 || n8 == 8 || (n8 & 15) == 0)) return;
+    if (agreed) {
+        double h[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(h, c->loss_xchg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (h[1] > 0) c->q8_loop = false;
+        return;
+    }
     DevState hs{};
     HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -988,13 +1169,11 @@ void exact_H(klnmf_ctx *c) {
     } while (0)
 
 // ------------------------------------------------------------- loop pieces ---
-// Empty V tile buffers.  fp16 storage of a problem that may run the NE kernels (zero_class): every element is the zero class of
-// k_tile_V (the smallest positive fp16 number, bit pattern 1) -- padding rows and columns included, so that an update pass
-// without the numerator's eps never sees a zero.  Other problems keep true zeros (an all-zero row of V then gives an exactly
-// zero row of W, as in the reference; with the zero class it is ~1e-12 of the matrix maximum).
+// Empty V tile buffers: true zeros (padding rows and columns are inert; an all-zero row of V gives an exactly zero row of W,
+// as in the reference -- also under the update pass without the numerator's eps, whose ratio carries a 2^-100 addend instead
+// of relying on a stored "zero class": mfma4.hip.h, NE).
 void fill_v_tiles(klnmf_ctx *c, void *tiles, size_t bytes) {
-    if (c->vsize() == 2 && c->zero_class) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)tiles, (unsigned short)1, bytes / 2, c->stream));
-    else HIPCHK(hipMemsetAsync(tiles, 0, bytes, c->stream));
+    HIPCHK(hipMemsetAsync(tiles, 0, bytes, c->stream));
 }
 
 void reset_state(klnmf_ctx *c) {
@@ -1003,7 +1182,7 @@ void reset_state(klnmf_ctx *c) {
 }
 
 // fused_tol != nullptr (klnmf_run): the stop rule rides in the loss kernel of the bf16 modes (no k_decide launch)
-void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
+void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr, bool defer_to_post = false) {
     // the W rule is the same for fit and transform (nmf.py:251-253); a fit also keeps the ratios for the H rule
     if (c->is_exact()) {
         EXACT_CALL(c, exact_Q, 1);
@@ -1015,6 +1194,13 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr) {
         // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
         if (measured && !fit) fast_pack_H(c, 0);
         static const bool defer_ok = !(std::getenv("KLNMF_LOSS_DEFER") && std::atoi(std::getenv("KLNMF_LOSS_DEFER")) == 0);
+        if (fit && defer_to_post && c->fused) {
+            // a fit on a communicator: one extra block of the first part's summing launch (k_post) reduces the partials into
+            // loss_xchg, which is exchanged with the numerator; the stop rule rides in the launch behind the all-reduce
+            c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 0, c->st,
+                                       0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0};
+            return;
+        }
         if (fit && fused_tol && defer_ok) {
             // a fit in one context: nothing needs the loss before the H rule -- it is reduced (and the stop rule applied) by
             // one extra block of the slab-sum launch behind the column pass (launch_sum_partials)
@@ -1036,14 +1222,58 @@ void piece_decide(klnmf_ctx *c, double tol_abs) {
     HIPCHK(hipGetLastError());
 }
 
+const LossArgs kNoLoss{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0};
+
 void piece_colpass(klnmf_ctx *c) {
-    if (c->is_exact()) EXACT_CALL(c, exact_N, c->cur ^ 1);
-    else fast_colpass(c);
+    if (c->is_exact()) { EXACT_CALL(c, exact_N, c->cur ^ 1); return; }
+    if (!c->fused) { fast_colpass(c); return; }
+    // (the pieces of a loop sequenced by the caller: the numerator is summed here, exchanged by the caller, applied by
+    // piece_update_H; the loss was left in loss_xchg by piece_rowpass)
+    const bool use8 = fused_w8_stage(c);
+    if (use8) c->stat_col8 += 1;
+    fused_colpass_part(c, c->whole, use8);
+    launch_post(c, POST_SUM, &c->whole, 1, kNoLoss, false, use8, true);
+}
+
+// one column part of the split layout (the caller exchanges it while the next part computes)
+void piece_colpass_part(klnmf_ctx *c, int p) {
+    if (c->is_exact() || !c->fused || c->nparts_cfg <= 1) {
+        if (p != 0) fail(KLNMF_ERR_ARG, "klnmf_iter_colpass_part: this problem has one part");
+        piece_colpass(c);
+        return;
+    }
+    if (p < 0 || p >= c->nparts_cfg) fail(KLNMF_ERR_ARG, "klnmf_iter_colpass_part: no such part");
+    if (p == 0) {
+        c->piece_use8 = fused_w8_stage(c);
+        if (c->piece_use8) c->stat_col8 += 1;
+    }
+    fused_colpass_part(c, c->parts[p], c->piece_use8);
+    launch_post(c, POST_SUM, &c->parts[p], 1, kNoLoss, false, c->piece_use8, p == c->nparts_cfg - 1);
+    c->piece_split = true;
 }
 
 void piece_update_H(klnmf_ctx *c) {
     if (c->is_exact()) EXACT_CALL(c, exact_H);
+    else if (c->fused && c->piece_split) launch_post(c, POST_RULE, c->parts, c->nparts_cfg, kNoLoss, false, false, false);
+    else if (c->fused) launch_post(c, POST_RULE, &c->whole, 1, kNoLoss, false, false, false);
     else fast_pack_H(c, 1);
+    c->piece_split = false;
+}
+
+// column pass + everything behind it of a single-context fit iteration (the row pass has run; its loss partials and the
+// tolerance ride in c->pending_loss when the stop rule is deferred to here)
+void piece_fit_tail(klnmf_ctx *c) {
+    if (c->is_exact() || !c->fused) {
+        piece_colpass(c);
+        piece_update_H(c);
+        return;
+    }
+    const LossArgs la = c->pending_loss;
+    c->pending_loss.part = nullptr;
+    const bool use8 = fused_w8_stage(c);
+    if (use8) c->stat_col8 += 1;
+    fused_colpass_part(c, c->whole, use8);
+    launch_post(c, POST_FULL, &c->whole, 1, la, la.part != nullptr, use8, true);
 }
 
 struct HostState {
@@ -1065,6 +1295,14 @@ void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopp
     c->stat_q8_sat = hs.q8_sat_total; c->stat_q8_unfixed = hs.q8_unfixed;
     // the current W is the one the last *executed* update wrote
     c->cur = (c->loop_start_cur + (int)(hs.n_done & 1)) & 1;
+    // ... and so is the current dictionary master: k_post swaps H32 / H32alt per ENQUEUED H rule, the device performed
+    // n_done of them (after the stop rule fired the launches return at their first instruction)
+    if (c->loop_hswaps > 0 && c->loop_h0 != nullptr) {
+        const bool odd = (hs.n_done & 1) != 0;
+        c->H32 = odd ? c->loop_h1 : c->loop_h0;
+        c->H32alt = odd ? c->loop_h0 : c->loop_h1;
+        c->loop_hswaps = 0;
+    }
 }
 
 // ---------------------------------------------------------------- uploads ---
@@ -1085,7 +1323,7 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
         case KLNMF_PREC_BF16:
             hipLaunchKernelGGL((k_tile_V<_Float16, S>), dim3(grid), dim3(256), 0, c->stream,
                                (_Float16 *)c->VtA, (_Float16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
-                               ld, row0, col0, scale * c->v_scale, c->st, row_idx, kEpsRatio * c->v_scale, c->zero_class ? 1 : 0);
+                               ld, row0, col0, scale * c->v_scale, c->st, row_idx, kEpsRatio * c->v_scale);
             break;
         default:
             hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
@@ -1457,7 +1695,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->q8_loop = false;
             c->iter_in_loop = 0;
             c->v_max = 0.0;
-            c->zero_class = c->q8_ok && !c->big && c->vsize() == 2;      // (q8_ok: enough rows for fp8 ratio tiles -- where the NE kernels exist)
+            c->ne_ok = c->q8_ok && !c->big && c->vsize() == 2;      // (q8_ok: enough rows for fp8 ratio tiles -- where the NE kernels exist)
             c->VtA = c->dalloc(vbytes, false);
             c->VtB = stored_q ? nullptr : c->dalloc(vbytes, false);
             fill_v_tiles(c, c->VtA, vbytes);
@@ -1513,17 +1751,56 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
             const int ctw = c->big ? kWavesPerWG / 2 : kWavesPerWG;      // column tiles per workgroup (colq.hip.h, KSPLIT)
             c->ncb = (c->nct_used + ctw - 1) / ctw;
-            int nch = 8;
             int64_t wg_per_cu = 1;       // workgroups per CU the decomposition aims at (one is resident per CU; 2 measured 1-3 % slower)
             if (const char *g = std::getenv("KLNMF_COL_WG_PER_CU")) wg_per_cu = std::max(1, std::atoi(g));
-            while ((int64_t)nch * c->ncb < wg_per_cu * c->cu_count && nch * 2 <= total_stages) nch += 8;
-            while (nch > 8 && ((int64_t)nch * c->ncb) % c->cu_count != 0 &&
-                   (int64_t)(nch - 8) * c->ncb >= c->cu_count) nch -= 8;
-            if (nch > total_stages) nch = total_stages > 0 ? ((total_stages + 7) / 8) * 8 : 8;
+            auto chunks_for = [&](int ncb) {      // row chunks of a column pass over `ncb` column blocks: the grid fills the chip once
+                int nch = 8;
+                while ((int64_t)nch * ncb < wg_per_cu * c->cu_count && nch * 2 <= total_stages) nch += 8;
+                while (nch > 8 && ((int64_t)nch * ncb) % c->cu_count != 0 &&
+                       (int64_t)(nch - 8) * ncb >= c->cu_count) nch -= 8;
+                if (nch > total_stages) nch = total_stages > 0 ? ((total_stages + 7) / 8) * 8 : 8;
+                return nch;
+            };
+            const int nch = chunks_for(c->ncb);
             c->nchunks = nch;
             c->stages_per_chunk = (total_stages + nch - 1) / nch;
-            c->NpartF = (float *)c->dalloc((size_t)nch * c->KP * c->f_pad * 4);
-            c->numerF = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
+            c->whole = klnmf_ctx::PartCfg{0, c->ncb, 0, c->nct_used, 0, (int)f, (int)c->f_pad, nch, c->stages_per_chunk, 0, 0};
+            // column parts for loops on a communicator (overlap of the numerator's all-reduce with the column pass)
+            c->fused = stored_q && (c->col_gen == 2 || c->big) && !c->w8_tail &&
+                       !(std::getenv("KLNMF_FUSE") && std::atoi(std::getenv("KLNMF_FUSE")) == 0);
+            c->nparts_cfg = 1;
+            if (const char *g = std::getenv("KLNMF_COMM_PARTS")) c->nparts_cfg = std::min(kPostMaxParts, std::max(1, std::atoi(g)));
+            if (!c->fused) c->nparts_cfg = 1;
+            c->nparts_cfg = std::min(c->nparts_cfg, c->ncb);
+            int64_t split_numer = 0, split_slabs = 0;
+            if (c->nparts_cfg > 1) {
+                for (int p = 0; p < c->nparts_cfg; ++p) {
+                    klnmf_ctx::PartCfg &q = c->parts[p];
+                    q.cb0 = (int)((int64_t)c->ncb * p / c->nparts_cfg);
+                    q.ncb = (int)((int64_t)c->ncb * (p + 1) / c->nparts_cfg) - q.cb0;
+                    q.ct0 = q.cb0 * ctw;
+                    q.nct = std::min(c->nct_used - q.ct0, q.ncb * ctw);
+                    q.col0 = q.ct0 * 32;
+                    q.ld = q.ncb * ctw * 32;
+                    q.ncols = (int)std::min<int64_t>(f - q.col0, q.ld);
+                    q.nchunks = chunks_for(q.ncb);
+                    q.spc = (total_stages + q.nchunks - 1) / q.nchunks;
+                    q.numer_off = split_numer;
+                    q.slab_off = split_slabs;
+                    split_numer += (int64_t)c->KP * q.ld;
+                    split_slabs += (int64_t)q.nchunks * c->KP * q.ld;
+                }
+            }
+            c->NpartF = (float *)c->dalloc((size_t)std::max<int64_t>((int64_t)nch * c->KP * c->f_pad, split_slabs) * 4);
+            c->numerF = (float *)c->dalloc((size_t)std::max<int64_t>((int64_t)c->KP * c->f_pad, split_numer) * 4);
+            c->H32alt = c->fused ? (float *)c->dalloc((size_t)c->KP * c->f_pad * 4) : nullptr;
+            c->loop_hswaps = 0;
+            c->w8tab = nullptr; c->w8s_next = nullptr; c->conv_ran = false;
+            if (c->fused && c->W8) {
+                c->w8tab = (unsigned *)c->dalloc((size_t)kW8TabRows * c->KP * 4);      // (zero-filled)
+                c->w8s_next = (float *)c->dalloc((size_t)c->KP * 4);
+                HIPCHK(hipMemcpyAsync(c->w8s_next, c->w8s, (size_t)c->KP * 4, hipMemcpyDeviceToDevice, c->stream));
+            }
             // Column-split update pass: with fewer than half as many 8-wave workgroups as CUs (n < ~32 000 rows; the
             // reference's own data sets have 10^2..10^3) split every row block's columns over blockIdx.y so that the grid
             // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
@@ -1772,6 +2049,9 @@ int klnmf_set_H_device(klnmf_ctx *c, const void *dsrc, int dtype, int64_t ld, in
         if (col0 < 0 || ncols < 0 || col0 + ncols > c->f || ld < ncols) fail(KLNMF_ERR_ARG, "klnmf_set_H_device: column block out of range");
         if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_set_H_device: dense problems");
         const bool f64 = dtype == KLNMF_DT_F64;
+        // the first block of a dictionary (col0 = 0) starts from zeros, as klnmf_set_H does: a pooled or re-used context
+        // must not keep padding rows / columns of the previous dictionary in its images
+        if (col0 == 0 && !c->is_exact()) HIPCHK(hipMemsetAsync(c->H32, 0, (size_t)c->KP * c->f_pad * 4, c->stream));
         if (c->prec == KLNMF_PREC_F64) {
             if (f64) copy_2d(c, (double *)c->H + col0, c->f, (const double *)dsrc, ld, c->k, ncols);
             else copy_2d(c, (double *)c->H + col0, c->f, (const float *)dsrc, ld, c->k, ncols);
@@ -1910,7 +2190,7 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     const char *g = std::getenv("KLNMF_QTILE");
     if (g) {
         c->q8_loop = std::atoi(g) == 8;
-        c->ne_loop = c->q8_loop && c->zero_class && ne_env && std::atoi(ne_env) == 1;
+        c->ne_loop = c->q8_loop && c->ne_ok && ne_env && std::atoi(ne_env) == 1;
         return;
     }
     double sum_x = sum_x_global, cells = cells_global;
@@ -1927,8 +2207,8 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     // (x + eps) / (W.H + eps) by a relative eps / x per element.  Simulated in fp64 over 50 iterations
     // the loss record moves by 0.06 .. 0.15 x eps / mean(V) and the factors by 0.5 .. 2.3 x eps / mean(V) of their maxima:
     // taken where eps / mean(V) <= 1e-5, i.e. 1.5e-6 and 2.5e-5 -- below the fp8 tiles' own floor (h29).
-    c->ne_loop = c->q8_loop && c->zero_class && mean >= 1.0e5 * kEpsRatio;
-    if (ne_env) c->ne_loop = c->q8_loop && c->zero_class && std::atoi(ne_env) == 1;
+    c->ne_loop = c->q8_loop && c->ne_ok && mean >= 1.0e5 * kEpsRatio;
+    if (ne_env) c->ne_loop = c->q8_loop && c->ne_ok && std::atoi(ne_env) == 1;
 }
 
 // ---- a loop on this context's RCCL communicator (klnmf_comm_init): entry and iteration, shared by klnmf_run_sharded (the
@@ -1974,7 +2254,60 @@ static void comm_loop_entry(klnmf_ctx *c) {
 // One iteration: row pass -> column pass (it does not depend on the stop decision) -> ONE grouped RCCL launch on the
 // context's stream (the k real rows of the numerator -- the 16-bit modes lay it out [KP][f_pad], rows beyond k are padding --
 // and the two doubles of the loss) -> stop rule on identical inputs -> H rule.
+static bool comm_overlap_on() {
+    const char *g = std::getenv("KLNMF_COMM_OVERLAP");
+    return !(g && std::atoi(g) == 0);
+}
 static void comm_iteration(klnmf_ctx *c, int fit, double tol_abs) {
+    if (fit && c->fused) {
+        // Fused tail with column parts (post.hip.h).  Per part: column pass -> k_post(SUM): slabs -> this part's numerator
+        // [KP][ld] (contiguous: one ncclAllReduce), fix-ups; the first part's launch also leaves the loss in loss_xchg.  The
+        // all-reduce of every part but the last goes to the communicator's own stream behind an event and runs while the
+        // next part's column pass computes (KLNMF_COMM_OVERLAP=0: all of them on the context's stream, in sequence -- the
+        // same arithmetic, bit for bit).  The last part's all-reduce and the loss travel as ONE grouped RCCL launch on the
+        // context's stream, AFTER the earlier all-reduces have completed (no two collectives of one communicator ever run
+        // concurrently); k_post(RULE) then takes the stop decision from the exchanged loss and applies the H rule.
+        const int P = c->nparts_cfg > 1 ? c->nparts_cfg : 1;
+        const klnmf_ctx::PartCfg *parts = P > 1 ? c->parts : &c->whole;
+        const bool overlap = P > 1 && comm_overlap_on() && c->comm_stream != nullptr;
+        piece_rowpass(c, fit, nullptr, true);
+        const LossArgs la = c->pending_loss;
+        c->pending_loss.part = nullptr;
+        const bool use8 = fused_w8_stage(c);
+        if (use8) c->stat_col8 += 1;
+        for (int p = 0; p < P; ++p) {
+            fused_colpass_part(c, parts[p], use8);
+            launch_post(c, POST_SUM, &parts[p], 1, p == 0 ? la : kNoLoss, false, use8, p == P - 1);
+            if (p < P - 1) {
+                float *nb = c->numerF + parts[p].numer_off;
+                const size_t cnt = (size_t)c->k * (size_t)parts[p].ld;
+                if (overlap) {
+                    HIPCHK(hipEventRecord(c->ev_part[p], c->stream));
+                    HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_part[p], 0));
+                    RCCLCHK(rccl().AllReduce(nb, nb, cnt, ncclFloat, ncclSum, c->comm, c->comm_stream));
+                    HIPCHK(hipEventRecord(c->ev_ar[p], c->comm_stream));
+                } else {
+                    RCCLCHK(rccl().AllReduce(nb, nb, cnt, ncclFloat, ncclSum, c->comm, c->stream));
+                }
+            }
+        }
+        if (overlap)
+            for (int p = 0; p < P - 1; ++p) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_ar[p], 0));
+        float *nb = c->numerF + parts[P - 1].numer_off;
+        const size_t cnt = (size_t)c->k * (size_t)parts[P - 1].ld;
+        RCCLCHK(rccl().GroupStart());
+        ncclResult_t ra = rccl().AllReduce(nb, nb, cnt, ncclFloat, ncclSum, c->comm, c->stream);
+        ncclResult_t rb = rccl().AllReduce(c->loss_xchg, c->loss_xchg, 2, ncclDouble, ncclSum, c->comm, c->stream);
+        ncclResult_t rc = rccl().GroupEnd();       // closed on the error path too
+        RCCLCHK(ra); RCCLCHK(rb); RCCLCHK(rc);
+        LossArgs lt = kNoLoss;
+        lt.tol_abs = tol_abs;
+        launch_post(c, POST_RULE, parts, P, lt, true, false, false);
+        c->cur ^= 1;
+        c->iter_in_loop += 1;
+        poll_fp8_overflow(c, true);
+        return;
+    }
     const size_t ncount = c->is_exact() ? (size_t)(c->k * c->f) : (size_t)c->k * (size_t)c->f_pad;
     void *nbuf = c->is_exact() ? c->numer : (void *)c->numerF;
     const ncclDataType_t ntype = c->prec == KLNMF_PREC_F64 ? ncclDouble : ncclFloat;
@@ -1989,7 +2322,7 @@ static void comm_iteration(klnmf_ctx *c, int fit, double tol_abs) {
     if (fit) piece_update_H(c);
     c->cur ^= 1;
     c->iter_in_loop += 1;
-    if (fit) poll_fp8_overflow(c);
+    if (fit) poll_fp8_overflow(c, !c->is_exact());
 }
 
 int klnmf_loop_begin(klnmf_ctx *c) {
@@ -2003,6 +2336,7 @@ int klnmf_loop_begin(klnmf_ctx *c) {
         }
         reset_state(c);
         c->loop_start_cur = c->cur;
+        c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;
         c->loop_iters = 0;
     });
 }
@@ -2015,6 +2349,7 @@ int klnmf_loop_begin_sharded(klnmf_ctx *c, double sum_x_all, double cells_all) {
         begin_fp8_loop(c, sum_x_all * c->v_scale, cells_all);      // (the caller's sums are in the data's own units)
         reset_state(c);
         c->loop_start_cur = c->cur;
+        c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;
         c->loop_iters = 0;
     });
 }
@@ -2041,10 +2376,7 @@ int klnmf_run_more(klnmf_ctx *c, int64_t iters, int fit, double tol_abs) {
                 piece_rowpass(c, fit);
                 piece_decide(c, tol_abs);
             }
-            if (fit) {
-                piece_colpass(c);
-                piece_update_H(c);
-            }
+            if (fit) piece_fit_tail(c);
             c->cur ^= 1;
             c->loop_iters += 1;
             c->iter_in_loop += 1;
@@ -2074,6 +2406,35 @@ int klnmf_iter_colpass(klnmf_ctx *c) {
     });
 }
 
+int klnmf_iter_colpass_part(klnmf_ctx *c, int part) {
+    return guarded([&] {
+        need_problem(c);
+        piece_colpass_part(c, part);
+    });
+}
+
+int klnmf_exchange_parts(klnmf_ctx *c, int *nparts, int64_t *offsets, int64_t *counts, int64_t *col0, int64_t *ncols) {
+    return guarded([&] {
+        need_problem(c);
+        if (!nparts || !offsets || !counts) fail(KLNMF_ERR_ARG, "klnmf_exchange_parts: null pointer");
+        const bool split = !c->is_exact() && c->fused && c->nparts_cfg > 1;
+        *nparts = split ? c->nparts_cfg : 1;
+        for (int p = 0; p < *nparts; ++p) {
+            if (split) {
+                offsets[p] = c->parts[p].numer_off;
+                counts[p] = c->k * (int64_t)c->parts[p].ld;
+                if (col0) col0[p] = c->parts[p].col0;
+                if (ncols) ncols[p] = c->parts[p].ncols;
+            } else {
+                offsets[p] = 0;
+                counts[p] = c->is_exact() ? c->k * c->f : c->k * c->f_pad;
+                if (col0) col0[p] = 0;
+                if (ncols) ncols[p] = c->f;
+            }
+        }
+    });
+}
+
 int klnmf_iter_update_H(klnmf_ctx *c) {
     return guarded([&] {
         need_problem(c);
@@ -2090,6 +2451,9 @@ int klnmf_iter_advance(klnmf_ctx *c) {
         c->cur ^= 1;
         c->loop_iters += 1;
         c->iter_in_loop += 1;
+        // the loop in pieces gives fp8 tiles up after bulk saturation like the loops in one call: the count is read where the
+        // caller's exchange left it (loss_xchg[1]: summed over the ranks by the loss all-reduce, this context's own without one)
+        if (!c->is_exact()) poll_fp8_overflow(c, true);
     });
 }
 
@@ -2110,6 +2474,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         begin_fp8_loop(c);
         reset_state(c);
         c->loop_start_cur = c->cur;
+        c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;
         // bf16 modes: the stop rule inside the loss kernel -- one launch fewer per iteration (a small problem's
         // iteration IS its kernel latencies: 7 launches of 4-10 us each).  Summing the column pass's slabs inside the
         // H rule as well (from_slabs) was measured and is NOT used: its k blocks walk the slabs serially, 47 -> 68 us.
@@ -2121,10 +2486,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
                 piece_rowpass(c, fit);
                 piece_decide(c, tol_abs);
             }
-            if (fit) {
-                piece_colpass(c);
-                piece_update_H(c);
-            }
+            if (fit) piece_fit_tail(c);
             c->cur ^= 1;
             c->iter_in_loop += 1;
             if (fit) poll_fp8_overflow(c);
@@ -2208,6 +2570,12 @@ int klnmf_comm_init(klnmf_ctx *c, const void *id, int rank, int nranks) {
         c->comm_rank = rank;
         c->comm_size = nranks;
         HIPCHK(hipMalloc((void **)&c->comm_scratch, 8 * sizeof(double)));
+        // the parts' all-reduces that overlap the column pass (comm_iteration) run on a stream of their own
+        HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        for (int p = 0; p < kPostMaxParts; ++p) {
+            HIPCHK(hipEventCreateWithFlags(&c->ev_part[p], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_ar[p], hipEventDisableTiming));
+        }
     });
 }
 
@@ -2247,6 +2615,7 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         }
         reset_state(c);
         c->loop_start_cur = c->cur;
+        c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;
         const double tol_abs = tol * (double)n_total * (double)c->f;          // nmf.py:207 on the GLOBAL shape
         for (int64_t it = 0; it < max_iter; ++it) {
             if (multi) {
@@ -2255,9 +2624,13 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
                 // one rank: the stop decision rides in the loss kernel, as in klnmf_run (one launch less per iteration)
                 if (c->is_exact()) piece_rowpass(c, fit);
                 else piece_rowpass(c, fit, &tol_abs);
-                if (fit) piece_colpass(c);
-                if (c->is_exact()) piece_decide(c, tol_abs);
-                if (fit) piece_update_H(c);
+                if (c->is_exact()) {
+                    if (fit) piece_colpass(c);
+                    piece_decide(c, tol_abs);
+                    if (fit) piece_update_H(c);
+                } else if (fit) {
+                    piece_fit_tail(c);
+                }
                 c->cur ^= 1;
                 c->iter_in_loop += 1;
                 if (fit) poll_fp8_overflow(c);
@@ -2284,7 +2657,10 @@ int klnmf_exchange_buffers(klnmf_ctx *c, void **loss_ptr, void **numer_ptr, int6
             if (numer_is_f64) *numer_is_f64 = c->prec == KLNMF_PREC_F64;
         } else {
             if (numer_ptr) *numer_ptr = c->numerF;
-            if (numer_count) *numer_count = (int64_t)c->KP * c->f_pad;
+            int64_t cnt = (int64_t)c->KP * c->f_pad;        // (the split layout of klnmf_exchange_parts may be longer: whole column blocks)
+            if (c->fused && c->nparts_cfg > 1)
+                cnt = std::max(cnt, c->parts[c->nparts_cfg - 1].numer_off + (int64_t)c->KP * c->parts[c->nparts_cfg - 1].ld);
+            if (numer_count) *numer_count = cnt;
             if (numer_is_f64) *numer_is_f64 = 0;
         }
     });
@@ -2626,6 +3002,7 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
         if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_all_distances_device: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
         if (na == 0 || nb == 0) return;
         if (!dout || (d > 0 && (!dA || !dB)) || lda < d || ldb < d) fail(KLNMF_ERR_ARG, "klnmf_all_distances_device: null pointer or short stride");
+        if (na * nb > ((int64_t)1 << 32)) fail(KLNMF_ERR_UNSUPP, "klnmf_all_distances_device: more than 2^32 pairs per call (four pairs per block on gridDim.x): split the rows");
         HIPCHK(hipSetDevice(device));
         const int64_t pairs = na * nb;
         if (dtype == KLNMF_DT_F64)
@@ -2648,6 +3025,7 @@ int klnmf_all_distances(int device, int dtype, int metric, int64_t na, int64_t n
         if (dtype != KLNMF_DT_F32 && dtype != KLNMF_DT_F64) fail(KLNMF_ERR_ARG, "klnmf_all_distances: dtype must be KLNMF_DT_F32 or KLNMF_DT_F64");
         if (na == 0 || nb == 0) return;
         if (!out || (d > 0 && (!A || !B))) fail(KLNMF_ERR_ARG, "klnmf_all_distances: null pointer");
+        if (na * nb > ((int64_t)1 << 32)) fail(KLNMF_ERR_UNSUPP, "klnmf_all_distances: more than 2^32 pairs per call: split the rows");
         HIPCHK(hipSetDevice(device));
         if (dtype == KLNMF_DT_F64) distances_on_device<double>(metric, na, nb, d, A, B, out);
         else distances_on_device<float>(metric, na, nb, d, A, B, out);

@@ -1005,7 +1005,7 @@ template <typename VT, typename S>
 __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int nct, const S *src,
                                                 int64_t rows, int64_t cols, int64_t ld, int64_t row0,
                                                 int64_t col0, double scale, DevState *st,
-                                                const int64_t *row_idx = nullptr, double eps_s = 0.0, int zero_class = 0) {
+                                                const int64_t *row_idx = nullptr, double eps_s = 0.0) {
     __shared__ double red[16];
     const int64_t total = rows * cols;
     double sx = 0, cc = 0, ce = 0;
@@ -1019,13 +1019,6 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
             atomicAdd(&st->v_overflow, 1);
         }
         const double xt = (double)xs;
-        // zero_class (fp16 storage of a problem whose loops may run the NE kernels: klnmf_set_problem): a zero is stored as the
-        // smallest positive number (2^-24 in storage units, ~1e-12 of the maximum) and the tile buffers are pre-filled with it
-        // -- the update pass that drops the numerator's eps (ratio x / (W.H + eps), NE in mfma4.hip.h) then never takes the
-        // logarithm of a zero ratio; every sum below sees the true zero
-        if constexpr (sizeof(VT) == 2) {
-            if (zero_class && xs == (VT)0) xs = __builtin_bit_cast(VT, (unsigned short)1);
-        }
         const int64_t row = row0 + ii, col = col0 + jj;
         const int64_t rt = row >> 5, ctile = col >> 5;
         const int i = row & 31, c = col & 31;
@@ -1093,12 +1086,13 @@ __device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const 
     if (threadIdx.x == 0) {
         const double err = (kLn2 * ta + (la.ne ? st->corr_eps : 0.0) + tb - st->sum_x - st->corr_c) * la.inv_c;
         la.out[0] = err;
-        la.out[1] = 0;
+        la.out[1] = (double)st->q8_unfixed;      // (row shards: summed by the loss exchange, so that every rank sees when fp8 tiles must be given up)
         if (la.decide) {
             if (la.st_rw->prev_err - err < la.tol_abs) {
                 la.st_rw->stop = 1;
             } else {
                 la.st_rw->prev_err = err;
+                la.st_rw->prev2[0] = err; la.st_rw->prev2[1] = err;
                 if (la.st_rw->n_done < la.cap) la.errors[la.st_rw->n_done] = err;
                 la.st_rw->n_done += 1;
             }

@@ -668,8 +668,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
         constexpr bool NE = Q8 == 2;       // ratio x / (W.H + eps): the numerator's eps dropped (16 multiplications per tile), see below
 #endif
-        float zero_f = 0.f;
-        if constexpr (NE) asm volatile("" : "+v"(zero_f));      // (an opaque zero keeps the v_fma_mix form: x stays in its fp16 storage form)
+        // NE: the addend of the ratio's multiply-add is not 0 but 2^-100 (opaque: the v_fma_mix form stays, x is consumed in its
+        // fp16 storage form).  For x > 0 it is below half an ulp of x * r whatever W.H is (x * r >= 2^-24 * 2^-40): the same bits as
+        // x * r.  For x = 0 the ratio is 2^-100 instead of 0: its logarithm is finite (-100), the loss term 0 * (-100) = 0 exactly,
+        // and it packs to a zero f16 / e4m3 operand -- so V keeps TRUE zeros (round 3 stored them as 2^-24 to keep log2(0) out of
+        // the loss), and an all-zero row of V gives an exactly zero row of W as in the reference (nmf.py:156, 342).
+        float zero_f = 0x1p-100f;
+        if constexpr (NE) asm volatile("" : "+v"(zero_f));
 #if defined(KL_E_PIPE)     // experiment: the epilogue as a hand-ordered 3-stage software pipeline (rcp two elements ahead, ratio one
         // ahead, log of the current, loss term of the previous): every result is consumed at least four instructions after
         // the one that produces it; order pinned with empty asm statements
@@ -711,9 +716,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps came in through MFMA-1
                 // NE (Q8 = 2; klnmf_api.hip chooses it per loop from the data's mean): the ratio as x * r.  Against the reference's
                 // (x + eps) * r that is a relative eps / x per element -- chosen only where eps / mean(V) <= 1e-5 (loss record within
-                // 1.5e-6, factors within 2.5e-5 of their maxima over 50 iterations: DESIGN.md section 8, h33) --, zeros are stored as
-                // 2^-24 (k_tile_V) so that no logarithm sees a zero ratio, and the loss gets the exact constant
-                // sum x ln(1 + eps/x) back (DevState.corr_eps).  Row pass -1.8 %, iteration -1.4 % at the headline shape.
+                // 1.5e-6, factors within 2.5e-5 of their maxima over 50 iterations: DESIGN.md section 8, h33) --, no logarithm sees
+                // a zero ratio (the 2^-100 addend above), and the loss gets the exact constant sum x ln(1 + eps/x) back
+                // (DevState.corr_eps).  Row pass -1.8 %, iteration -1.4 % at the headline shape.
                 if constexpr (NE) q[e] = fmaf(x, rinv, zero_f);
                 else q[e] = fmaf(x, rinv, eps * rinv);
 #ifdef KL_ABL_LOGD        // timing-only experiment: the loss term from log2(W.H) (independent of the reciprocal) -- the loss VALUE is then another sum

@@ -10,7 +10,7 @@ with the per-modality coefficient and the column placement (learner.py:53-56).
 import numpy as np
 
 from . import _native
-from .lib.nmf import KLdivNMF, check_non_negative, _default_precision
+from .lib.nmf import KLdivNMF, check_non_negative, _default_precision, resolve_precision
 from .lib.sklearn_utils import atleast2d_or_csr
 
 
@@ -37,11 +37,14 @@ class DeviceDataset(object):
         assert all(b.shape[0] == self.n_samples for b in self.blocks)
         self._blocks64 = {}
 
-    def source(self, which):
+    def source(self, which, precision=None):
         """(device matrix, is_float64) the fits and transforms read modality `which` from: the float64 copy when the NMF runs
-        in the reference's own arithmetic (KLNMF_PRECISION=f64: results then agree with the reference to summation order),
-        the float32 one otherwise (the 16-bit modes store V in 16 bits anyway)."""
-        if _default_precision() == 'auto' or _native.PRECISIONS[_default_precision()] == _native.PREC_F64:
+        in the reference's own arithmetic (f64: results then agree with the reference to summation order), the float32 one
+        otherwise (the 16-bit modes store V in 16 bits anyway).  `precision`: what the context that reads it resolved to
+        (`Context.precision_name`); None: the process default."""
+        if precision is None:
+            precision = _default_precision()
+        if precision == 'auto' or _native.PRECISIONS[precision] == _native.PREC_F64:
             return self.block64(which), True           # ('auto' decides per fit: the float64 copy serves either outcome)
         return self.blocks[which], False
 
@@ -62,7 +65,7 @@ class DeviceDataset(object):
             ctx.set_v_max(max([c * self.maxima[w] for w, c in zip(which, coefs)] + [0.0]))
             col = 0
             for w, c in zip(which, coefs):
-                b, f64 = self.source(w)
+                b, f64 = self.source(w, getattr(ctx, 'precision_name', None))
                 ctx.upload_V_device_rows_dt(b.data_ptr(), f64, idx.data_ptr(), idx.numel(), b.shape[1], b.stride(0),
                                             row0=0, col0=col, scale=c)
                 col += b.shape[1]
@@ -138,12 +141,14 @@ class DeviceEvaluation(object):
         n, f = int(idx.numel()), sum(lr.dim[w] for w in which)
         out = torch.empty((n, self.k), dtype=torch.float64, device=self.dev)
         model = KLdivNMF(n_components=self.k, max_iter=self.iter_test, tol=0)
-        with model._context() as ctx:
+        # (the shape decides the arithmetic exactly as the host path's _fit_uploaded does: 'auto' by size, k beyond the MFMA
+        # kernels' range on the fp32 kernels)
+        with model._context(shape=(n, f, self.k)) as ctx:
             ctx.set_problem(n, f, self.k, self.iter_test)
             ctx.set_v_max(max([lr.coef[w] * self.ds.maxima[w] for w in which] + [0.0]))
             col = 0
             for w in which:
-                b, f64 = self.ds.source(w)
+                b, f64 = self.ds.source(w, getattr(ctx, 'precision_name', None))
                 ctx.upload_V_device_rows_dt(b.data_ptr(), f64, idx.data_ptr(), n, b.shape[1], b.stride(0), row0=0, col0=col,
                                             scale=lr.coef[w])
                 col += b.shape[1]

@@ -92,6 +92,13 @@ class ShardedKLNMF(object):
         if hasattr(self.ctx, 'exchange_layout'):
             _, valid = self.ctx.exchange_layout()
         self.numer_xchg = self.numer_t[:valid]
+        # column parts of the numerator (KLNMF_COMM_PARTS > 1, 16-bit modes): each part is one contiguous block of the buffer and
+        # is exchanged while the next part's column pass computes (`iterate`)
+        self.parts = None
+        if hasattr(self.ctx, 'exchange_parts'):
+            parts = self.ctx.exchange_parts()
+            if len(parts) > 1:
+                self.parts = [self.numer_t[off:off + cnt] for off, cnt, _, _ in parts]
         # collective path: 'torch' = torch.distributed all-reduces sequenced here around the C-ABI's pieces;
         # 'native' = klnmf_run_sharded: ONE grouped RCCL all-reduce per iteration issued inside the C-ABI
         self.collective = collective
@@ -168,18 +175,30 @@ class ShardedKLNMF(object):
             return
         multi = self.dist is not None and self.world_size > 1
         err = None
-        try:
+        if multi and hasattr(self.ctx, 'sum_V'):
             # every rank must take the same fp8 decision (16-bit modes): it is made from the sums over ALL shards, as
-            # klnmf_run_sharded does on the native path
-            if multi and hasattr(self.ctx, 'sum_V'):
-                t = self.torch.tensor([self.ctx.sum_V(), float(self.n_local) * float(self.f)], dtype=self.torch.float64,
-                                      device=self.tensor_device)
-                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-                self.ctx.loop_begin(float(t[0].item()), float(t[1].item()))
-            else:
+            # klnmf_run_sharded does on the native path.  ONE all-reduce carries [sum V, cells, refusal flag]: a rank whose
+            # own sum cannot be read joins it with zeros and its flag set, so no rank is ever alone in a collective of
+            # another shape
+            vals = [0.0, 0.0, 0.0]
+            try:
+                vals = [self.ctx.sum_V(), float(self.n_local) * float(self.f), 0.0]
+            except Exception as e:
+                err, vals = e, [0.0, 0.0, 1.0]
+            t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.tensor_device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if err is None and float(t[2].item()) == 0.0:
+                try:
+                    self.ctx.loop_begin(float(t[0].item()), float(t[1].item()))
+                except Exception as e:         # (reported below, on every rank)
+                    err = e
+            elif err is None:
+                err = RuntimeError("another rank could not read its shard's sums: the sharded loop is not started on any rank")
+        else:
+            try:
                 self.ctx.loop_begin()
-        except Exception as e:             # (reported below, on every rank)
-            err = e
+            except Exception as e:
+                err = e
         if multi:
             flag = self.torch.tensor([1.0 if err is not None else 0.0], dtype=self.torch.float64, device=self.tensor_device)
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -213,8 +232,19 @@ class ShardedKLNMF(object):
             # The 16-byte loss exchange starts as soon as the row pass has left the local loss and runs on the
             # collective's own stream WHILE the column pass computes: only the numerator exchange is exposed.
             pending = self._all_reduce_async(self.loss_t)
-            self.ctx.iter_colpass()
-            self._all_reduce(self.numer_xchg)
+            if self.parts is not None:
+                # the numerator in column parts: the all-reduce of part p runs (on the collective's own stream) while the
+                # column pass of part p + 1 computes; only the last part's exchange is exposed
+                handles = []
+                for p, buf in enumerate(self.parts):
+                    self.ctx.iter_colpass_part(p)
+                    handles.append(self._all_reduce_async(buf))
+                for h in handles:
+                    if h is not None:
+                        h.wait()
+            else:
+                self.ctx.iter_colpass()
+                self._all_reduce(self.numer_xchg)
             if pending is not None:
                 pending.wait()
             self.ctx.iter_decide(tol_abs)

@@ -50,16 +50,42 @@ AUTO_F16_WORK = 2e9
 
 MAX_K_MFMA = 512          # the 16-bit MFMA kernels hold a wave's accumulators of all components in registers: k <= 512
 
+_NOTED = set()
+
+
+def _note_once(key, text):
+    """One stderr line per process and cause when a problem runs in another arithmetic than the one asked for (never silently)."""
+    if key not in _NOTED:
+        _NOTED.add(key)
+        sys.stderr.write(text)
+
 
 def resolve_precision(precision, n, f, k):
     """The arithmetic one problem runs in.  'auto' by size (above); the 16-bit modes hand k > 512 to the fp32 kernels of the
-    same library (LDS-tiled VALU GEMMs: any k, at least the 16-bit mode's accuracy) instead of refusing the problem."""
+    same library (LDS-tiled VALU GEMMs: any k, at least the 16-bit mode's accuracy) instead of refusing the problem -- and
+    say so once on stderr (the fp32 kernels are an order of magnitude slower than the MFMA path)."""
     if precision == 'auto':
         precision = 'f16' if float(n) * float(f) * float(k) >= AUTO_F16_WORK else 'f64'
     code = _native.PRECISIONS[precision]
     if (code == _native.PREC_BF16 and k > MAX_K_MFMA) or (code == _native.PREC_BF16_V32 and k > 256):      # (fp32-stored V: generation-1 kernels)
+        _note_once(('k', precision), "KLdivNMF: precision=%r holds k <= %d; k = %d runs on the fp32 kernels (precision='f32')\n"
+                   % (precision, MAX_K_MFMA if code == _native.PREC_BF16 else 256, k))
         return 'f32'
     return precision
+
+
+def sparse_precision(precision):
+    """The arithmetic CSR input runs in: the reference's sparse branch (ratio on the stored entries only, nmf.py:52-70,
+    301-308, 331-334) exists as SDDMM + SpMM kernels in the exact modes.  'f64' / 'auto' -> f64, 'f32' -> f32; the 16-bit
+    modes run it in fp32 (never the dense rule on a densified matrix, which is a different algorithm: off X's structure the
+    dense ratio is eps / (W.H + eps), not 0) and say so once on stderr."""
+    if precision in ('auto', 'f64'):
+        return 'f64'
+    if _native.PRECISIONS[precision] == _native.PREC_F32:
+        return 'f32'
+    _note_once(('csr', precision), "KLdivNMF: CSR input with precision=%r runs the reference's sparse branch on the fp32 "
+               "sparse kernels (precision='f32'); pass a dense array for the 16-bit MFMA path\n" % (precision,))
+    return 'f32'
 
 
 def _default_device():
@@ -91,8 +117,8 @@ def _scale(matrix, factors, axis=0):
 def _special_sparse_dot(a, b, refmat):
     """a.b sampled on the non-zeros of refmat, returned as CSR with refmat's
     structure (reference nmf.py:52-70, including its `eliminate_zeros` side
-    effect on refmat).  Host scipy helper of the sparse branch, which is off
-    the GPU path (sparse input is densified before upload)."""
+    effect on refmat).  Host scipy helper kept for callers of the module function; the
+    fit / transform / error of CSR input run the same SDDMM on the device (csrc/sparse.hip.h)."""
     refmat.eliminate_zeros()
     ii, jj = refmat.nonzero()
     vals = np.einsum('ij,ij->i', a[ii, :], b.T[jj, :])
@@ -100,8 +126,8 @@ def _special_sparse_dot(a, b, refmat):
 
 
 def _dense(X):
-    """Dense ndarray of validated input (CSR is densified: the GPU path is
-    dense; Q off the non-zeros is ~1e-8/WH instead of exactly 0)."""
+    """Dense ndarray of validated input (only reached with CSR input by the single-step helpers that are handed an
+    explicit dense Q; fit / transform / error / _update of CSR input take the sparse kernels: `_sparse_route`)."""
     if sp.issparse(X):
         return np.asarray(X.toarray())
     return np.asarray(X)
@@ -147,15 +173,15 @@ class KLdivNMF(object):
 
     # ------------------------------------------------------------ helpers ---
     def _sparse_route(self, *blocks):
-        """CSR input runs the reference's sparse branch (ratio on the stored entries only, nmf.py:52-70,
-        301-308, 331-334) in the exact modes; the bf16 modes densify (Q off the non-zeros ~1e-8/WH)."""
-        # ('auto': sparse input takes the reference's sparse branch, i.e. the exact mode)
-        return (any(sp.issparse(b) for b in blocks) and
-                (self.precision == 'auto' or _native.PRECISIONS[self.precision] in (_native.PREC_F64, _native.PREC_F32)))
+        """CSR input ALWAYS runs the reference's sparse branch (ratio on the stored entries only, nmf.py:52-70,
+        301-308, 331-334): SDDMM + SpMM kernels of the exact modes, in the arithmetic `sparse_precision` names."""
+        return any(sp.issparse(b) for b in blocks)
 
-    def _context(self, exact=False, shape=None):
+    def _context(self, exact=False, shape=None, sparse=False):
         prec = self.precision
-        if prec == 'auto' and shape is None:      # single steps and loss evaluations: exact
+        if sparse:                                # CSR input: f64 ('auto', 'f64') or f32 (everything else), never densified
+            prec = sparse_precision(prec)
+        elif prec == 'auto' and shape is None:    # single steps and loss evaluations: exact
             prec = 'f64'
         elif shape is not None:                   # decided per problem (shape = (n, f, k)): 'auto' by size, k > 512 -> fp32 kernels
             prec = resolve_precision(prec, *shape)
@@ -214,7 +240,8 @@ class KLdivNMF(object):
         max_iter = int(self.max_iter)
         out_dtype = out_dtype_of(H_init)
 
-        with self._context(shape=None if sparse_X is not None else (n_samples, n_features, k)) as ctx:
+        with self._context(shape=None if sparse_X is not None else (n_samples, n_features, k),
+                           sparse=sparse_X is not None) as ctx:
             if sparse_X is not None:
                 ctx.set_problem_sparse(sparse_X, k, max_iter)
             else:
@@ -261,19 +288,23 @@ class KLdivNMF(object):
     # -------------------------------------------------------- single steps ---
     def _update(self, X, W, _fit=True, scale_W=False, eps=1.e-8):
         """One update iteration (reference nmf.py:232-257)."""
-        Xd = _dense(X)
+        sparse = self._sparse_route(X)
+        Xd = None if sparse else _dense(X)
         if scale_W:
             # dead from every caller in the reference (nmf.py:246-250), kept
             W = _scale(normalize_sum(W, axis=1), np.asarray(X.sum(axis=1)).ravel(), axis=1)
-        if eps != 1.e-8 and self.precision != 'auto' and _native.PRECISIONS[self.precision] >= _native.PREC_BF16:
+        if (eps != 1.e-8 and not sparse and self.precision != 'auto'
+                and _native.PRECISIONS[self.precision] >= _native.PREC_BF16):
             raise ValueError("the bf16 kernels use the reference's fixed eps = 1e-8")
         H = self.components_
-        with self._context() as ctx:
-            if self._sparse_route(X):
-                ctx.set_problem_sparse(X, H.shape[0], 1)
+        with self._context(sparse=sparse) as ctx:
+            if sparse:
+                Xc = ctx.set_problem_sparse(X, H.shape[0], 1)
+                dt = _out_dtype(Xc.data, W, H)
             else:
                 ctx.set_problem(Xd.shape[0], Xd.shape[1], H.shape[0], 1)
                 ctx.upload_blocks([Xd])
+                dt = _out_dtype(Xd, W, H)
             ctx.set_H(H)
             ctx.set_W(W)
             if eps != 1.e-8:
@@ -284,9 +315,9 @@ class KLdivNMF(object):
                     ctx.step_H()
             else:
                 ctx.update(_fit)
-            Wn = ctx.get_W(dtype=_out_dtype(Xd, W, H))
+            Wn = ctx.get_W(dtype=dt)
             if _fit:
-                self.components_ = ctx.get_H(dtype=_out_dtype(Xd, W, H))
+                self.components_ = ctx.get_H(dtype=dt)
         return Wn
 
     def error(self, X, W, H=None, weights=1., eps=1.e-8):
@@ -295,7 +326,7 @@ class KLdivNMF(object):
         X = atleast2d_or_csr(X)
         if H is None:
             H = self.components_
-        with self._context() as ctx:
+        with self._context(sparse=self._sparse_route(X)) as ctx:
             if self._sparse_route(X):
                 ctx.set_problem_sparse(X, np.shape(H)[0], 1)      # nmf.py:301-308
             else:

@@ -118,7 +118,46 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, f, k, iters, tol, fit, out_dir):
+class PartedOracleContext(OracleContext):
+    """The column-part form of the exchange (klnmf_exchange_parts / klnmf_iter_colpass_part): the numerator is produced and
+    exchanged in `nparts` column ranges, each one contiguous block [k][width] of the buffer."""
+
+    def __init__(self, nparts):
+        OracleContext.__init__(self)
+        self.nparts = nparts
+
+    def _ranges(self):
+        edges = [self.f * p // self.nparts for p in range(self.nparts + 1)]
+        return list(zip(edges[:-1], edges[1:]))
+
+    def bind_exchange(self, loss_ptr, numer_ptr):
+        self.loss = np.ctypeslib.as_array((ctypes.c_double * 2).from_address(loss_ptr))
+        self.flat = np.ctypeslib.as_array((ctypes.c_double * (self.k * self.f)).from_address(numer_ptr))
+
+    def exchange_parts(self):
+        out, off = [], 0
+        for a, b in self._ranges():
+            out.append((off, self.k * (b - a), a, b - a))
+            off += self.k * (b - a)
+        return out
+
+    def iter_colpass_part(self, p):
+        if self.stop:
+            return
+        (off, cnt, a, w) = self.exchange_parts()[p]
+        self.flat[off:off + cnt] = self.W_new.T.dot(self.Q[:, a:a + w]).ravel()
+
+    def iter_colpass(self):
+        raise AssertionError("a problem with column parts is driven part by part")
+
+    def iter_update_H(self):
+        if self.stop:
+            return
+        numer = np.hstack([self.flat[off:off + cnt].reshape(self.k, w) for off, cnt, a, w in self.exchange_parts()])
+        self.H = orc.normalize_sum(self.H * numer, axis=1)
+
+
+def _worker(rank, world, port, n, f, k, iters, tol, fit, out_dir, nparts=1):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -127,7 +166,8 @@ def _worker(rank, world, port, n, f, k, iters, tol, fit, out_dir):
         X = orc.synthetic_V(77, n, f, k)
         H0 = orc.synthetic_H0(77, f, k)
         r0, r1 = row_partition(n, world)[rank]
-        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=iters, backend=OracleContext())
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=iters, backend=OracleContext() if nparts == 1 else PartedOracleContext(nparts))
+        assert (m.parts is None) == (nparts == 1)
         m.set_v_max(X[r0:r1].max())
         m.upload_V(X[r0:r1])
         m.set_H(H0)
@@ -162,6 +202,26 @@ def test_sharded_equals_single_process(tmp_path, iters, tol, fit):
     np.testing.assert_array_equal(res[0]['H'], res[1]['H'])      # replicas stay bit-identical
     if tol > 0:
         assert bool(res[0]['stopped']) and len(eo) < iters
+
+
+@pytest.mark.parametrize('world,nparts,iters,tol', [(2, 2, 8, 0.0), (4, 2, 6, 0.0), (2, 3, 200, 1e-4)])
+def test_numerator_exchanged_in_column_parts_equals_single_process(tmp_path, world, nparts, iters, tol):
+    """The column-range form of the exchange (round 4: the all-reduce of part p is started while part p + 1 computes):
+    sequencing over gloo with 2 and 4 ranks, 2 and 3 parts, with and without a stop rule that fires -- the result is the
+    single-process oracle fit, the replicas stay bit-identical."""
+    import torch.multiprocessing as mp
+    n, f, k = 140, 40, 6
+    mp.spawn(_worker, args=(world, _free_port(), n, f, k, iters, tol, True, str(tmp_path), nparts), nprocs=world, join=True)
+    X = orc.synthetic_V(77, n, f, k)
+    H0 = orc.synthetic_H0(77, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=tol, warn=False)
+    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    for r in res:
+        assert int(r['n_done']) == len(eo)
+        np.testing.assert_allclose(r['errors'], eo, rtol=1e-11)
+        np.testing.assert_allclose(r['W'], Wo, rtol=1e-9)
+        np.testing.assert_allclose(r['H'], Ho, rtol=1e-9)
+        np.testing.assert_array_equal(res[0]['H'], r['H'])
 
 
 def _tiny_worker(rank, world, port, n, out_dir):
@@ -222,6 +282,55 @@ def _refusal_worker(rank, world, port, out_dir):
         dist.barrier()                       # nobody is left waiting in a collective
     finally:
         dist.destroy_process_group()
+
+
+class NoSumContext(OracleContext):
+    """A shard whose sums cannot be read at the loop's entry (klnmf_query_f64 failing on one rank)."""
+    def __init__(self, broken):
+        OracleContext.__init__(self)
+        self.broken = broken
+
+    def sum_V(self):
+        if self.broken:
+            raise RuntimeError("klnmf error -4: hipMemcpyAsync: device lost")
+        return float(self.V.sum())
+
+    def loop_begin(self, sum_all=None, cells_all=None):
+        OracleContext.loop_begin(self)
+
+
+def _nosum_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n, f, k = 75, 40, 6
+        X = orc.synthetic_V(77, n, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=3, backend=NoSumContext(broken=(rank == 1)))
+        m.set_v_max(X[r0:r1].max()); m.upload_V(X[r0:r1]); m.set_H(orc.synthetic_H0(77, f, k)); m.init_W()
+        try:
+            m.run(3, fit=True, tol=0.0)
+            msg = 'no error'
+        except RuntimeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, 'r%d.txt' % rank), 'w') as fh:
+            fh.write(msg)
+        dist.barrier()                       # nobody is left waiting in a collective of another shape
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_sum_on_one_rank_joins_the_same_collective(tmp_path):
+    """an exception from ctx.sum_V() on one rank happened BEFORE the entry's first all-reduce, so that rank
+    went straight to the 1-element flag all-reduce while its peers sat in the 2-element one (mismatched collectives).  The
+    flag now rides in the same 3-element all-reduce: every rank raises, nobody hangs."""
+    import torch.multiprocessing as mp
+    mp.spawn(_nosum_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
+    assert 'device lost' in msgs[1]
+    assert "another rank" in msgs[0]
 
 
 def test_a_refusal_on_one_rank_stops_every_rank(tmp_path):

@@ -210,12 +210,21 @@ def test_f64_sparse_branch_fit_transform_and_stop_match_reference_golden():
     assert len(e2) == len(g['errors_tol'])
     assert_allclose(e2, g['errors_tol'], rtol=1e-10)
     assert_allclose(m2.components_, g['H_tol'], rtol=1e-8, atol=1e-300)
-    # float32 mode runs the same branch; the bf16 modes densify (close, not identical)
+    # float32 mode runs the same branch; the 16-bit modes hand CSR input to the SAME sparse kernels in fp32 (the dense rule on
+    # a densified matrix is another algorithm: off X's structure its ratio is eps / (W.H + eps), not 0) and say so on stderr
     m3, W3, e3, _ = fit_gpu(X.astype(np.float32), H0.astype(np.float32), k, 12, 0, precision='f32')
     assert W3.dtype == np.float32
     assert_allclose(e3, g['errors'], rtol=2e-4)
-    m4, W4, e4, _ = fit_gpu(X, H0, k, 12, 0, precision='bf16')
-    assert_allclose(e4, g['errors'], rtol=5e-3)
+    from multimodal_amd.lib import nmf as nmf_mod
+    nmf_mod._NOTED.clear()
+    m4, W4, e4, note4 = fit_gpu(X, H0, k, 12, 0, precision='bf16')
+    note4b = fit_gpu(X, H0, k, 2, 0, precision='bf16')[3]
+    assert (note4 + note4b).count("CSR input with precision='bf16' runs the reference's sparse branch") == 1      # once per process
+    assert_allclose(e4, g['errors'], rtol=2e-4)
+    assert_allclose(W4, g['W'], rtol=5e-3, atol=1e-6 * np.abs(g['W']).max())
+    Wt4 = m4.transform(X[:20])
+    assert_allclose(Wt4, g['Wt'], rtol=5e-3, atol=1e-6 * np.abs(g['Wt']).max())
+    assert_allclose(m4.error(X, W4), orc.sparse_kl_error(X, W4.astype(np.float64), m4.components_.astype(np.float64)), rtol=1e-4)
     # learner with one sparse modality: the stacked matrix stays sparse (array_utils.py:5-9)
     lr = MultimodalLearner(['s', 'd'], [60, 30], [1.0, 0.5], k)
     import multimodal_amd.learner as L
@@ -630,8 +639,8 @@ def test_fp8_column_pass_agrees_with_f16_operands_and_oracle(monkeypatch, n, f, 
 def test_ratio_without_the_numerator_eps_keeps_the_reference_results(monkeypatch, n, f, k, iters, zero_frac):
     """Loops on fp8 ratio tiles over data whose mean is >= 1e5 eps form the ratio as x / (W.H + eps) (16 multiplications per
     tile fewer; NE kernels, mfma4.hip.h) instead of the reference's (x + eps) / (W.H + eps) (nmf.py:332-336): a relative eps / x
-    per element.  Zeros are stored as 2^-24 (no logarithm of a zero ratio: the loss stays finite with 30-60 % exact zeros) and
-    the loss gets sum x ln(1 + eps/x) back exactly.  Against the same loop WITH the numerator's eps (KLNMF_NE=0): losses within
+    per element.  V keeps true zeros (the ratio carries a 2^-100 addend: no logarithm of a zero ratio, the loss stays finite
+    with 30-60 % exact zeros) and the loss gets sum x ln(1 + eps/x) back exactly.  Against the same loop WITH the numerator's eps (KLNMF_NE=0): losses within
     2e-6, factors within 1e-3 of their maxima (fp8 tiles on both sides); against the oracle: the usual 1e-4."""
     X = orc.synthetic_V(21, n, f, min(k, 24))
     if zero_frac > 0:
@@ -1096,3 +1105,85 @@ def test_run_more_is_the_loop_of_klnmf_run(precision, n, f, k):
         np.testing.assert_array_equal(o[4], out[0][4])
         assert o[5] == out[0][5]
     assert out[0][5] == (iters - 2 if n > 32768 else 0)
+
+
+def test_zero_row_and_zero_column_at_fp8_size():
+    """SURVEY a3's edge case where the DEFAULT fast regime runs (>= 32 769 rows: fp8 ratio tiles from the third iteration, the
+    ratio without the numerator's eps): an all-zero ROW of V gives an exactly zero row of W (W0 = V.H0^T = 0 stays 0,
+    nmf.py:156, 342), an all-zero COLUMN stays finite -- the reference leaves ~1e-11 there (ratio eps / (W.H + eps) > 0), the
+    NE kernels exactly 0 --, every loss and the final KL within 1e-4 of the fp64 oracle.  Round 3 stored zeros as 2^-24 in
+    these problems (row of W ~1e-12 of the maximum); round 4 keeps true zeros (2^-100 addend in the ratio's multiply-add)."""
+    n, f, k, iters = 40000, 256, 40, 7
+    X = orc.synthetic_V(31, n, f, 24).copy()
+    X[np.random.RandomState(6).rand(n, f) < 0.2] = 0.0          # scattered exact zeros as well
+    zero_rows, zero_col = [5, 12345, n - 1], 77
+    X[zero_rows, :] = 0.0
+    X[:, zero_col] = 0.0
+    H0 = orc.synthetic_H0(31, f, k)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    rep = m.last_fp8_report
+    assert rep['tile_iterations'] == iters - 2 and rep['no_numerator_eps'], rep      # the regime this test is about
+    assert len(errors) == iters and np.all(np.isfinite(errors)) and np.all(np.isfinite(W)) and np.all(np.isfinite(m.components_))
+    assert np.all(W[zero_rows, :] == 0)                            # exactly, as in the reference
+    H = m.components_
+    assert np.all(H[:, zero_col] >= 0) and H[:, zero_col].max() <= 1e-9 * H.max()
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    assert np.all(Wo[zero_rows, :] == 0) and Ho[:, zero_col].max() <= 1e-8 * Ho.max()      # what the reference's rule does (~1e-11)
+    assert_allclose(errors, eo, rtol=1e-4)
+    keep = np.ones(f, bool)
+    keep[zero_col] = False
+    assert np.abs(H[:, keep] - Ho[:, keep]).max() <= 5e-3 * Ho.max()
+    assert np.abs(W - Wo).max() <= 5e-3 * Wo.max()
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(orc.kl_error(X, W.astype(np.float64), H.astype(np.float64)) - fo) <= 1e-4 * fo
+    # the same with the reference's formula kept (KLNMF_NE=0 path is covered by test_ratio_without_the_numerator_eps...)
+
+
+@pytest.mark.parametrize('n,f,k,iters', [(3000, 512, 40, 6), (70000, 256, 200, 7), (40000, 256, 50, 6), (66000, 384, 300, 5)])
+def test_one_launch_behind_the_column_pass_equals_the_separate_launches(monkeypatch, n, f, k, iters):
+    """k_post (slab sum + fix-ups + loss + stop rule + H rule + e4m3 scales in one launch, post.hip.h) against the round-3
+    sequence of launches it replaces (KLNMF_FUSE=0): the same arithmetic -- the losses bit for bit; W and H to the order of
+    the fp64 additions of a dictionary row's sum (k_post's threads take four consecutive columns each) -- at a small
+    shape (column-split update pass), with fp8 tiles + fp8 x fp8 column pass (k = 200), fp8 tiles + f16 operands (k = 50)
+    and on the component-split kernels (k = 300)."""
+    X = orc.synthetic_V(13, n, f, 12)
+    H0 = orc.synthetic_H0(13, f, k)
+    out = []
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('KLNMF_FUSE', fuse)
+        with _native.Context('f16', device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            ctx.set_v_max(float(X.max()))
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            e, nd, st = ctx.run(iters, True, 0.0)
+            out.append((np.asarray(e), nd, ctx.get_W(), ctx.get_H(), ctx.fp8_report()))
+    assert out[0][1] == out[1][1] == iters
+    assert out[0][4]['tile_iterations'] == out[1][4]['tile_iterations']
+    assert out[0][4]['column_pass_iterations'] == out[1][4]['column_pass_iterations']
+    assert_allclose(out[1][0], out[0][0], rtol=1e-9)
+    assert_allclose(out[1][2], out[0][2], rtol=1e-5, atol=1e-7 * np.abs(out[0][2]).max())
+    assert_allclose(out[1][3], out[0][3], rtol=1e-5, atol=1e-7 * np.abs(out[0][3]).max())
+
+
+def test_stop_rule_inside_the_fused_launch_matches_the_oracle():
+    """The stop rule evaluated by every block of k_post (prev from the two-entry ring, block 0 records): the same break
+    iteration, `len(errors)` and factors as the oracle's loop with a tolerance that fires mid-way (nmf.py:214-220), and the
+    dictionary handed back is the one of the last EXECUTED update (the H ping-pong is settled from n_done)."""
+    n, f, k = 3000, 256, 24
+    X = orc.synthetic_V(17, n, f, 12)
+    H0 = orc.synthetic_H0(17, f, k)
+    _, _, e_all = orc.fit_transform(X, k=k, H0=H0, max_iter=100, tol=0, warn=False)
+    desc = -np.diff(np.array(e_all)) / (n * f)                  # descent per iteration in the rule's units (nmf.py:207)
+    for i in (60, 69):
+        assert desc[i] > 1.02 * desc[i + 1] and np.all(desc[:i + 1] > desc[i + 1])      # a clear crossing, the first one
+        tol = float(np.sqrt(desc[i] * desc[i + 1]))            # between two consecutive descents: fires at iteration i + 2
+        Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=100, tol=tol, warn=False)
+        assert len(eo) == i + 2
+        for extra in (0, 1):                                     # an even / odd number of enqueued-but-skipped updates behind the stop
+            m, W, errors, _ = fit_gpu(X, H0, k, 100 + extra, tol, precision='f16')
+            assert len(errors) == len(eo), (len(errors), len(eo))
+            assert_allclose(errors, eo, rtol=1e-4)
+            assert np.abs(m.components_ - Ho).max() <= 5e-3 * Ho.max()
+            assert np.abs(W - Wo).max() <= 5e-3 * Wo.max()
