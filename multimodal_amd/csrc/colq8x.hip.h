@@ -33,18 +33,16 @@ __host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 
 // tab64 != nullptr (round 4, post.hip.h): the block maxima are combined by atomicMax into row (blockIdx & 63) of a
 // [64][KP] table instead of one row per block -- 16 blocks per address, 64 x KP addresses: no hot line -- which ONE block of
 // the launch behind the column pass turns into the next iteration's scales (w8s = those scales: computed by k_post from the
-// previous conversion's table); w8s_copy: block 0 copies the scales it converts with there, for the launches behind it.
+// previous conversion's table into the buffer the host swaps in as w8s).
 __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
                                                     const float *w8s, unsigned *w8max, const DevState *st, int *sat = nullptr,
-                                                    int probe_col = -1, unsigned *tab64 = nullptr, float *w8s_copy = nullptr) {
+                                                    int probe_col = -1, unsigned *tab64 = nullptr) {
     const int ld8 = w8_ld(kp);
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
     if (st->stop) return;
     KL_FP16_SATURATE();
     __shared__ float red[8][256 / 8 * 8];
-    if (w8s_copy != nullptr && blockIdx.x == 0)
-        for (int c = threadIdx.x; c < kp; c += blockDim.x) w8s_copy[c] = w8s[c];
     const int groups = kp / 8;                       // threads per row
     const int c8 = threadIdx.x % groups, rl = threadIdx.x / groups;
     const int rows_per_block = blockDim.x / groups;

@@ -275,7 +275,8 @@ struct klnmf_ctx {
     int64_t loop_hswaps = 0;                  // H rules enqueued since the loop's entry (how many the device executed: n_done -- fetch_results)
     float *loop_h0 = nullptr, *loop_h1 = nullptr;      // H32 / H32alt as the loop found them
     unsigned *w8tab = nullptr;                // [kW8TabRows][KP] maxima of the conversion kernel (k_post: -> w8s_next, emptied)
-    float *w8s_next = nullptr;                // [KP] scales the NEXT conversion uses
+    float *w8s_next = nullptr;                // [KP] scales of the NEXT image: k_post writes them, then w8s / w8s_next swap
+    bool tail_use8 = false;                   // KLNMF_COL8=2 on the fused tail: the image the W rule just wrote carries measured scales
     bool conv_ran = false;                    // this iteration's conversion ran: k_post derives the next scales
 
     // Column parts of the H numerator.  `whole`: all columns as one part (layout [KP][f_pad], what every single-context loop
@@ -578,15 +579,24 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.eps = (float)(kEpsRatio * c->v_scale);
     // fp8 x fp8 column pass with the image written by the W rule (KLNMF_COL8=2): this iteration's scales from the previous
     // iteration's maxima first, then the row pass writes image and maxima
-    const bool w8_here = c->w8_tail && c->W8 && store_q && mode == ROW_UPDATE && c->q8() && c->pingpong() && c->row_chunks == 1;
+    // (on the fused tail -- post.hip.h -- the maxima go to the 64-row table k_post turns into the next scales, and the image is
+    // written from the loop's second iteration on, so that the third can already multiply it)
+    const bool w8_here = c->w8_tail && c->W8 && store_q && mode == ROW_UPDATE && c->pingpong() && c->row_chunks == 1 &&
+                         (c->fused ? (c->q8_loop && c->iter_in_loop >= 1) : c->q8());
+    if (c->fused && c->w8_tail && mode == ROW_UPDATE) { c->conv_ran = false; c->tail_use8 = false; }
     if (w8_here) {
-        c->w8_use = c->w8_meas;
-        if (c->w8_meas) {
-            w8_make_scales(c, c->w8_entries);
+        if (c->fused) {
+            c->tail_use8 = c->w8_meas && c->q8();
+            a.w8tab = c->w8tab;
+        } else {
+            c->w8_use = c->w8_meas;
+            if (c->w8_meas) {
+                w8_make_scales(c, c->w8_entries);
+            }
+            a.w8max = c->w8max;
         }
         a.W8 = c->W8;
         a.w8s = c->w8s;
-        a.w8max = c->w8max;
         a.w8_sat = &c->st->w8_sat;
         a.w8_probe = w8_probe_col(c);
     }
@@ -637,15 +647,17 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                 const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
                 hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
                                    c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
-                                   c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st, &c->st->w8_sat, w8_probe_col(c));
+                                   c->fused ? (unsigned *)nullptr : c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st,
+                                   &c->st->w8_sat, w8_probe_col(c), c->fused ? c->w8tab : (unsigned *)nullptr);
                 HIPCHK(hipGetLastError());
                 c->w8_entries = t4.base.rt0 + blocks;
                 c->w8_meas = true;
+                if (c->fused) c->conv_ran = true;
             }
             if (c->profiling) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
             return;
         }
-        if (w8_here) { c->w8_entries = c->nrt; c->w8_meas = true; }
+        if (w8_here) { c->w8_entries = c->nrt; c->w8_meas = true; if (c->fused) c->conv_ran = true; }
         switch (mode) {
             case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
             case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
@@ -829,6 +841,7 @@ ColPassQArgs colq_part_args(klnmf_ctx *c, const klnmf_ctx::PartCfg &p) {
 // the e4m3 image of W_new for this iteration's fp8 x fp8 column pass (once per iteration, before the first part's pass):
 // converted with the scales k_post derived from the PREVIOUS conversion's maxima; returns whether the fp8 x fp8 pass may run
 bool fused_w8_stage(klnmf_ctx *c) {
+    if (c->w8_tail) return c->tail_use8 && c->conv_ran;      // the row pass's W rule wrote image and maxima itself (fast_rowpass)
     c->conv_ran = false;
     if (!c->W8 || !c->q8_loop) return false;
     const bool measure_only = c->iter_in_loop == 1 && !c->w8_meas;      // the loop's second iteration (16-bit tiles still)
@@ -838,8 +851,8 @@ bool fused_w8_stage(klnmf_ctx *c) {
     const int64_t rows = c->n_pad;
     const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
     hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
-                       c->KP, (int)w_ld(c->KP), (const float *)c->w8s_next, (unsigned *)nullptr, (const DevState *)c->st,
-                       &c->st->w8_sat, w8_probe_col(c), c->w8tab, c->w8s);
+                       c->KP, (int)w_ld(c->KP), (const float *)c->w8s, (unsigned *)nullptr, (const DevState *)c->st,
+                       &c->st->w8_sat, w8_probe_col(c), c->w8tab);
     HIPCHK(hipGetLastError());
     c->w8_meas = true;
     c->conv_ran = true;
@@ -923,6 +936,9 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     a.w8_block = (a.do_sum && last_sum && c->conv_ran && c->w8tab != nullptr) ? 1 : 0;
     a.last_sum = (a.do_sum && last_sum) ? 1 : 0;
     a.it = (int)(c->iter_in_loop & 1);
+    static const int post_abl = std::getenv("KLNMF_POST_ABL") ? std::atoi(std::getenv("KLNMF_POST_ABL")) : 0;      // (timing experiments only)
+    a.abl = post_abl;
+    if (post_abl & 8) { a.do_decide = 0; a.loss_from_parts = 0; }
     a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne;
     a.tol_abs = la.tol_abs; a.errors = c->errors; a.cap = c->cap;
     a.st = c->st;
@@ -950,7 +966,10 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
         c->loop_hswaps += 1;
         c->images_measured = false;
     }
-    if (a.w8_block) c->conv_ran = false;
+    if (a.w8_block) {
+        std::swap(c->w8s, c->w8s_next);      // what this launch derived is what the next image is written with
+        c->conv_ran = false;
+    }
 }
 
 void fast_colpass(klnmf_ctx *c) {
@@ -1766,7 +1785,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->stages_per_chunk = (total_stages + nch - 1) / nch;
             c->whole = klnmf_ctx::PartCfg{0, c->ncb, 0, c->nct_used, 0, (int)f, (int)c->f_pad, nch, c->stages_per_chunk, 0, 0};
             // column parts for loops on a communicator (overlap of the numerator's all-reduce with the column pass)
-            c->fused = stored_q && (c->col_gen == 2 || c->big) && !c->w8_tail &&
+            c->fused = stored_q && (c->col_gen == 2 || c->big) &&
                        !(std::getenv("KLNMF_FUSE") && std::atoi(std::getenv("KLNMF_FUSE")) == 0);
             c->nparts_cfg = 1;
             if (const char *g = std::getenv("KLNMF_COMM_PARTS")) c->nparts_cfg = std::min(kPostMaxParts, std::max(1, std::atoi(g)));

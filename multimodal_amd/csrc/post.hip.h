@@ -63,6 +63,7 @@ struct PostArgs {
     int last_sum;             // the iteration's last summing launch: its last block also clears w8_sat for the next conversion
                               // (every summing launch's last block empties the suspect list: the next part's column pass refills it)
     int it;                   // iteration index within the loop (parity of DevState.prev2)
+    int abl;                  // timing experiments (KLNMF_POST_ABL): 1 no normalisation pass, 2 no slab pass, 4 no last-block counter
     // ---- loss / stop rule
     const double2 *loss_part; int64_t loss_count; double inv_c; double *loss_xchg; int ne;
     double tol_abs; double *errors; int64_t cap;
@@ -124,7 +125,10 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
             // with image / scale <= 224 (e4m3 reaches 448).  The table is left empty for the next conversion.
             for (int c = tid; c < a.kp; c += blockDim.x) {
                 unsigned mb = 0u;
-                for (int r = 0; r < kW8TabRows; ++r) { mb = max(mb, a.w8tab[r * a.kp + c]); a.w8tab[r * a.kp + c] = 0u; }
+                const unsigned *tab = a.w8tab + c;
+#pragma unroll
+                for (int r = 0; r < kW8TabRows; ++r) mb = max(mb, tab[r * a.kp]);      // 64 independent loads, then the stores (interleaved,
+                for (int r = 0; r < kW8TabRows; ++r) a.w8tab[r * a.kp + c] = 0u;       // they were a chain of 64 round trips: 30 us for this block alone)
                 const float m = __uint_as_float(mb);
                 float s = 1.f;
                 if (m > 0.f) {
@@ -170,6 +174,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
 
     // ---- the row: slabs in fixed order -> numerator; x old dictionary -> unnormalised new row + row sum -----------------
     double s = 0;
+    if (!(a.abl & 2))
     for (int64_t j4 = 4 * (int64_t)tid; j4 < a.f_pad; j4 += 4 * (int64_t)blockDim.x) {      // this thread's four columns
         int p = 0;                                                        // the part that holds them (parts are multiples of 128 columns)
         while (p + 1 < a.nparts && j4 >= a.part[p + 1].col0) ++p;
@@ -272,12 +277,14 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         }
         __syncthreads();
     }
-    if (a.do_sum) {
+    if (a.do_sum && !(a.abl & 4)) {
         // the block that finishes last empties the suspect list for the next column pass (the next part's, the next iteration's)
         // and -- in the iteration's last summing launch -- clears the count of clipped entries of the e4m3 W image for the next
         // conversion (every block has read both by now)
         if (tid == 0) {
-            __threadfence();
+            // (no fence: every block has long consumed what it read of the list and of w8_sat when it arrives here, and the
+            // reset is ordered against the next launch by the kernel boundary -- a device-scope fence per block costs an L2
+            // write-back on this part)
             if (atomicAdd(&a.st->q8_fix_done, 1) == nb_main - 1) {
                 if (n_sus_all > kQ8ListCap) a.st->q8_unfixed += n_sus_all - kQ8ListCap;
                 a.st->q8_fix_done = 0;
@@ -286,7 +293,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
             }
         }
     }
-    if (!a.do_rule || stop_now) return;
+    if (!a.do_rule || stop_now || (a.abl & 1)) return;
     // ---- H rule (nmf.py:349-350): H * numerator, row-normalised; fp16 tile image, its row sum, the scales ----------------
     if (a.kc >= 0 && comp == 0) {
         const opnd_t ev = (opnd_t)(a.eps_pad / kCarrierW);          // x the carrier column of the W image = eps

@@ -1,33 +1,118 @@
-"""Timing of the CSR branch (next-row N3) on an Acorns-shaped problem: n x f very sparse, k components.
-Prints ms per fit iteration on the GPU (f64 / f32) and for the numpy/scipy oracle on a row sample."""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Next-row N3 with a roofline: the reference's CSR branch (nmf.py:52-70, 301-308, 331-334, 342, 349 -- SDDMM + two SpMMs per
+fit iteration, csrc/sparse.hip.h) on an Acorns-shaped matrix (HAC histograms, f = 110 000 columns, very
+sparse): 20 000 x 110 000, 0.5 % stored entries, k = 50.  Prints ONE JSON line in bench.py's shape.
+
+    python3 scripts/bench_sparse.py [--precision f64|f32] [--steps 10] [--no-cpu-baseline]
+
+Roofline (HBM-bound integer / gather work, no MFMA): the ALGORITHMIC bytes of one fit iteration are
+    stored entries:  SDDMM  nnz (idx 8 + x es + q es)   W rule  nnz (idx 8 + q es)   H rule  nnz (row 8 + perm 8 + q es)
+    gathers:         one k-vector per stored entry and product: 3 nnz k es   (rows of H^T twice, rows of W once)
+    factors:         W read by the SDDMM, read + written by the W rule, read by the column sums: 4 n k es;
+                     H: transpose (2), dots (1), numerator written (1), H rule (3), = 7 k f es
+`roofline.achieved` = those bytes / the iteration's time (the gathers are what a cache-less machine would move; on this part
+Infinity Cache / L2 serve a share of them -- `hbm_minimal_bytes` is the count without them).  CPU baseline: the scipy
+restatement of the same branch (oracle.sparse_fit_transform), fp64, on a row sample, scaled linearly in n."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 import scipy.sparse as sp
-from multimodal_amd import _native
-from oracle import klnmf_oracle as orc
 
-n, f, k, dens, iters = 20000, 110000, 50, 0.005, 10
-rs = np.random.RandomState(0)
-X = sp.random(n, f, density=dens, format='csr', random_state=rs, data_rvs=lambda s: rs.gamma(1.0, 1.0, s))
-H0 = orc.synthetic_H0(3, f, k)
-print('X %dx%d nnz %d (%.2f%%), k=%d' % (n, f, X.nnz, 100.0 * X.nnz / (n * f), k))
-for prec in ('f64', 'f32'):
-    with _native.Context(prec) as c:
-        c.set_problem_sparse(X.astype(np.float32) if prec == 'f32' else X, k, iters + 2)
-        c.set_H(H0); c.init_W()
-        c.run(2, True, 0.0)
-        c.set_H(H0); c.init_W()
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--n', type=int, default=20000)
+    ap.add_argument('--f', type=int, default=110000)
+    ap.add_argument('--k', type=int, default=50)
+    ap.add_argument('--density', type=float, default=0.005)
+    ap.add_argument('--precision', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--repeats', type=int, default=3)
+    ap.add_argument('--cpu-rows', type=int, default=2000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    from multimodal_amd import _native
+    from oracle import klnmf_oracle as orc
+    import bench
+
+    n, f, k = args.n, args.f, args.k
+    rs = np.random.RandomState(0)
+    X = sp.random(n, f, density=args.density, format='csr', random_state=rs, data_rvs=lambda s: rs.gamma(1.0, 1.0, s))
+    H0 = orc.synthetic_H0(3, f, k)
+    es = 8 if args.precision == 'f64' else 4
+    nnz = int(X.nnz)
+    seg, prof = [], None
+    with _native.Context(args.precision) as c:
+        c.set_problem_sparse(X.astype(np.float32) if es == 4 else X, k, args.steps + args.warmup)
+        for rep in range(args.repeats):
+            c.set_H(H0)
+            c.init_W()
+            c.loop_begin()
+            c.run_more(args.warmup, True, 0.0)
+            c.profile_enable(True)
+            c.synchronize()
+            t0 = time.perf_counter()
+            c.run_more(args.steps, True, 0.0)
+            c.synchronize()
+            seg.append(time.perf_counter() - t0)
+            prof = c.profile_read(reset=True)
+            c.profile_enable(False)
+            errs, nd, st = c.loop_end(args.steps + args.warmup)
+    t = sorted(seg)[len(seg) // 2] / args.steps
+    entries = nnz * ((8 + 2 * es) + (8 + es) + (16 + es))
+    gathers = 3 * nnz * k * es
+    factors = 4 * n * k * es + 7 * k * f * es
+    alg = entries + gathers + factors
+    out = {
+        'metric': 'nmf_update_iterations_per_sec', 'value': 1.0 / t, 'unit': 'it/s', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * t, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': 'KL-NMF fit iteration on CSR input (reference sparse branch), V %dx%d, %.2f %% stored (%d entries), k=%d'
+                               % (n, f, 100.0 * nnz / (n * f), nnz, k),
+                   'n': n, 'f': f, 'k': k, 'nnz': nnz, 'precision': args.precision,
+                   'generator': 'scipy.sparse.random(density=%g, RandomState(0)), Gamma(1, 1) values' % args.density,
+                   'timing': 'median of %d segments of %d iterations after %d warm-up iterations of the same loop' % (args.repeats, args.steps, args.warmup)},
+        'valid': bool(nd == args.steps + args.warmup and not st),
+        'loss_first': errs[0], 'loss_last': errs[-1],
+        'loss_finite_and_decreasing': bool(all(b < a for a, b in zip(errs, errs[1:]))),
+        'roofline': {'bound': 'hbm', 'kernel': 'the whole iteration (k_sp_q SDDMM + loss, k_sp_w, k_sp_n, dense H rule)',
+                     'achieved': alg / t / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': alg / t / 1e9 / PEAK_HBM_GBS,
+                     'traffic': None,
+                     'algorithmic_bytes': alg, 'of_which': {'stored_entries': entries, 'gathers': gathers, 'factors': factors},
+                     'hbm_minimal_bytes': entries + factors,
+                     'frac_of_hbm_minimal': (entries + factors) / t / 1e9 / PEAK_HBM_GBS},
+        'kernels': {'k_sp_q (SDDMM + loss)': {'avg_launch_ms': prof['rowpass_ms'] / max(1, prof['rowpass_launches']),
+                                               'gather_gbs': nnz * k * es / (prof['rowpass_ms'] / max(1, prof['rowpass_launches']) * 1e-3) / 1e9},
+                    'k_sp_n (W^T.Q over CSC)': {'avg_launch_ms': prof['colpass_ms'] / max(1, prof['colpass_launches']),
+                                                'gather_gbs': nnz * k * es / (prof['colpass_ms'] / max(1, prof['colpass_launches']) * 1e-3) / 1e9}},
+        'device': _native.device_info(0),
+    }
+    if not args.no_cpu_baseline:
+        host = bench.host_info()
+        rows = min(args.cpu_rows, n)
+        Xs = X[:rows]
+        orc.sparse_fit_transform(Xs, k, H0, max_iter=1, tol=0)
         t0 = time.perf_counter()
-        errs, nd, st = c.run(iters, True, 0.0)
-        dt = time.perf_counter() - t0
-        # bytes per iteration (algorithmic): SDDMM reads nnz*(k of W amortised per row + k of H^T) ...; report the simple count
-        b = X.nnz * (8 + 8 + 2 * 8) + 2 * n * k * 8 + 3 * k * f * 8
-        print('%s: %.2f ms / iteration   loss %.6e -> %.6e   (~%.1f GB/s of the minimal bytes)' % (
-            prec, 1e3 * dt / iters, errs[0], errs[-1], b / (dt / iters) / 1e9))
-rows = 2000
-Xs = X[:rows]
-t0 = time.perf_counter()
-orc.sparse_fit_transform(Xs, k, H0, max_iter=3, tol=0)
-dt = (time.perf_counter() - t0) / 3
-print('oracle (scipy, fp64) on %d rows: %.1f ms / iteration -> %.1f ms scaled to %d rows' % (rows, 1e3 * dt, 1e3 * dt * n / rows, n))
+        iters = 3
+        orc.sparse_fit_transform(Xs, k, H0, max_iter=iters, tol=0)
+        dt = (time.perf_counter() - t0) / iters
+        out['cpu_baseline'] = {'value': (1.0 / dt) * rows / n, 'unit': 'it/s', 'cores': 1, 'kind': 'port',
+                               'sample': 'rows [0, %d) of the same matrix: %d timed fp64 iterations of the scipy restatement of the '
+                                         'sparse branch (%.2f s / iteration on the sample), scaled linearly in n' % (rows, iters, dt),
+                               'cpu_model': host.get('cpu_model'), 'numpy': host.get('numpy')}
+    print(json.dumps(out))
+    sys.stderr.write('%s: %.3f ms / iteration  (%.0f GB/s of %.2f GB algorithmic = %.0f %% of the HBM roof; SDDMM %.3f ms, W^T.Q %.3f ms)\n' % (
+        args.precision, 1e3 * t, alg / t / 1e9, alg / 1e9, 100 * alg / t / 1e9 / PEAK_HBM_GBS,
+        out['kernels']['k_sp_q (SDDMM + loss)']['avg_launch_ms'], out['kernels']['k_sp_n (W^T.Q over CSC)']['avg_launch_ms']))
+
+
+if __name__ == '__main__':
+    main()

@@ -245,3 +245,80 @@ def test_bench_two_rank_rehearsal():
     assert cfg['collective_path'] == 'torch' and 'rccl_ranks' in cfg and cfg['rccl_ranks'] is None
     assert cfg['fp8']['source'] == 'klnmf_query' and cfg['fp8']['timed_iterations_with_fp8_ratio_tiles'] == 0      # 10 016 rows per rank
     assert d['dtype'] == 'f16' and d['value_16bit'] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,f,k,iters', [(3000, 1024, 40, 5), (66048, 1024, 128, 6), (40000, 768, 300, 5)])
+def test_numerator_in_column_parts_with_overlapped_all_reduce(monkeypatch, n, f, k, iters):
+    """Round 4: on a communicator the H numerator can be produced and exchanged in column parts (KLNMF_COMM_PARTS = 2 / 3), the
+    all-reduce of part p on the communicator's own stream behind an event while the column pass of part p + 1 computes, the
+    last part's all-reduce grouped with the loss on the context's stream AFTER the earlier ones have completed.  Run on a
+    one-rank communicator (KLNMF_COMM_SINGLE=1: RCCL refuses two ranks on one device; a one-rank all-reduce is the identity):
+      * overlap on == overlap off (KLNMF_COMM_OVERLAP=0: every all-reduce on the context's stream), bit for bit -- the second
+        stream and the events change nothing but the timing;
+      * parts == no parts to the order of the fp32 slab sums (each part has its own row chunks);
+    at a small shape (column-split update pass), with fp8 tiles + fp8 x fp8 column pass, and on the component-split kernels."""
+    from multimodal_amd import _native
+    monkeypatch.setenv('KLNMF_COMM_SINGLE', '1')
+    X = orc.synthetic_V(5, n, f, 12)
+    H0 = orc.synthetic_H0(5, f, k)
+    out = {}
+    for parts, overlap in ((1, 1), (2, 1), (2, 0), (3, 1)):
+        monkeypatch.setenv('KLNMF_COMM_PARTS', str(parts))
+        monkeypatch.setenv('KLNMF_COMM_OVERLAP', str(overlap))
+        with _native.Context('f16', device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
+            ctx.set_v_max(float(X.max()))
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            layout = ctx.exchange_parts()
+            assert len(layout) == min(parts, (f + 255) // 256)
+            assert sum(nc for _, _, _, nc in layout) == f and layout[0][2] == 0
+            errs, n_done, stopped = ctx.run_sharded(n, iters, True, 0.0)
+            out[(parts, overlap)] = (np.array(errs), n_done, ctx.get_W(), ctx.get_H(), ctx.fp8_report())
+            ctx.comm_destroy()
+    base = out[(1, 1)]
+    assert base[1] == iters
+    for key in ((2, 1), (2, 0), (3, 1)):
+        o = out[key]
+        assert o[1] == iters and o[4]['tile_iterations'] == base[4]['tile_iterations']
+        assert o[0][0] == base[0][0]                                  # the first loss: before any H rule, the same bits
+        np.testing.assert_allclose(o[0], base[0], rtol=1e-6)          # (later ones see H to another fp32 summation order)
+        np.testing.assert_allclose(o[2], base[2], rtol=1e-4, atol=1e-6 * np.abs(base[2]).max())
+        np.testing.assert_allclose(o[3], base[3], rtol=1e-4, atol=1e-6 * np.abs(base[3]).max())
+    for i in (0, 2, 3):
+        np.testing.assert_array_equal(out[(2, 1)][i], out[(2, 0)][i])      # overlapped == serial, bit for bit
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    np.testing.assert_allclose(out[(2, 1)][0], eo, rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_torch_path_exchanges_the_numerator_in_parts(monkeypatch, tmp_path):
+    """The torch-sequenced loop on the split layout (klnmf_exchange_parts / klnmf_iter_colpass_part): one process, no
+    collective -- the sequencing of the pieces and the layout, against the same loop unsplit."""
+    import torch
+    from multimodal_amd.distributed import ShardedKLNMF
+    n, f, k, iters = 40000, 768, 64, 6
+    X = orc.synthetic_V(8, n, f, 12)
+    H0 = orc.synthetic_H0(8, f, k)
+    res = {}
+    for parts in (1, 2):
+        monkeypatch.setenv('KLNMF_COMM_PARTS', str(parts))
+        m = ShardedKLNMF(n, n, f, k, max_iter=iters, precision='f16', collective='torch')
+        assert (m.parts is None) == (parts == 1)
+        m.set_v_max(float(X.max()))
+        m.upload_V(X)
+        m.set_H(H0)
+        m.init_W()
+        m.begin()
+        for _ in range(iters):
+            m.iterate(fit=True, tol=0.0)
+        errors, n_done, stopped = m.end()
+        res[parts] = (np.array(errors), n_done, m.get_W_local(), m.get_H())
+        m.close()
+    assert res[1][1] == res[2][1] == iters
+    np.testing.assert_allclose(res[2][0], res[1][0], rtol=1e-6)
+    np.testing.assert_allclose(res[2][2], res[1][2], rtol=1e-4, atol=1e-6 * np.abs(res[1][2]).max())
+    np.testing.assert_allclose(res[2][3], res[1][3], rtol=1e-4, atol=1e-6 * np.abs(res[1][3]).max())

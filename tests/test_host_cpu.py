@@ -215,8 +215,9 @@ def test_bench_defaults_follow_the_measurement_contract():
     a = bench.parse_args([])
     assert (a.gpus, a.n, a.f, a.k, a.precision) == (1, 1000000, 4096, 200, 'f16')       # BASELINE.json configs[3]
     assert a.tol == 0.0 and a.repeats == 5 and a.data == 'blocks'
-    # the CPU sample is the smallest context that runs fp8 ratio tiles, 1 + 7 iterations: the parity leg on it covers 6 fp8 ones
-    assert a.cpu_rows == 65536 and a.cpu_iters == 7 and a.segment_timeout > 0
+    # the CPU sample is SURVEY 8d's n = 100 000 (more than 65 536: the parity leg on it runs fp8 tiles and the fp8 x fp8 column
+    # pass), 1 + 5 iterations: about 25 s of fp64 work on the GPU box's host, 4 of the 6 GPU iterations on fp8
+    assert a.cpu_rows == 100000 and a.cpu_iters == 5 and a.segment_timeout > 0
 
 
 def test_scale_inverse_scales_W_columns_and_H_rows():
@@ -311,3 +312,24 @@ def test_every_launched_rowpass4_instantiation_is_in_the_list():
     small = set(re.findall(r'X\(KT, ODD, \d, EP, (8), (\d), (\d)\)', lst))
     big = set(re.findall(r'X\(KT, 0, \d, EP, (4), (\d), (\d)\)', lst))
     assert launched and launched <= (small | big), launched - (small | big)
+
+
+def test_csr_input_and_large_k_never_change_arithmetic_silently(capsys):
+    """Round-3 verdict: CSR input in a 16-bit mode was densified (another algorithm: off X's structure the dense ratio is
+    eps / (W.H + eps), not 0) and k > 512 went to the fp32 kernels without a word.  Both now name the arithmetic that runs,
+    once per process, on stderr; CSR input always takes the sparse kernels."""
+    from multimodal_amd.lib import nmf as nm
+    nm._NOTED.clear()
+    assert nm.sparse_precision('auto') == 'f64' and nm.sparse_precision('f64') == 'f64' and nm.sparse_precision('f32') == 'f32'
+    assert capsys.readouterr().err == ''
+    assert nm.sparse_precision('f16') == 'f32' and nm.sparse_precision('f16') == 'f32'
+    err = capsys.readouterr().err
+    assert err.count("CSR input with precision='f16' runs the reference's sparse branch") == 1
+    assert nm.resolve_precision('f16', 1000, 100, 512) == 'f16'
+    assert capsys.readouterr().err == ''
+    assert nm.resolve_precision('f16', 1000, 100, 600) == 'f32' and nm.resolve_precision('f16', 10, 10, 700) == 'f32'
+    err = capsys.readouterr().err
+    assert err.count("k = 600 runs on the fp32 kernels") == 1 and 'k = 700' not in err
+    import scipy.sparse as sp
+    m = nm.KLdivNMF(n_components=3, precision='f16')
+    assert m._sparse_route(sp.csr_matrix(np.eye(3))) and not m._sparse_route(np.eye(3))
