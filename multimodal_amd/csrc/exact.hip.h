@@ -16,66 +16,149 @@ constexpr int GT = 64;   // output tile edge
 constexpr int GK = 16;   // contraction step
 
 // C[M,N] = A[M,K] . B[K,N]; element (r,c) of A is A[r*ars + c*acs] (so a
-// transposed operand is a stride swap).  256 threads, 4x4 outputs each.
+// transposed operand is a stride swap).  256 threads, TT x TT outputs each: tiles of 64 x 64 (TT = 4) or 128 x 128 (TT = 8).
 // blockIdx.z selects a contraction chunk [z*kchunk, (z+1)*kchunk).
-template <typename T, typename Epi>
-__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const T *A, int64_t ars,
+// Round 4: with 4 x 4 outputs per thread every contraction step reads 8 operands from LDS for 16 multiply-adds -- in fp64
+// that is 128 LDS cycles for 64 VALU cycles per step and workgroup: LDS-bound at a quarter of the fp64 peak (18 TFLOP/s
+// measured), with element-wise bounds-checked staging on top.  8 x 8 outputs per thread read 16 operands for 64
+// multiply-adds (LDS and VALU time balanced) and stage a quarter of the elements per flop; tiles that do not touch a matrix
+// edge load without bounds checks; the next step's operands are prefetched into registers under the current step's
+// arithmetic.  The summation order of one output element is unchanged (k ascending within its chunk): for the same chunking
+// the results are bit-identical to the 64 x 64 tiles.  128 x 128 tiles are used where their grid still fills the chip
+// (klnmf_set_problem); measured (scripts/small_problem_timing.py): see DESIGN.md.
+// MF (fp64, 64 x 64 tiles): the inner product on v_mfma_f64_16x16x4_f64 -- wave w owns rows 16 w .. 16 w + 15 of the tile and
+// its four 16-column blocks; per 4 contraction steps one double of A and four of B per lane from the SAME LDS images (A[i][k]
+// in lane i + 16 k, B[k][j] in lane j + 16 k; result register r of lane l = D[(l >> 4) + 4 r][l & 15]: probed,
+// experiments/micro/mfma_f64_probe.hip).  Same fp64 peak as the vector pipe on this part, a sixth of the LDS reads and a
+// sixteenth of the instructions: the VALU form is LDS-bound at a quarter of that peak.  Round 1 had tried it and found no
+// gain (526 vs 540 us at 2000 x 4096, k = 200) because the bounds-checked synchronous staging bound the kernel then.
+template <typename T, typename Epi, int TT = 4, bool MF = false>
+__global__ __launch_bounds__(256, (TT == 4 ? 3 : 2)) void k_gemm(int M, int N, int K, const T *A, int64_t ars,
                                               int64_t acs, const T *B, int64_t brs, int64_t bcs,
                                               int kchunk, const DevState *st, Epi epi) {
     if (st && st->stop) return;
-    __shared__ T As[GK][GT + 4];
-    __shared__ T Bs[GK][GT + 4];
+    constexpr int TL = 16 * TT;             // tile edge
+    __shared__ T As[GK][TL + 4];
+    __shared__ T Bs[GK][TL + 4];
     __shared__ double red[16];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int m0 = blockIdx.y * TL, n0 = blockIdx.x * TL;
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
-    T acc[4][4];
+    T acc[TT][TT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
+        for (int j = 0; j < TT; ++j) acc[i][j] = T(0);
+    typedef __attribute__((ext_vector_type(4))) double d4_t;
+    d4_t accm[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accm[t] = d4_t{0.0, 0.0, 0.0, 0.0};
 
     const bool a_k_contig = (acs == 1);   // consecutive threads walk the contiguous axis
     const bool b_n_contig = (bcs == 1);
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    const bool m_inside = m0 + TL <= M, n_inside = n0 + TL <= N;      // (uniform) this tile's rows of A / columns of B all exist
+    // The next contraction step's operands are requested into registers BEFORE this step's arithmetic and written to LDS
+    // behind it: the global latency runs under 16 x TT x TT multiply-adds per thread instead of in front of them (rounds
+    // 1-3: load -> LDS -> barrier -> compute -> barrier, the latency exposed at every step).
+    constexpr int PER = TL * GK / 256;      // elements of A (and of B) per thread and step
+    T ra[PER], rb[PER];
+    auto fetch = [&](int k0) {
+        const bool k_inside = k0 + GK <= kend;
 #pragma unroll
-        for (int e = tid; e < GT * GK; e += 256) {
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 256 * u;
             int m, kk;
-            if (a_k_contig) { kk = e % GK; m = e / GK; } else { m = e % GT; kk = e / GT; }
+            if (a_k_contig) { kk = e % GK; m = e / GK; } else { m = e % TL; kk = e / TL; }
             const int gm = m0 + m, gk = k0 + kk;
-            As[kk][m] = (gm < M && gk < kend) ? A[gm * ars + gk * acs] : T(0);
+            if (m_inside && k_inside) ra[u] = A[(int64_t)gm * ars + (int64_t)gk * acs];
+            else ra[u] = (gm < M && gk < kend) ? A[(int64_t)gm * ars + (int64_t)gk * acs] : T(0);
         }
 #pragma unroll
-        for (int e = tid; e < GT * GK; e += 256) {
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 256 * u;
             int n, kk;
-            if (b_n_contig) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
+            if (b_n_contig) { n = e % TL; kk = e / TL; } else { kk = e % GK; n = e / GK; }
             const int gn = n0 + n, gk = k0 + kk;
-            Bs[kk][n] = (gn < N && gk < kend) ? B[gk * brs + gn * bcs] : T(0);
+            if (n_inside && k_inside) rb[u] = B[(int64_t)gk * brs + (int64_t)gn * bcs];
+            else rb[u] = (gn < N && gk < kend) ? B[(int64_t)gk * brs + (int64_t)gn * bcs] : T(0);
         }
-        __syncthreads();
+    };
+    auto commit = [&]() {
 #pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 256 * u;
+            int m, kk;
+            if (a_k_contig) { kk = e % GK; m = e / GK; } else { m = e % TL; kk = e / TL; }
+            As[kk][m] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 256 * u;
+            int n, kk;
+            if (b_n_contig) { n = e % TL; kk = e / TL; } else { kk = e % GK; n = e / GK; }
+            Bs[kk][n] = rb[u];
+        }
+    };
+    if (kbeg < kend) { fetch(kbeg); commit(); }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        const bool more = k0 + GK < kend;
+        constexpr bool PREF = !(sizeof(T) == 8 && TT == 8);      // (fp64 with 8 x 8 outputs: 128 accumulator registers leave no room for the prefetch)
+        if (PREF && more) fetch(k0 + GK);
+        if constexpr (MF) {
+            static_assert(!MF || (sizeof(T) == 8 && TT == 4), "fp64 MFMA inner product: 64 x 64 tiles");
+            const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+            for (int k4 = 0; k4 < GK / 4; ++k4) {
+                const double av = (double)As[4 * k4 + (lane >> 4)][16 * wv + (lane & 15)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double bv = (double)Bs[4 * k4 + (lane >> 4)][16 * t + (lane & 15)];
+                    accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accm[t], 0, 0, 0);
+                }
+            }
+        } else {
+        constexpr int UNR = TT == 8 ? 2 : 4;
+#pragma unroll UNR
         for (int kk = 0; kk < GK; ++kk) {
-            T a[4], b[4];
+            T a[TT], b[TT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+            for (int i = 0; i < TT; ++i) a[i] = As[kk][ty * TT + i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+            for (int j = 0; j < TT; ++j) b[j] = Bs[kk][tx * TT + j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+                for (int j = 0; j < TT; ++j) acc[i][j] += a[i] * b[j];
+        }
         }
         __syncthreads();
+        if (more) {
+            if (!PREF) fetch(k0 + GK);
+            commit();
+            __syncthreads();
+        }
     }
+    if constexpr (MF) {
+        const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = m0 + ty * 4 + i, c = n0 + tx * 4 + j;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = m0 + 16 * wv + (lane >> 4) + 4 * rr, c = n0 + 16 * t + (lane & 15);
+                if (r < M && c < N) epi.apply(r, c, (T)accm[t][rr]);
+            }
+    } else {
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int r = m0 + ty * TT + i, c = n0 + tx * TT + j;
             if (r < M && c < N) epi.apply(r, c, acc[i][j]);
         }
+    }
     epi.finish(red);
 }
 

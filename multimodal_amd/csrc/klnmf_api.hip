@@ -203,6 +203,7 @@ struct klnmf_ctx {
     int64_t loss_part_count = 0;
     int nsplit = 1, kchunk = 0;
     int wsplit = 1, wchunk = 0;       // exact modes: feature chunks of the W rule's contraction (few rows), slabs in Wpart
+    int q_tt = 4, w_tt = 4, n_tt = 4; // exact modes: outputs per thread and axis of the three GEMMs (k_gemm: 4 = 64 x 64 tiles, 8 = 128 x 128)
     void *Wpart = nullptr;
 
     // CSR input in the exact modes (sparse.hip.h): structure of X in CSR and CSC order, ratio values, H^T
@@ -607,7 +608,15 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     const bool v16 = c->prec == KLNMF_PREC_BF16;
     if (c->pingpong()) {                               // ping-pong schedule (mfma4.hip.h), fp16 V only
         RowPass4Args a4{a, c->Ht4};
-        const int nw = c->big ? 4 : kWaves4;
+        int nw = c->big ? 4 : kWaves4;
+        // KLNMF_ROW_RPW=N (experiment): N < 8 row tiles per 8-wave workgroup, its last waves idling, so that one round of
+        // workgroups covers more CUs (C2: 196 -> 224 workgroups of 7).  Measured round 4: no gain (row pass 0.135 vs 0.133 ms;
+        // 6 tiles -- two rounds -- 0.185): such a pass is bound by the HBM stream as a whole (4.9 TB/s), not by the number of
+        // CUs that pull on it.  Off unless asked for.
+        if (const char *g = std::getenv("KLNMF_ROW_RPW")) {
+            const int w = std::min(nw, std::max(0, std::atoi(g)));
+            if (w > 0 && !c->big && c->row_chunks == 1 && c->tail_wg == 0) { a4.base.rpw = w; nw = w; }
+        }
         const int grid4 = (c->nrt + nw - 1) / nw;
         if (mode == ROW_UPDATE && c->row_chunks > 1) {     // few rows: column chunks in blockIdx.y, W rule from the slabs
             a4.base.gpart = c->Gpart;
@@ -1071,14 +1080,21 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
                        (T *)c->HT, c->k, c->f, (const DevState *)c->st);
 #define KL_SPQ_ARGS (const int64_t *)c->sp_indptr, (const int64_t *)c->sp_indices, (const T *)c->sp_data, \
         (const T *)c->W[c->cur], (const T *)c->HT, (T *)c->sp_q, c->sp_row_loss, c->k, (T)eps, write_q, (const DevState *)c->st
-    switch ((int)((c->k + 63) / 64)) {
-        case 1: hipLaunchKernelGGL((k_sp_q<T, 1>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
-        case 2: hipLaunchKernelGGL((k_sp_q<T, 2>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
-        case 3: case 4: hipLaunchKernelGGL((k_sp_q<T, 4>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
-        case 5: case 6: case 7: case 8:
-            hipLaunchKernelGGL((k_sp_q<T, 8>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
-        default: hipLaunchKernelGGL((k_sp_q_anyk<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS); break;
-    }
+    // fp64: 32 entries per trip (half the registers, twice the waves per SIMD: sparse.hip.h); KLNMF_SPQ_NB=64 keeps 64
+    static const bool nb64 = std::getenv("KLNMF_SPQ_NB") && std::atoi(std::getenv("KLNMF_SPQ_NB")) == 64;
+    constexpr int NBD = sizeof(T) == 8 ? 32 : 64;
+    const int kc = (int)((c->k + 63) / 64);
+#define KL_SPQ_LAUNCH(KCV)                                                                                              \
+    do {                                                                                                                \
+        if (nb64) hipLaunchKernelGGL((k_sp_q<T, KCV, 64>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);   \
+        else hipLaunchKernelGGL((k_sp_q<T, KCV, NBD>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);      \
+    } while (0)
+    if (kc <= 1) KL_SPQ_LAUNCH(1);
+    else if (kc == 2) KL_SPQ_LAUNCH(2);
+    else if (kc <= 4) KL_SPQ_LAUNCH(4);
+    else if (kc <= 8) KL_SPQ_LAUNCH(8);
+    else hipLaunchKernelGGL((k_sp_q_anyk<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);
+#undef KL_SPQ_LAUNCH
 #undef KL_SPQ_ARGS
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
@@ -1091,21 +1107,36 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
     HIPCHK(hipGetLastError());
 }
 
+// k_gemm with 64 x 64 (tt = 4) or 128 x 128 (tt = 8) tiles
+// ... fp64 with 64 x 64 tiles: the inner product on the fp64 MFMA (KLNMF_GEMM_MFMA=0: the VALU form)
+static bool gemm_mfma64() {
+    static const bool on = !(std::getenv("KLNMF_GEMM_MFMA") && std::atoi(std::getenv("KLNMF_GEMM_MFMA")) == 0);
+    return on;
+}
+#define KL_GEMM_TT(tt, T, EPI, grid, stream, ...)                                                          \
+    do {                                                                                                   \
+        if ((tt) == 8) hipLaunchKernelGGL((k_gemm<T, EPI, 8>), grid, dim3(256), 0, stream, __VA_ARGS__);    \
+        else if (sizeof(T) == 8 && gemm_mfma64())                                                          \
+            hipLaunchKernelGGL((k_gemm<T, EPI, 4, sizeof(T) == 8>), grid, dim3(256), 0, stream, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((k_gemm<T, EPI, 4>), grid, dim3(256), 0, stream, __VA_ARGS__);              \
+    } while (0)
+
 template <typename T>
 void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
     if (c->sparse) { sparse_Q<T>(c, write_q, eps); return; }
     EpiQ<T> epi{(const T *)c->V, (T *)c->Q, c->f, c->loss_part, write_q, 0.0, (T)eps};
-    dim3 grid((unsigned)((c->f + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), 1);
+    const int TL = 16 * c->q_tt;
+    dim3 grid((unsigned)((c->f + TL - 1) / TL), (unsigned)((c->n + TL - 1) / TL), 1);
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
-    hipLaunchKernelGGL((k_gemm<T, EpiQ<T>>), grid, dim3(256), 0, c->stream, (int)c->n, (int)c->f,
-                       (int)c->k, (const T *)c->W[c->cur], (int64_t)c->k, (int64_t)1,
-                       (const T *)c->H, (int64_t)c->f, (int64_t)1, (int)c->k + GK,
-                       (const DevState *)c->st, epi);
+    KL_GEMM_TT(c->q_tt, T, EpiQ<T>, grid, c->stream, (int)c->n, (int)c->f,
+               (int)c->k, (const T *)c->W[c->cur], (int64_t)c->k, (int64_t)1,
+               (const T *)c->H, (int64_t)c->f, (int64_t)1, (int)c->k + GK,
+               (const DevState *)c->st, epi);
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     hipLaunchKernelGGL(k_sum_doubles, dim3(1), dim3(1024), 0, c->stream,
-                       (const double *)c->loss_part, c->loss_part_count, c->loss_xchg,
+                       (const double *)c->loss_part, (int64_t)grid.x * grid.y, c->loss_xchg,
                        (const DevState *)c->st);
     HIPCHK(hipGetLastError());
 }
@@ -1123,10 +1154,11 @@ void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
     }
     if (c->wsplit > 1) {     // few rows: contraction over f split into chunks (blockIdx.z), W rule from the slabs
         EpiWpart<T> epip{(T *)c->Wpart, c->k, c->n * c->k};
-        dim3 gridp((unsigned)((c->k + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), (unsigned)c->wsplit);
-        hipLaunchKernelGGL((k_gemm<T, EpiWpart<T>>), gridp, dim3(256), 0, c->stream, (int)c->n, (int)c->k,
-                           (int)c->f, (const T *)qsrc, (int64_t)c->f, (int64_t)1, (const T *)c->H,
-                           (int64_t)1, (int64_t)c->f, c->wchunk, (const DevState *)c->st, epip);
+        const int TLw = 16 * c->w_tt;
+        dim3 gridp((unsigned)((c->k + TLw - 1) / TLw), (unsigned)((c->n + TLw - 1) / TLw), (unsigned)c->wsplit);
+        KL_GEMM_TT(c->w_tt, T, EpiWpart<T>, gridp, c->stream, (int)c->n, (int)c->k,
+                   (int)c->f, (const T *)qsrc, (int64_t)c->f, (int64_t)1, (const T *)c->H,
+                   (int64_t)1, (int64_t)c->f, c->wchunk, (const DevState *)c->st, epip);
         HIPCHK(hipGetLastError());
         const int64_t count = c->n * c->k;
         hipLaunchKernelGGL((k_wrule_exact<T>), dim3(grid_for(count)), dim3(256), 0, c->stream, (const T *)c->Wpart,
@@ -1136,10 +1168,11 @@ void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
         return;
     }
     EpiW<T> epi{(const T *)c->W[c->cur], (T *)c->W[c->cur ^ 1], c->k, multiply};
-    dim3 grid((unsigned)((c->k + GT - 1) / GT), (unsigned)((c->n + GT - 1) / GT), 1);
-    hipLaunchKernelGGL((k_gemm<T, EpiW<T>>), grid, dim3(256), 0, c->stream, (int)c->n, (int)c->k,
-                       (int)c->f, (const T *)qsrc, (int64_t)c->f, (int64_t)1, (const T *)c->H,
-                       (int64_t)1, (int64_t)c->f, (int)c->f + GK, (const DevState *)c->st, epi);
+    const int TLw = 16 * c->w_tt;
+    dim3 grid((unsigned)((c->k + TLw - 1) / TLw), (unsigned)((c->n + TLw - 1) / TLw), 1);
+    KL_GEMM_TT(c->w_tt, T, EpiW<T>, grid, c->stream, (int)c->n, (int)c->k,
+               (int)c->f, (const T *)qsrc, (int64_t)c->f, (int64_t)1, (const T *)c->H,
+               (int64_t)1, (int64_t)c->f, (int)c->f + GK, (const DevState *)c->st, epi);
     HIPCHK(hipGetLastError());
 }
 
@@ -1158,13 +1191,14 @@ void exact_N(klnmf_ctx *c, int widx) {
         return;
     }
     EpiN<T> epi{(T *)c->Npart, c->f, c->k * c->f};
-    dim3 grid((unsigned)((c->f + GT - 1) / GT), (unsigned)((c->k + GT - 1) / GT), (unsigned)c->nsplit);
+    const int TLn = 16 * c->n_tt;
+    dim3 grid((unsigned)((c->f + TLn - 1) / TLn), (unsigned)((c->k + TLn - 1) / TLn), (unsigned)c->nsplit);
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_col);
-    hipLaunchKernelGGL((k_gemm<T, EpiN<T>>), grid, dim3(256), 0, c->stream, (int)c->k, (int)c->f,
-                       (int)c->n, (const T *)c->W[widx], (int64_t)1, (int64_t)c->k,
-                       (const T *)c->Q, (int64_t)c->f, (int64_t)1, c->kchunk,
-                       (const DevState *)c->st, epi);
+    KL_GEMM_TT(c->n_tt, T, EpiN<T>, grid, c->stream, (int)c->k, (int)c->f,
+               (int)c->n, (const T *)c->W[widx], (int64_t)1, (int64_t)c->k,
+               (const T *)c->Q, (int64_t)c->f, (int64_t)1, c->kchunk,
+               (const DevState *)c->st, epi);
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     const int64_t count = c->k * c->f;
@@ -1635,11 +1669,27 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->W[0] = c->dalloc((size_t)n * k * es);
             c->W[1] = c->dalloc((size_t)n * k * es);
             c->H = c->dalloc((size_t)k * f * es);
-            const int64_t tiles = ((k + GT - 1) / GT) * ((f + GT - 1) / GT);
-            int64_t s = (4 * (int64_t)c->cu_count + tiles - 1) / tiles;
+            // 128 x 128 output tiles (8 x 8 per thread: k_gemm) where both output dimensions are long enough to fill them;
+            // KLNMF_GEMM_TT=4 keeps the 64 x 64 tiles of rounds 1-3 everywhere
+            const bool tt4 = std::getenv("KLNMF_GEMM_TT") && std::atoi(std::getenv("KLNMF_GEMM_TT")) == 4;
+            const bool tt8 = std::getenv("KLNMF_GEMM_TT") && std::atoi(std::getenv("KLNMF_GEMM_TT")) == 8;      // (force, for A/B runs)
+            auto tiles_of = [](int64_t M, int64_t N, int64_t TL) { return ((M + TL - 1) / TL) * ((N + TL - 1) / TL); };
+            // ... i.e. where the grid of 128 x 128 tiles (times the contraction split, if the GEMM has one) still covers the chip
+            // Measured (profiles/r04_exact_modes.txt): with the register prefetch the 64 x 64 tiles win at every shape tried
+            // (2000 x 4096, k = 200, fp64: 440 us per iteration against 455 with 128 x 128 tiles, 537 before): four waves per
+            // SIMD hide more than the halved LDS traffic gains.  128 x 128 tiles only on request (KLNMF_GEMM_TT=8).
+            (void)tt4;
+            c->q_tt = (tt8 && n >= 96 && f >= 96) ? 8 : 4;
             const int64_t smax = (n + 63) / 64;          // at least four contraction steps per chunk
-            if (s > smax) s = smax;
-            if (s < 1) s = 1;
+            auto n_split = [&](int tt) {
+                const int64_t tiles = tiles_of(k, f, 16 * tt);
+                int64_t s = ((tt == 8 ? 2 : 4) * (int64_t)c->cu_count + tiles - 1) / tiles;
+                if (s > smax) s = smax;
+                if (s < 1) s = 1;
+                return s;
+            };
+            c->n_tt = (tt8 && k >= 96 && f >= 96) ? 8 : 4;
+            int64_t s = n_split(c->n_tt);
             int64_t chunk = (n + s - 1) / s;
             chunk = (chunk + GK - 1) / GK * GK;
             s = (n + chunk - 1) / chunk;
@@ -1650,8 +1700,13 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // W rule: n*k/4096 output tiles, each contracting over all of f.  With fewer tiles than CUs split f so that
             // the grid covers the chip about twice (KLNMF_W_SPLIT = 0 / N forces it off / to N chunks).
             {
-                const int64_t wtiles = ((k + GT - 1) / GT) * ((n + GT - 1) / GT);
-                int64_t ws = wtiles < c->cu_count ? (2 * (int64_t)c->cu_count + wtiles - 1) / wtiles : 1;
+                auto w_split = [&](int tt) {
+                    const int64_t wt = tiles_of(k, n, 16 * tt);
+                    int64_t w = wt < c->cu_count ? ((tt == 8 ? 1 : 2) * (int64_t)c->cu_count + wt - 1) / wt : 1;
+                    return std::min<int64_t>(w, (f + 4 * GK - 1) / (4 * GK));
+                };
+                c->w_tt = (tt8 && n >= 96 && k >= 96) ? 8 : 4;
+                int64_t ws = w_split(c->w_tt);
                 if (const char *g = std::getenv("KLNMF_W_SPLIT")) ws = std::max(1, std::atoi(g));
                 ws = std::min<int64_t>(ws, (f + 4 * GK - 1) / (4 * GK));
                 while (ws > 1 && ws * n * k * (int64_t)es > ((int64_t)256 << 20)) --ws;

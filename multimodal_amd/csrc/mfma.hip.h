@@ -272,6 +272,10 @@ struct RowPassArgs {
     float *gpart;
     int ct_chunk;
     int wg0, rt0;
+    // row tiles per workgroup of the ping-pong pass (0 = its wave count).  One round of workgroups that leaves CUs idle
+    // (50 000 rows = 196 workgroups of 8 row tiles on 256 CUs) is spread over more of them with 7, 6, ... row tiles per
+    // workgroup, the workgroup's last waves idling: such problems are HBM-bound per CU (klnmf_api.hip, fast_rowpass)
+    int rpw;
     // fp8 x fp8 column pass (colq8x.hip.h): the W rule also leaves the e4m3 image of W_new (f16 image / w8s[component],
     // exactly as k_w8_from_wb converts it) and this wave's column maxima of the f16 image; null: not written
     unsigned char *W8;

@@ -282,8 +282,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // MI355X_MICROARCH.md, two waves per SIMD, item 4), set once, never flipped: row pass 4.33 -> 4.13 ms at C4, same bits
     // (profiles/r02_ab_static_priority.txt; 1, 2 and 3 measure the same; per-segment flips were no gain in round 1).
     if (KL_STATIC_PRIO > 0 && grpY) __builtin_amdgcn_s_setprio(KL_STATIC_PRIO);
-    const int rt_raw = ((int)blockIdx.x + a.wg0) * kWaves4 + wave;
-    const bool active = rt_raw < a.nrt;
+    const int rpw = a.rpw > 0 ? a.rpw : kWaves4;                      // row tiles per workgroup (scalar)
+    const int rt_raw = ((int)blockIdx.x + a.wg0) * rpw + wave;
+    const bool active = wave < rpw && rt_raw < a.nrt;
     const int rt = active ? rt_raw : a.nrt - 1;
 
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
@@ -548,7 +549,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
 #else
                 // (a VALU write of the data registers of a store wider than 8 bytes needs a wait state after its issue:
                 // hipcc pads its own stores, nobody pads an asm statement -- cf. DESIGN.md section 8, h4 and h9 vii)
-                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp_s) : "memory");
+#ifndef KL_Q8_ST_MOD
+#define KL_Q8_ST_MOD " nt"       // experiment -DKL_Q8_ST_MOD='""': cacheable ratio-tile stores (could a small problem's tiles stay in Infinity Cache?)
+#endif
+                asm volatile("global_store_dwordx4 %0, %1, %2" KL_Q8_ST_MOD "\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp_s) : "memory");
 #endif
 #endif
                 return;

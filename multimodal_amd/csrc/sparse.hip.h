@@ -72,33 +72,42 @@ struct LaneTransposeSum<T, 1> {
 // lane walks a different row of H^T; one entry at a time with a wave reduction and lane 0 taking the
 // logarithm 2.7 ms -- the fp64 log of one lane costs the wave as much as 64 of them; this version: see
 // DESIGN 4.5.)
-template <typename T, int KC>      // KC = ceil(k / 64) <= 8
+// NB = entries per trip: 64 (all lanes end up with one dot product) or 32 (round 4, fp64: the 64 partial-product vectors of
+// a trip are 128 registers, the kernel had 170 and ran two waves per SIMD -- every wave a serial chain of index load, 64
+// gathers, reduction, logarithm with nobody to cover its latencies: 2.07 ms for 11 M entries = 2.1 TB/s of gathers where the
+// same gathers in k_sp_w run at 6.5 TB/s.  With 32 entries per trip the dot products end up twice, in both lane halves (one
+// more exchange), the lower half takes division and logarithm; half the registers per trip, twice the waves per SIMD).
+template <typename T, int KC, int NB = 64>      // KC = ceil(k / 64) <= 8
 __global__ __launch_bounds__(64) void k_sp_q(const int64_t *indptr, const int64_t *indices, const T *data, const T *W,
                                               const T *HT, T *q, double *row_loss, int64_t k, T eps, int write_q,
                                               const DevState *st) {
+    static_assert(NB == 64 || NB == 32, "entries per trip");
     if (st && st->stop) return;
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
+    const int el = lane & (NB - 1);            // the entry of the trip this lane ends up with
     T w[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) w[c] = (64 * c + lane < k) ? W[i * k + 64 * c + lane] : T(0);
     double local = 0;
     const int64_t p0 = indptr[i], p1 = indptr[i + 1];
-    for (int64_t p = p0; p < p1; p += 64) {
-        const bool mine = p + lane < p1;
-        const int64_t my_j = mine ? indices[p + lane] : 0;      // past the end: row 0 of H^T, result unused
-        T part[64];
+    for (int64_t p = p0; p < p1; p += NB) {
+        const bool mine = lane < NB && p + lane < p1;
+        const bool have = p + el < p1;
+        const int64_t my_j = have ? indices[p + el] : 0;      // past the end: row 0 of H^T, result unused
+        const T x = mine ? data[p + lane] : T(0);              // (requested with the indices: one round trip, not two)
+        T part[NB];
 #pragma unroll
-        for (int u = 0; u < 64; ++u) {
+        for (int u = 0; u < NB; ++u) {
             const T *h = HT + lane_value(my_j, u) * k;
             part[u] = T(0);
 #pragma unroll
             for (int c = 0; c < KC; ++c)
                 if (64 * c + lane < k) part[u] += w[c] * h[64 * c + lane];
         }
-        const T wh = LaneTransposeSum<T, 64>::run(part, lane);
+        T wh = LaneTransposeSum<T, NB>::run(part, lane);
+        if (NB == 32) wh += __shfl_xor(wh, 32);                // the two lane halves each summed their own 32 lanes
         if (mine) {
-            const T x = data[p + lane];
             const T qq = (x + eps) / (wh + eps);
             if (write_q) q[p + lane] = qq;
             local += (double)(x * log(qq)) - (double)x;

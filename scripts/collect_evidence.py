@@ -8,7 +8,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 G = os.path.join(R, 'gpurun_out', tag)
 P = os.path.join(R, 'profiles')
@@ -40,6 +40,9 @@ if os.path.exists(os.path.join(G, 'pmc_c4', 'traffic.json')):
     conv = [k for k in t4 if k.startswith('k_w8')]
     if conv:
         kern['k_w8_from_wb'] = t4[conv[0]]
+    post = [k for k in t4 if k.startswith('k_post')]
+    if post:
+        kern['k_post'] = t4[post[0]]
     if split in t4:
         kern[split] = t4[split]
     if slabs:

@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs|k_w8_from_wb')
+pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs|k_w8_from_wb|k_post')
 
 
 def short(name):
@@ -63,11 +63,17 @@ for k in sorted(vals):
 import json
 traffic = {}
 for kname in vals:
-    if 'k_rowpass' in kname and 'mode=0' in kname or kname.startswith('k_colpass') or kname.startswith('k_wrule_slabs') or kname.startswith('k_w8'):
+    if 'k_rowpass' in kname and 'mode=0' in kname or kname.startswith('k_colpass') or kname.startswith('k_wrule_slabs') or kname.startswith('k_w8') or kname.startswith('k_post'):
         fs = vals[kname].get('FETCH_SIZE'); ws = vals[kname].get('WRITE_SIZE')
         if fs and ws:
             traffic[kname] = {'fetch_bytes_corrected': 2 * 1024 * sum(fs) / len(fs),
                               'write_bytes': 1024 * sum(ws) / len(ws),
                               'hbm_bytes_per_launch': 2 * 1024 * sum(fs) / len(fs) + 1024 * sum(ws) / len(ws)}
+            # the shader clock the kernel held: GRBM_GUI_ACTIVE counts busy cycles summed over the 8 XCDs (an in-run cycle
+            # count, unlike sysfs clocks sampled from outside), divided by the kernel's mean duration under the PMC passes
+            ga, d = vals[kname].get('GRBM_GUI_ACTIVE'), durs.get(kname, [])
+            if ga and d:
+                traffic[kname]['sclk_mhz_from_grbm_gui_active'] = (sum(ga) / len(ga)) / 8.0 / (sum(d) / len(d) * 1e-3) / 1e6
+                traffic[kname]['mean_duration_ms_under_pmc'] = sum(d) / len(d)
 json.dump(traffic, open(os.path.join(root, 'traffic.json'), 'w'), indent=1)
 print('traffic', json.dumps(traffic))
