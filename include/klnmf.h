@@ -7,9 +7,11 @@
  * every function returns an int status (0 = ok, <0 = error class) and the
  * message for the calling thread is available from klnmf_last_error().
  *
- * One context = one GPU (one process per GPU in the multi-GPU case; the
- * collective between shards is issued by the host between klnmf_iter_* calls,
- * see INTEGRATION.md).  A context is used from one thread at a time; different
+ * One context = one GPU (one process per GPU in the multi-GPU case).  The
+ * collective between row shards is issued INSIDE the library on the native path
+ * (klnmf_comm_init + klnmf_run_sharded / klnmf_run_more: RCCL over xGMI), or by
+ * the caller between the klnmf_iter_* pieces (e.g. torch.distributed); see
+ * INTEGRATION.md.  A context is used from one thread at a time; different
  * contexts may be used from different threads.  All calls are asynchronous on
  * the context's stream unless they return data to the host.
  *

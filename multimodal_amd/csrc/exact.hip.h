@@ -26,7 +26,7 @@ constexpr int GK = 16;   // contraction step
 // arithmetic.  The summation order of one output element is unchanged (k ascending within its chunk): for the same chunking
 // the results are bit-identical to the 64 x 64 tiles.  128 x 128 tiles are used where their grid still fills the chip
 // (klnmf_set_problem); measured (scripts/small_problem_timing.py): see DESIGN.md.
-// MF (fp64, 64 x 64 tiles): the inner product on v_mfma_f64_16x16x4_f64 -- wave w owns rows 16 w .. 16 w + 15 of the tile and
+// MF (64 x 64 tiles): the inner product on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 -- wave w owns rows 16 w .. 16 w + 15 of the tile and
 // its four 16-column blocks; per 4 contraction steps one double of A and four of B per lane from the SAME LDS images (A[i][k]
 // in lane i + 16 k, B[k][j] in lane j + 16 k; result register r of lane l = D[(l >> 4) + 4 r][l & 15]: probed,
 // experiments/micro/mfma_f64_probe.hip).  Same fp64 peak as the vector pipe on this part, a sixth of the LDS reads and a
@@ -52,9 +52,11 @@ __global__ __launch_bounds__(256, (TT == 4 ? 3 : 2)) void k_gemm(int M, int N, i
 #pragma unroll
         for (int j = 0; j < TT; ++j) acc[i][j] = T(0);
     typedef __attribute__((ext_vector_type(4))) double d4_t;
+    typedef __attribute__((ext_vector_type(4))) float f4_t;
     d4_t accm[4];
+    f4_t accf[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) accm[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < 4; ++t) { accm[t] = d4_t{0.0, 0.0, 0.0, 0.0}; accf[t] = f4_t{0.f, 0.f, 0.f, 0.f}; }
 
     const bool a_k_contig = (acs == 1);   // consecutive threads walk the contiguous axis
     const bool b_n_contig = (bcs == 1);
@@ -108,15 +110,16 @@ __global__ __launch_bounds__(256, (TT == 4 ? 3 : 2)) void k_gemm(int M, int N, i
         constexpr bool PREF = !(sizeof(T) == 8 && TT == 8);      // (fp64 with 8 x 8 outputs: 128 accumulator registers leave no room for the prefetch)
         if (PREF && more) fetch(k0 + GK);
         if constexpr (MF) {
-            static_assert(!MF || (sizeof(T) == 8 && TT == 4), "fp64 MFMA inner product: 64 x 64 tiles");
+            static_assert(!MF || TT == 4, "MFMA inner product: 64 x 64 tiles");
             const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
             for (int k4 = 0; k4 < GK / 4; ++k4) {
-                const double av = (double)As[4 * k4 + (lane >> 4)][16 * wv + (lane & 15)];
+                const T av = As[4 * k4 + (lane >> 4)][16 * wv + (lane & 15)];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const double bv = (double)Bs[4 * k4 + (lane >> 4)][16 * t + (lane & 15)];
-                    accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accm[t], 0, 0, 0);
+                    const T bv = Bs[4 * k4 + (lane >> 4)][16 * t + (lane & 15)];
+                    if constexpr (sizeof(T) == 8) accm[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accm[t], 0, 0, 0);
+                    else accf[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accf[t], 0, 0, 0);      // (same operand / result layout)
                 }
             }
         } else {
@@ -147,8 +150,9 @@ __global__ __launch_bounds__(256, (TT == 4 ? 3 : 2)) void k_gemm(int M, int N, i
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int r = m0 + 16 * wv + (lane >> 4) + 4 * rr, c = n0 + 16 * t + (lane & 15);
-                if (r < M && c < N) epi.apply(r, c, (T)accm[t][rr]);
+                // result register rr of lane l: fp64 D[(l >> 4) + 4 rr][l & 15] (probed); fp32 D[4 (l >> 4) + rr][l & 15]
+                const int r = m0 + 16 * wv + (sizeof(T) == 8 ? (lane >> 4) + 4 * rr : 4 * (lane >> 4) + rr), c = n0 + 16 * t + (lane & 15);
+                if (r < M && c < N) epi.apply(r, c, sizeof(T) == 8 ? (T)accm[t][rr] : (T)accf[t][rr]);
             }
     } else {
 #pragma unroll
@@ -256,6 +260,37 @@ __global__ __launch_bounds__(256) void k_update_H(T *H, const T *num, int64_t f,
     __syncthreads();
     const T d = (T)(kEpsNorm + total);
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
+}
+
+// The same rule for long rows (round 4: the CSR problems have f = 110 000 columns and k = 50 components -- 50 blocks walked
+// 880 KB each, three dependent passes: 0.33 ms of a 3.3 ms iteration): the row in S segments, two launches, no communication
+// inside a launch.  k_update_H_part: H * num written back + the segment's fp64 partial sum; k_update_H_norm: every block adds
+// the row's S partial sums in the same fixed order and divides its segment.
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_H_part(T *H, const T *num, int64_t f, int64_t seg, double *part, const DevState *st) {
+    if (st && st->stop) return;
+    __shared__ double red[16];
+    const int64_t a = blockIdx.y, j0 = blockIdx.x * seg, j1 = min(f, j0 + seg);
+    T *row = H + a * f;
+    const T *nrow = num + a * f;
+    double s = 0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const T v = row[j] * nrow[j];
+        row[j] = v;
+        s += (double)v;
+    }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) part[a * gridDim.x + blockIdx.x] = t;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_H_norm(T *H, int64_t f, int64_t seg, const double *part, const DevState *st) {
+    if (st && st->stop) return;
+    const int64_t a = blockIdx.y, j0 = blockIdx.x * seg, j1 = min(f, j0 + seg);
+    double total = 0;
+    for (unsigned z = 0; z < gridDim.x; ++z) total += part[a * gridDim.x + z];      // (every thread: the same order, the same bits)
+    const T d = (T)(kEpsNorm + total);
+    T *row = H + a * f;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) row[j] = row[j] / d;
 }
 
 // Sum of `count` doubles in a fixed order (deterministic), one block.

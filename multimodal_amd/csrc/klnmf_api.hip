@@ -213,6 +213,8 @@ struct klnmf_ctx {
     void *sp_data = nullptr, *sp_q = nullptr, *HT = nullptr;
     double *sp_row_loss = nullptr, *sp_wpart = nullptr, *sp_prod = nullptr;
     int64_t sp_nblk = 0;
+    double *hpart = nullptr;          // exact modes, long rows: [k][hseg_n] partial row sums of the H rule / of the CSR loss term
+    int hseg_n = 1; int64_t hseg = 0; // segments per dictionary row and their length (1: the one-block-per-row kernels)
 
     // bf16 modes
     int KT = 0, KP = 0, ks = 0;
@@ -1100,15 +1102,23 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     hipLaunchKernelGGL((k_sp_colsum_part<T>), dim3((unsigned)c->sp_nblk), dim3(256), 0, c->stream,
                        (const T *)c->W[c->cur], c->sp_wpart, c->n, c->k, (const DevState *)c->st);
-    hipLaunchKernelGGL((k_sp_dots<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (const double *)c->sp_wpart,
-                       c->sp_nblk, (const T *)c->H, c->k, c->f, c->sp_prod, (const DevState *)c->st);
+    if (c->hseg_n > 1) {
+        hipLaunchKernelGGL((k_sp_hsum_part<T>), dim3((unsigned)c->hseg_n, (unsigned)c->k), dim3(256), 0, c->stream, (const T *)c->H,
+                           c->f, c->hseg, c->hpart, (const DevState *)c->st);
+        hipLaunchKernelGGL((k_sp_dots<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (const double *)c->sp_wpart,
+                           c->sp_nblk, (const T *)c->H, c->k, c->f, c->sp_prod, (const DevState *)c->st, (const double *)c->hpart,
+                           c->hseg_n);
+    } else {
+        hipLaunchKernelGGL((k_sp_dots<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (const double *)c->sp_wpart,
+                           c->sp_nblk, (const T *)c->H, c->k, c->f, c->sp_prod, (const DevState *)c->st);
+    }
     hipLaunchKernelGGL(k_sp_loss, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sp_row_loss, c->n,
                        (const double *)c->sp_prod, c->k, c->loss_xchg, (const DevState *)c->st);
     HIPCHK(hipGetLastError());
 }
 
 // k_gemm with 64 x 64 (tt = 4) or 128 x 128 (tt = 8) tiles
-// ... fp64 with 64 x 64 tiles: the inner product on the fp64 MFMA (KLNMF_GEMM_MFMA=0: the VALU form)
+// ... 64 x 64 tiles: the inner product on the fp64 / fp32 MFMA (KLNMF_GEMM_MFMA=0: the VALU form)
 static bool gemm_mfma64() {
     static const bool on = !(std::getenv("KLNMF_GEMM_MFMA") && std::atoi(std::getenv("KLNMF_GEMM_MFMA")) == 0);
     return on;
@@ -1116,8 +1126,8 @@ static bool gemm_mfma64() {
 #define KL_GEMM_TT(tt, T, EPI, grid, stream, ...)                                                          \
     do {                                                                                                   \
         if ((tt) == 8) hipLaunchKernelGGL((k_gemm<T, EPI, 8>), grid, dim3(256), 0, stream, __VA_ARGS__);    \
-        else if (sizeof(T) == 8 && gemm_mfma64())                                                          \
-            hipLaunchKernelGGL((k_gemm<T, EPI, 4, sizeof(T) == 8>), grid, dim3(256), 0, stream, __VA_ARGS__);  \
+        else if (gemm_mfma64())                                                                            \
+            hipLaunchKernelGGL((k_gemm<T, EPI, 4, true>), grid, dim3(256), 0, stream, __VA_ARGS__);         \
         else hipLaunchKernelGGL((k_gemm<T, EPI, 4>), grid, dim3(256), 0, stream, __VA_ARGS__);              \
     } while (0)
 
@@ -1210,8 +1220,15 @@ void exact_N(klnmf_ctx *c, int widx) {
 
 template <typename T>
 void exact_H(klnmf_ctx *c) {
-    hipLaunchKernelGGL((k_update_H<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H,
-                       (const T *)c->numer, c->f, (const DevState *)c->st);
+    if (c->hseg_n > 1) {          // long rows: S segments per row, two launches (exact.hip.h)
+        hipLaunchKernelGGL((k_update_H_part<T>), dim3((unsigned)c->hseg_n, (unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H,
+                           (const T *)c->numer, c->f, c->hseg, c->hpart, (const DevState *)c->st);
+        hipLaunchKernelGGL((k_update_H_norm<T>), dim3((unsigned)c->hseg_n, (unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H,
+                           c->f, c->hseg, (const double *)c->hpart, (const DevState *)c->st);
+    } else {
+        hipLaunchKernelGGL((k_update_H<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H,
+                           (const T *)c->numer, c->f, (const DevState *)c->st);
+    }
     HIPCHK(hipGetLastError());
 }
 
@@ -1652,6 +1669,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         c->free_all();
         c->Gpart = nullptr; c->row_chunks = 1; c->tail_wg = 0; c->tail_chunks = 1;
         c->Wpart = nullptr; c->wsplit = 1;
+        c->hseg_n = 1; c->hpart = nullptr;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
         c->sparse = false;
@@ -1696,6 +1714,9 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->nsplit = (int)s;
             c->kchunk = (int)chunk;
             c->Npart = c->dalloc((size_t)s * k * f * es);
+            c->hseg = 4096;          // dictionary rows of 16 384 columns and more: the H rule in segments (exact_H)
+            c->hseg_n = f >= 16384 ? (int)((f + c->hseg - 1) / c->hseg) : 1;
+            c->hpart = c->hseg_n > 1 ? (double *)c->dalloc(sizeof(double) * (size_t)k * c->hseg_n) : nullptr;
             c->numer = c->dalloc((size_t)k * f * es);
             // W rule: n*k/4096 output tiles, each contracting over all of f.  With fewer tiles than CUs split f so that
             // the grid covers the chip about twice (KLNMF_W_SPLIT = 0 / N forces it off / to N chunks).
@@ -1966,7 +1987,11 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         c->sp_data = c->dalloc((size_t)(nnz > 0 ? nnz : 1) * es);
         c->sp_q = c->dalloc((size_t)(nnz > 0 ? nnz : 1) * es);
         c->sp_row_loss = (double *)c->dalloc(sizeof(double) * n);
-        c->sp_nblk = (n + 255) / 256;
+        c->sp_nblk = (n + kSpColsumRows - 1) / kSpColsumRows;
+        // dictionary rows of 16 384 columns and more: the H rule and the loss term's row sums in segments of 4096
+        c->hseg = 4096;
+        c->hseg_n = f >= 16384 ? (int)((f + c->hseg - 1) / c->hseg) : 1;
+        c->hpart = c->hseg_n > 1 ? (double *)c->dalloc(sizeof(double) * (size_t)k * c->hseg_n) : nullptr;
         c->sp_wpart = (double *)c->dalloc(sizeof(double) * c->sp_nblk * k);
         c->sp_prod = (double *)c->dalloc(sizeof(double) * k);
         reset_state(c);

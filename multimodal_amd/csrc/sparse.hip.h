@@ -219,11 +219,13 @@ __global__ __launch_bounds__(256) void k_sp_n(const int64_t *csc_indptr, const i
     }
 }
 
-// Column sums of W in two fixed-order stages: part[b][a] over row blocks of 256, then over b.
+// Column sums of W in two fixed-order stages: part[b][a] over row blocks of kSpColsumRows, then over b.  (32 rows per block
+// since round 4: with k = 50 only 50 threads of a block work, and 79 blocks of 256 rows left them a serial walk of 100 us.)
+constexpr int kSpColsumRows = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_colsum_part(const T *W, double *part, int64_t n, int64_t k, const DevState *st) {
     if (st && st->stop) return;
-    const int64_t r0 = blockIdx.x * 256, r1 = min(n, r0 + 256);
+    const int64_t r0 = blockIdx.x * (int64_t)kSpColsumRows, r1 = min(n, r0 + kSpColsumRows);
     for (int64_t a = threadIdx.x; a < k; a += blockDim.x) {
         double s = 0;
         for (int64_t i = r0; i < r1; ++i) s += (double)W[i * k + a];
@@ -231,14 +233,30 @@ __global__ __launch_bounds__(256) void k_sp_colsum_part(const T *W, double *part
     }
 }
 
-// prod[a] = colsum(W)_a * rowsum(H)_a ; one block per component, fixed order.
+// Row sums of H in S segments (long rows: one block per component walked 880 KB at f = 110 000): hpart[a][s].
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_hsum_part(const T *H, int64_t f, int64_t seg, double *hpart, const DevState *st) {
+    if (st && st->stop) return;
+    __shared__ double red[16];
+    const int64_t a = blockIdx.y, j0 = blockIdx.x * seg, j1 = min(f, j0 + seg);
+    double hs = 0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) hs += (double)H[a * f + j];
+    const double t = block_sum(hs, red);
+    if (threadIdx.x == 0) hpart[a * gridDim.x + blockIdx.x] = t;
+}
+
+// prod[a] = colsum(W)_a * rowsum(H)_a ; one block per component, fixed order.  hpart != nullptr: the row sum from its S
+// segment sums (k_sp_hsum_part) instead of a walk over the row.
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_dots(const double *wpart, int64_t nblk, const T *H, int64_t k, int64_t f,
-                                                  double *prod, const DevState *st) {
+                                                  double *prod, const DevState *st, const double *hpart = nullptr, int S = 0) {
     if (st && st->stop) return;
     __shared__ double red[16];
     const int64_t a = blockIdx.x;
     double hs = 0, ws = 0;
+    if (hpart != nullptr) {
+        if (threadIdx.x == 0) for (int z = 0; z < S; ++z) hs += hpart[a * S + z];
+    } else
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) hs += (double)H[a * f + j];
     for (int64_t b = threadIdx.x; b < nblk; b += blockDim.x) ws += wpart[b * k + a];
     const double hsum = block_sum(hs, red);
