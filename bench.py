@@ -83,41 +83,85 @@ class Watchdog(object):
         return False
 
 
+SAMPLER_HELPER = r"""
+import json, subprocess, sys, time
+card = sys.argv[1]
+samples, on = [], False
+import select
+def num(v):
+    return float(str(v).strip('()').lower().replace('mhz', ''))
+while True:
+    r, _, _ = select.select([sys.stdin], [], [], 0.05 if on else 1.0)
+    if r:
+        cmd = sys.stdin.readline().strip()
+        if cmd == 'start':
+            on = True
+        elif cmd == 'stop' or cmd == '':
+            break
+    if on:
+        try:
+            out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showuse', '--json'], capture_output=True,
+                                 text=True, timeout=5).stdout
+            c = json.loads(out[out.index('{'):]).get(card, {})
+            power = [num(v) for kk, v in c.items() if 'power' in kk.lower()]
+            samples.append((power[0] if power else None, num(c.get('sclk clock speed:')), num(c.get('GPU use (%)', 0))))
+        except Exception:
+            pass
+print(json.dumps(samples))
+"""
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library into this process (with --pmc it initialises the GPU before main): no helper
+    processes may be started from here then (the pool refuses an exec from a process that has initialised the GPU)."""
+    return 'rocprofiler' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+
+
 class PowerClockSampler(object):
-    """Socket power and shader clock of this rank's card while the timed segments run (rocm-smi from a
-    helper thread, back to back: sysfs reads, no GPU context of its own).  The 2.5 PFLOP/s the roofline divides by assume 2.4 GHz; under this
-    workload the part sits at its board power limit and holds 1.5-1.6 GHz, so the line also says what the kernel reaches of the
-    peak AT THE HELD CLOCK.  Purely informative: any failure (no rocm-smi, unreadable fields) leaves the fields None."""
+    """Socket power and shader clock of this rank's card while the timed segments run.  The samples come from a HELPER PROCESS
+    (a loop around rocm-smi: sysfs reads, no GPU context of its own) that is started at the very top of main(), BEFORE this
+    process touches the GPU, and told over a pipe when to sample: nothing is fork+exec'ed from a process that has initialised
+    the GPU.  The 2.5 PFLOP/s the roofline divides by assume 2.4 GHz; under this workload the part sits at its board power
+    limit and holds 1.5-1.6 GHz.  Purely informative (`held_clock`, outside `roofline`): any failure leaves the fields None."""
     NOMINAL_MHZ = 2400.0
 
     def __init__(self, card):
-        import threading
-        self.card, self.samples, self.stop_flag = 'card%d' % card, [], threading.Event()
-        self.thread = threading.Thread(target=self.loop)
-        self.thread.daemon = True
-
-    def loop(self):
-        import subprocess
-        while not self.stop_flag.is_set():
-            try:
-                out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showuse', '--json'], capture_output=True,
-                                     text=True, timeout=5).stdout
-                c = json.loads(out[out.index('{'):]).get(self.card, {})
-                num = lambda v: float(str(v).strip('()').lower().replace('mhz', ''))
-                power = [num(v) for kk, v in c.items() if 'power' in kk.lower()]
-                self.samples.append((power[0] if power else None, num(c.get('sclk clock speed:')), num(c.get('GPU use (%)', 0))))
-            except Exception:
-                pass
-            self.stop_flag.wait(0.05)
+        self.samples, self.proc = [], None
+        if under_profiler():
+            return
+        try:
+            import subprocess
+            self.proc = subprocess.Popen([sys.executable, '-c', SAMPLER_HELPER, 'card%d' % card], stdin=subprocess.PIPE,
+                                         stdout=subprocess.PIPE, text=True)
+        except Exception:
+            self.proc = None
 
     def __enter__(self):
-        self.thread.start()
+        try:
+            if self.proc is not None:
+                self.proc.stdin.write('start\n')
+                self.proc.stdin.flush()
+        except Exception:
+            pass
         return self
 
     def __exit__(self, *exc):
-        self.stop_flag.set()
-        self.thread.join(timeout=10)
+        try:
+            if self.proc is not None:
+                out, _ = self.proc.communicate('stop\n', timeout=15)
+                self.samples = [tuple(x) for x in json.loads(out.strip().splitlines()[-1])]
+        except Exception:
+            try:
+                self.proc.kill()
+            except Exception:
+                pass
+        self.proc = None
         return False
+
+    def close(self):
+        """(a run that never sampled: end the helper)"""
+        if self.proc is not None:
+            self.__exit__()
 
     def summary(self):
         busy = [(p, c) for p, c, u in self.samples if u >= 50 and p is not None and c is not None]
@@ -127,7 +171,8 @@ class PowerClockSampler(object):
         return {'samples_used': len(busy), 'socket_power_w_median': ps[len(ps) // 2], 'socket_power_w_max': ps[-1],
                 'sclk_mhz_median': cs[len(cs) // 2], 'sclk_mhz_min': cs[0], 'sclk_mhz_max': cs[-1],
                 'nominal_sclk_mhz': self.NOMINAL_MHZ, 'samples_total': len(self.samples),
-                'source': 'rocm-smi --showpower --showclocks --showuse, back to back during the timed segments (samples at >= 50 % use)'}
+                'source': 'rocm-smi --showpower --showclocks --showuse from a helper process started before this one touched '
+                          'the GPU, back to back during the timed segments (samples at >= 50 % use)'}
 
 
 def parse_args(argv=None):
@@ -362,6 +407,8 @@ def gpu_parity_on_sample(args, sample):
 
 def main():
     args = parse_args()
+    # (the power / clock helper is a child process: it must exist before anything here initialises the GPU)
+    sampler0 = PowerClockSampler(int(os.environ.get('LOCAL_RANK', '0'))) if int(os.environ.get('RANK', '0')) == 0 else None
     import torch
     import torch.distributed as dist
     from multimodal_amd.distributed import ShardedKLNMF, row_partition
@@ -467,8 +514,8 @@ def main():
             fp8 = model.ctx.fp8_report()
         return segments, fits, prof_tot, tail_rows, fp8
 
-    if rank == 0:          # (one sampler per job: rank 0's card)
-        with PowerClockSampler(local_rank) as sampler:
+    if rank == 0 and sampler0 is not None:          # (one sampler per job: rank 0's card)
+        with sampler0 as sampler:
             segments, fits, prof_tot, tail_rows, fp8 = run_segments(args.repeats)
         power_clock = sampler.summary()
     else:

@@ -10,6 +10,6 @@ for i in $(seq 1 $ROUNDS); do
     lib=$R/ab/libklnmf_$tag.so; [ "$tag" = base ] && lib=$R/multimodal_amd/csrc/libklnmf.so
     ( export KLNMF_LIB=$lib; for kv in ${envs//,/ }; do export $kv; done
       python3 $R/bench.py --steps 20 --warmup 3 --repeats 1 --data device --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python3 -c "
-import json,sys;d=json.loads(sys.stdin.read());print('$e round $i: %.1f it/s  step %.3f ms  row %.3f  col %.3f  valid %s  loss_last %.6e'%(d['value'],d['ms_per_step'],d['roofline']['avg_launch_ms'],[v for kk, v in d['kernels'].items() if kk.startswith('k_colpass')][0]['avg_launch_ms'],d['valid'],d['loss_last']))" )
+import json,sys;d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]);print('$e round $i: %.1f it/s  step %.3f ms  row %.3f  col %.3f  valid %s  loss_last %.6e'%(d['value'],d['ms_per_step'],d['roofline']['avg_launch_ms'],[v for kk, v in d['kernels'].items() if kk.startswith('k_colpass')][0]['avg_launch_ms'],d['valid'],d['loss_last']))" )
   done
 done

@@ -324,3 +324,49 @@ def test_torch_path_exchanges_the_numerator_in_parts(monkeypatch, tmp_path):
     # side: single entries of W differ by the fp8 tiles' own step, the bulk by 1e-6)
     np.testing.assert_allclose(res[2][2], res[1][2], rtol=1e-3, atol=1e-5 * np.abs(res[1][2]).max())
     np.testing.assert_allclose(res[2][3], res[1][3], rtol=1e-3, atol=1e-5 * np.abs(res[1][3]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('parts', [1, 2])
+def test_exact_fix_ups_on_the_collective_path(monkeypatch, parts):
+    """Ratios beyond the fp8 tiles' range (spikes the model cannot follow) on the path row shards take: the fix-ups run in
+    k_post's SUMMING launch -- per column part, before the numerator is exchanged -- with the dictionary's old master, not in
+    the launch that applies the H rule.  One-rank communicator (KLNMF_COMM_SINGLE=1), whole matrix and two column parts
+    (512 columns: the spikes sit in both parts); the result must be what the single-context loop gives and keep the oracle's
+    1e-4, with every saturated entry counted and none left unfixed."""
+    from multimodal_amd import _native
+    monkeypatch.setenv('KLNMF_COMM_SINGLE', '1')
+    monkeypatch.setenv('KLNMF_COMM_PARTS', str(parts))
+    n, f, k, iters = 70000, 512, 200, 8
+    rs = np.random.RandomState(5)
+    X = orc.synthetic_V(13, n, f, 12)
+    X[:, f // 2:] = 1e-4 * rs.random_sample((n, f - f // 2))
+    X[:, 100:140] = 1e-4 * rs.random_sample((n, 40))
+    spikes = [(100, 103), (7000, 139), (30001, f // 2 + 64), (65999, f - 40)]
+    for (i, j) in spikes:
+        X[i, j] = 100.0 * X.mean()
+    H0 = orc.synthetic_H0(13, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    fo = orc.kl_error(X, Wo, Ho)
+    out = []
+    for native in (False, True):
+        with _native.Context('f16', device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            if native:
+                ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
+            ctx.set_v_max(float(X.max()))
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            errs, n_done, stopped = (ctx.run_sharded(n, iters, True, 0.0) if native else ctx.run(iters, True, 0.0))
+            out.append((np.array(errs), ctx.get_W(), ctx.get_H(), ctx.fp8_report()))
+            if native:
+                ctx.comm_destroy()
+    for e, W, H, rep in out:
+        assert rep['tile_iterations'] == iters - 2 and rep['ratio_saturated'] >= len(spikes) and rep['ratio_unfixed'] == 0, rep
+        np.testing.assert_allclose(e, eo, rtol=1e-4)
+        assert abs(orc.kl_error(X, W.astype(np.float64), H.astype(np.float64)) - fo) <= 1e-4 * fo
+    cols = sorted({j for _, j in spikes})
+    scale = Ho.max()
+    assert np.abs(out[1][2][:, cols] - out[0][2][:, cols]).max() <= 2e-3 * scale        # the spikes' dictionary columns: same correction
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-5)
