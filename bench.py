@@ -407,6 +407,12 @@ def gpu_parity_on_sample(args, sample):
 
 def main():
     args = parse_args()
+    # stdout carries ONE JSON line and nothing else: libraries write there too (RCCL prints a version banner at the first
+    # communicator of a process, to fd 1), so everything before the line goes to stderr -- fd 1 is parked on fd 2 until rank 0
+    # prints its result
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     # (the power / clock helper is a child process: it must exist before anything here initialises the GPU)
     sampler0 = PowerClockSampler(int(os.environ.get('LOCAL_RANK', '0'))) if int(os.environ.get('RANK', '0')) == 0 else None
     import torch
@@ -737,8 +743,11 @@ def main():
                 out['parity'] = gpu_parity_on_sample(args, sample)
             except Exception as e:   # parity is reported, never hidden
                 out['parity'] = {'error': str(e)}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out))
         sys.stdout.flush()
+        os.dup2(2, 1)
     model.close()
     if world > 1:
         dist.barrier()
