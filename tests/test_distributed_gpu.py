@@ -370,3 +370,38 @@ def test_exact_fix_ups_on_the_collective_path(monkeypatch, parts):
     scale = Ho.max()
     assert np.abs(out[1][2][:, cols] - out[0][2][:, cols]).max() <= 2e-3 * scale        # the spikes' dictionary columns: same correction
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('parts', [1, 2])
+def test_stop_rule_on_the_collective_path_breaks_where_the_oracle_does(monkeypatch, parts):
+    """The stop rule of row shards rides in k_post's RULE launch behind the all-reduce (every block evaluates it from the
+    exchanged loss, block 0 records): a tolerance that fires mid-way must break at the oracle's iteration (nmf.py:214-220,
+    tol x n_total x f), `len(errors)` equal, and the dictionary handed back must be the one of the last executed update
+    (the H ping-pong is settled from n_done) -- for an even and an odd number of launches enqueued behind the break."""
+    from multimodal_amd import _native
+    monkeypatch.setenv('KLNMF_COMM_SINGLE', '1')
+    monkeypatch.setenv('KLNMF_COMM_PARTS', str(parts))
+    n, f, k = 3000, 512, 24
+    X = orc.synthetic_V(17, n, f, 12)
+    H0 = orc.synthetic_H0(17, f, k)
+    _, _, e_all = orc.fit_transform(X, k=k, H0=H0, max_iter=100, tol=0, warn=False)
+    desc = -np.diff(np.array(e_all)) / (n * f)
+    i = next(j for j in range(40, 95) if desc[j] > 1.02 * desc[j + 1] and np.all(desc[:j + 1] > np.sqrt(desc[j] * desc[j + 1])))
+    tol = float(np.sqrt(desc[i] * desc[i + 1]))             # between two consecutive descents, below every earlier one
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=100, tol=tol, warn=False)
+    assert len(eo) == i + 2
+    for extra in (0, 1):
+        with _native.Context('f16', device=0) as ctx:
+            ctx.set_problem(n, f, k, 100 + extra)
+            ctx.comm_init(_native.Context.comm_unique_id(), 0, 1)
+            ctx.set_v_max(float(X.max()))
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            errs, n_done, stopped = ctx.run_sharded(n, 100 + extra, True, tol)
+            W, H = ctx.get_W(), ctx.get_H()
+            ctx.comm_destroy()
+        assert stopped and n_done == len(eo) == len(errs), (n_done, len(eo))
+        np.testing.assert_allclose(errs, eo, rtol=1e-4)
+        assert np.abs(H - Ho).max() <= 5e-3 * Ho.max() and np.abs(W - Wo).max() <= 5e-3 * Wo.max()
