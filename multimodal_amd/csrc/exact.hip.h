@@ -293,15 +293,61 @@ __global__ __launch_bounds__(256) void k_update_H_norm(T *H, int64_t f, int64_t 
     for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) row[j] = row[j] / d;
 }
 
+// The stop rule of nmf.py:214-220 behind a one-block loss reduction (single-context loops of the exact modes: k_decide as a
+// launch of its own is a seventh of a small problem's iteration).
+struct DecideArgs {
+    int on;                   // 0: the loss only (it is exchanged or read by the caller; the rule follows elsewhere)
+    DevState *st_rw;
+    double tol_abs;
+    double *errors;
+    int64_t cap;
+};
+__device__ __forceinline__ void decide_here(const DecideArgs &d, double err) {
+    if (!d.on) return;
+    if (d.st_rw->prev_err - err < d.tol_abs) {
+        d.st_rw->stop = 1;
+        return;
+    }
+    d.st_rw->prev_err = err;
+    d.st_rw->prev2[0] = err; d.st_rw->prev2[1] = err;
+    if (d.st_rw->n_done < d.cap) d.errors[d.st_rw->n_done] = err;
+    d.st_rw->n_done += 1;
+}
+
 // Sum of `count` doubles in a fixed order (deterministic), one block.
 __global__ __launch_bounds__(1024) void k_sum_doubles(const double *part, int64_t count,
-                                                      double *out, const DevState *st) {
+                                                      double *out, const DevState *st,
+                                                      DecideArgs dec = DecideArgs{0, nullptr, 0.0, nullptr, 0}) {
     if (st && st->stop) return;
     __shared__ double red[16];
     double s = 0;
     for (int64_t e = threadIdx.x; e < count; e += blockDim.x) s += part[e];
     const double t = block_sum(s, red);
-    if (threadIdx.x == 0) { out[0] = t; out[1] = 0; }
+    if (threadIdx.x == 0) { out[0] = t; out[1] = 0; decide_here(dec, t); }
+}
+
+// The H rule straight from the row chunks' slabs (single-context loops): num[j] = sum_z part[z][a][j] in k_sum_partials'
+// order, then exactly k_update_H -- one launch instead of two, the same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_H_slabs(T *H, const T *part, int nslab, int64_t slab, int64_t f, const DevState *st) {
+    if (st && st->stop) return;
+    __shared__ double red[16];
+    __shared__ double total;
+    T *row = H + blockIdx.x * f;
+    const T *prow = part + blockIdx.x * f;
+    double s = 0;
+    for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
+        T nj = T(0);
+        for (int z = 0; z < nslab; ++z) nj += prow[z * slab + j];
+        const T v = row[j] * nj;
+        row[j] = v;
+        s += (double)v;
+    }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) total = t;
+    __syncthreads();
+    const T d = (T)(kEpsNorm + total);
+    for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
 }
 
 // V[row0+i, col0+j] = scale * src[i, j]  (learner.py:53-56 fused into the upload).

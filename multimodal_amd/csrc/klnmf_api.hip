@@ -1074,7 +1074,7 @@ void poll_fp8_overflow(klnmf_ctx *c, bool agreed = false) {
 // ------------------------------------------------------------ exact pieces ---
 // CSR input: ratio on the stored entries + loss (nmf.py:301-308, 331-334)
 template <typename T>
-void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
+void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
     const int64_t hk = c->k * c->f;
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
@@ -1113,7 +1113,7 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps) {
                            c->sp_nblk, (const T *)c->H, c->k, c->f, c->sp_prod, (const DevState *)c->st);
     }
     hipLaunchKernelGGL(k_sp_loss, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sp_row_loss, c->n,
-                       (const double *)c->sp_prod, c->k, c->loss_xchg, (const DevState *)c->st);
+                       (const double *)c->sp_prod, c->k, c->loss_xchg, (const DevState *)c->st, dec);
     HIPCHK(hipGetLastError());
 }
 
@@ -1131,9 +1131,10 @@ static bool gemm_mfma64() {
         else hipLaunchKernelGGL((k_gemm<T, EPI, 4>), grid, dim3(256), 0, stream, __VA_ARGS__);              \
     } while (0)
 
+// dec.on: the stop rule rides in the one-block loss reduction (single-context loops: no k_decide launch)
 template <typename T>
-void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
-    if (c->sparse) { sparse_Q<T>(c, write_q, eps); return; }
+void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio, DecideArgs dec = DecideArgs{0, nullptr, 0.0, nullptr, 0}) {
+    if (c->sparse) { sparse_Q<T>(c, write_q, eps, dec); return; }
     EpiQ<T> epi{(const T *)c->V, (T *)c->Q, c->f, c->loss_part, write_q, 0.0, (T)eps};
     const int TL = 16 * c->q_tt;
     dim3 grid((unsigned)((c->f + TL - 1) / TL), (unsigned)((c->n + TL - 1) / TL), 1);
@@ -1147,7 +1148,7 @@ void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio) {
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
     hipLaunchKernelGGL(k_sum_doubles, dim3(1), dim3(1024), 0, c->stream,
                        (const double *)c->loss_part, (int64_t)grid.x * grid.y, c->loss_xchg,
-                       (const DevState *)c->st);
+                       (const DevState *)c->st, dec);
     HIPCHK(hipGetLastError());
 }
 
@@ -1186,9 +1187,9 @@ void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
     HIPCHK(hipGetLastError());
 }
 
-// numer = W[widx]^T . Q
+// numer = W[widx]^T . Q   (sum_slabs = false: the dense row chunks' slabs are left for exact_H to sum: single-context loops)
 template <typename T>
-void exact_N(klnmf_ctx *c, int widx) {
+void exact_N(klnmf_ctx *c, int widx, bool sum_slabs = true) {
     if (c->sparse) {        // W^T . Q, one block per feature column (CSC order)
         EventPair evs{};
         if (c->profiling) evs = begin_event(c, c->ev_col);
@@ -1211,6 +1212,7 @@ void exact_N(klnmf_ctx *c, int widx) {
                (const DevState *)c->st, epi);
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (!sum_slabs) return;
     const int64_t count = c->k * c->f;
     hipLaunchKernelGGL((k_sum_partials<T>), dim3(grid_for(count)), dim3(256), 0, c->stream,
                        (const T *)c->Npart, (T *)c->numer, count, c->nsplit,
@@ -1219,7 +1221,13 @@ void exact_N(klnmf_ctx *c, int widx) {
 }
 
 template <typename T>
-void exact_H(klnmf_ctx *c) {
+void exact_H(klnmf_ctx *c, bool from_slabs = false) {
+    if (from_slabs) {             // (dense, short rows: the rule sums the row chunks' slabs itself -- the same bits, one launch less)
+        hipLaunchKernelGGL((k_update_H_slabs<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H, (const T *)c->Npart,
+                           c->nsplit, c->k * c->f, c->f, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     if (c->hseg_n > 1) {          // long rows: S segments per row, two launches (exact.hip.h)
         hipLaunchKernelGGL((k_update_H_part<T>), dim3((unsigned)c->hseg_n, (unsigned)c->k), dim3(256), 0, c->stream, (T *)c->H,
                            (const T *)c->numer, c->f, c->hseg, c->hpart, (const DevState *)c->st);
@@ -1251,12 +1259,18 @@ void reset_state(klnmf_ctx *c) {
     HIPCHK(hipGetLastError());
 }
 
+void piece_decide(klnmf_ctx *c, double tol_abs);
 // fused_tol != nullptr (klnmf_run): the stop rule rides in the loss kernel of the bf16 modes (no k_decide launch)
 void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr, bool defer_to_post = false) {
     // the W rule is the same for fit and transform (nmf.py:251-253); a fit also keeps the ratios for the H rule
     if (c->is_exact()) {
-        EXACT_CALL(c, exact_Q, 1);
+        // fused_tol (single-context loops): the stop rule in the loss reduction's launch, no k_decide (KLNMF_EXACT_FUSE=0: apart)
+        static const bool xfuse = !(std::getenv("KLNMF_EXACT_FUSE") && std::atoi(std::getenv("KLNMF_EXACT_FUSE")) == 0);
+        DecideArgs dec{0, nullptr, 0.0, nullptr, 0};
+        if (fused_tol && xfuse) dec = DecideArgs{1, c->st, *fused_tol, c->errors, c->cap};
+        EXACT_CALL(c, exact_Q, 1, kEpsRatio, dec);
         EXACT_CALL(c, exact_W, c->sparse ? c->sp_q : c->Q, 1);
+        if (fused_tol && !xfuse) piece_decide(c, *fused_tol);
     } else {
         const bool measured = c->images_measured;
         fast_rowpass(c, ROW_UPDATE, fit);
@@ -1333,7 +1347,17 @@ void piece_update_H(klnmf_ctx *c) {
 // column pass + everything behind it of a single-context fit iteration (the row pass has run; its loss partials and the
 // tolerance ride in c->pending_loss when the stop rule is deferred to here)
 void piece_fit_tail(klnmf_ctx *c) {
-    if (c->is_exact() || !c->fused) {
+    if (c->is_exact()) {
+        static const bool xfuse = !(std::getenv("KLNMF_EXACT_FUSE") && std::atoi(std::getenv("KLNMF_EXACT_FUSE")) == 0);
+        // the H rule sums the row chunks' slabs itself where that is a few thousand loads per row (the reference's own data
+        // scale: one launch less of 7); beyond, one block per row walking the slabs is slower than the wide sum kernel
+        // (1000 x 2000, k = 50, 16 slabs: 97 vs 73 us per iteration)
+        const bool slabs = xfuse && !c->sparse && c->hseg_n == 1 && (int64_t)c->nsplit * c->f <= 8192;
+        EXACT_CALL(c, exact_N, c->cur ^ 1, !slabs);
+        EXACT_CALL(c, exact_H, slabs);
+        return;
+    }
+    if (!c->fused) {
         piece_colpass(c);
         piece_update_H(c);
         return;
@@ -2469,12 +2493,8 @@ int klnmf_run_more(klnmf_ctx *c, int64_t iters, int fit, double tol_abs) {
         }
         const bool fused = !c->is_exact();
         for (int64_t it = 0; it < iters; ++it) {
-            if (fused) {
-                piece_rowpass(c, fit, &tol_abs);
-            } else {
-                piece_rowpass(c, fit);
-                piece_decide(c, tol_abs);
-            }
+            (void)fused;
+            piece_rowpass(c, fit, &tol_abs);      // (every mode: the stop rule rides in the loss reduction's launch)
             if (fit) piece_fit_tail(c);
             c->cur ^= 1;
             c->loop_iters += 1;
@@ -2579,12 +2599,8 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         // H rule as well (from_slabs) was measured and is NOT used: its k blocks walk the slabs serially, 47 -> 68 us.
         const bool fused = !c->is_exact();
         auto one_iteration = [&] {
-            if (fused) {
-                piece_rowpass(c, fit, &tol_abs);
-            } else {
-                piece_rowpass(c, fit);
-                piece_decide(c, tol_abs);
-            }
+            (void)fused;
+            piece_rowpass(c, fit, &tol_abs);      // (every mode: the stop rule rides in the loss reduction's launch)
             if (fit) piece_fit_tail(c);
             c->cur ^= 1;
             c->iter_in_loop += 1;
@@ -2721,15 +2737,8 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
                 comm_iteration(c, fit, tol_abs);
             } else {
                 // one rank: the stop decision rides in the loss kernel, as in klnmf_run (one launch less per iteration)
-                if (c->is_exact()) piece_rowpass(c, fit);
-                else piece_rowpass(c, fit, &tol_abs);
-                if (c->is_exact()) {
-                    if (fit) piece_colpass(c);
-                    piece_decide(c, tol_abs);
-                    if (fit) piece_update_H(c);
-                } else if (fit) {
-                    piece_fit_tail(c);
-                }
+                piece_rowpass(c, fit, &tol_abs);
+                if (fit) piece_fit_tail(c);
                 c->cur ^= 1;
                 c->iter_in_loop += 1;
                 if (fit) poll_fp8_overflow(c);

@@ -13,6 +13,7 @@
 // read two contiguous k-vectors).
 #pragma once
 #include "common.hip.h"
+#include "exact.hip.h"
 
 namespace klnmf {
 
@@ -266,14 +267,15 @@ __global__ __launch_bounds__(256) void k_sp_dots(const double *wpart, int64_t nb
 
 // loss = sum_i row_loss[i] + sum_a prod[a] ; one block, fixed order.
 __global__ __launch_bounds__(1024) void k_sp_loss(const double *row_loss, int64_t n, const double *prod, int64_t k,
-                                                   double *out, const DevState *st) {
+                                                   double *out, const DevState *st,
+                                                   DecideArgs dec = DecideArgs{0, nullptr, 0.0, nullptr, 0}) {
     if (st && st->stop) return;
     __shared__ double red[16];
     double s = 0;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += row_loss[i];
     for (int64_t a = threadIdx.x; a < k; a += blockDim.x) s += prod[a];
     const double t = block_sum(s, red);
-    if (threadIdx.x == 0) { out[0] = t; out[1] = 0; }
+    if (threadIdx.x == 0) { out[0] = t; out[1] = 0; decide_here(dec, t); }
 }
 
 }  // namespace klnmf
