@@ -48,7 +48,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned u4;
 constexpr int kImg = 13312;          // 32 columns x 208 components x 2 B
 constexpr int kObj = 13312;
 constexpr int kTilesL2 = 128;        // dictionary: 128 tile images = 1.7 MB
-constexpr int N2 = 14, N1 = 13, NF = 27, D = 3;
+#ifndef MN2
+#define MN2 14
+#endif
+constexpr int N2 = MN2, N1 = 13, NF = N1 + N2, D = 3;
 
 template <int OFF> __device__ __forceinline__ void rd128(h8 &r, unsigned a) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
             constexpr int n_a = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
             constexpr int n_b = (last - p) - n_a;
             lwait<n_a + (TR ? 2 : 1) * n_b>(ring[p % 4]);
-            if constexpr (p < N2) acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+            if constexpr (p < N2) acc[(p >> 1) % 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], (p & 1) ? b1 : b0, acc[(p >> 1) % 7], 0, 0, 0);
             else {
                 if constexpr (p == N2 && DEP) for (int e = 0; e < 16; ++e) d[e] = 0.f;
                 if constexpr (DEP) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], wf[p - N2], d, 0, 0, 0);
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void k(float *out, const unsigned char *ht,
                 issue(std::integral_constant<int, p + D>{});
                 constexpr int last = (p + D < N2 - 1) ? p + D : N2 - 1;
                 lwait<last - p>(ring[p % 4]);
-                acc[p >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+                acc[(p >> 1) % 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[p % 4], (p & 1) ? b1 : b0, acc[(p >> 1) % 7], 0, 0, 0);
             });
         };
         // the epilogue of tile `it` on dd; with AHEAD, the 13 MFMAs of the NEXT tile's W.H (into dn) are issued between its quarters
