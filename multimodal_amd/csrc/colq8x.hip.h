@@ -13,6 +13,10 @@
 #pragma once
 #include "colq.hip.h"
 
+#ifndef KL_COL8_PF
+#define KL_COL8_PF 1      // accumulator blocks of W8 fragments requested ahead of their product (round 4, C4, one box: 1 / 2 / 3 blocks
+                          // ahead = 0.845 / 0.857 / 0.870 ms -- the pass waits for HBM, not for LDS: profiles/r04_ab_colpass_prefetch.txt)
+#endif
 #ifndef KL_COL8_NB
 #define KL_COL8_NB 4      // LDS objects of the fp8 x fp8 column pass (3 and 5 measured: profiles/r02_ab_fp8_fp8_colpass.txt)
 #endif
@@ -347,7 +351,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             constexpr int u = decltype(U)::value;
             lds_read_tr8<u * 8 * 32>(bq[u], base + off_b);
         });
-        i32x2 ring[2][4];
+        // W8 fragments run PF accumulator blocks ahead of their product (KL_COL8_PF; ring of PF + 1 register sets of 8)
+        constexpr int PF = KL_COL8_PF < KTW ? KL_COL8_PF : (KTW > 1 ? KTW - 1 : 1);
+        constexpr int RG = PF + 1;
+        i32x2 ring[RG][4];
         // accumulator blocks in DESCENDING order: the last block (it holds the probe component KP - 1) is multiplied first, so that
         // its result is there, without a wait, when the stage's other products have been issued
         auto fetch = [&](auto M) {
@@ -355,20 +362,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             if constexpr (m < KTW) {
                 static_for<0, 4>([&](auto U) {
                     constexpr int u = decltype(U)::value;
-                    lds_read_tr8<u * 8 * LD8 + 32 * (KTW - 1 - m)>(ring[m & 1][u], base + off_a);
+                    lds_read_tr8<u * 8 * LD8 + 32 * (KTW - 1 - m)>(ring[m % RG][u], base + off_a);
                 });
             }
         };
-        fetch(std::integral_constant<int, 0>{});
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+        static_for<0, PF>([&](auto M) { fetch(M); });
+        constexpr int young0 = 4 * (PF < KTW ? PF : KTW);              // reads younger than the ratio operand's
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "n"(young0));
         const i32x8 bo = {bq[0][0], bq[0][1], bq[1][0], bq[1][1], bq[2][0], bq[2][1], bq[3][0], bq[3][1]};
         static_for<0, KTW>([&](auto M) {
             constexpr int m = decltype(M)::value;
-            fetch(std::integral_constant<int, m + 1>{});
-            if constexpr (m + 1 < KTW) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ring[m & 1][0]), "+v"(ring[m & 1][1]), "+v"(ring[m & 1][2]), "+v"(ring[m & 1][3]));
-            const i32x8 ao = {ring[m & 1][0][0], ring[m & 1][0][1], ring[m & 1][1][0], ring[m & 1][1][1],
-                              ring[m & 1][2][0], ring[m & 1][2][1], ring[m & 1][3][0], ring[m & 1][3][1]};
+            fetch(std::integral_constant<int, m + PF>{});
+            constexpr int young = 4 * ((m + PF < KTW ? m + PF : KTW - 1) - m);      // reads of the blocks behind block m
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ring[m % RG][0]), "+v"(ring[m % RG][1]), "+v"(ring[m % RG][2]), "+v"(ring[m % RG][3]) : "n"(young));
+            const i32x8 ao = {ring[m % RG][0][0], ring[m % RG][0][1], ring[m % RG][1][0], ring[m % RG][1][1],
+                              ring[m % RG][2][0], ring[m % RG][2][1], ring[m % RG][3][0], ring[m % RG][3][1]};
             acc[KTW - 1 - m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[KTW - 1 - m], 0, 0, 0, 127, 0, 127);
             // the source order IS the schedule (read, counted wait, product, ...): without the fence hipcc moved the probe block's
             // product behind the others as soon as its accumulator was read below, hoisted every read in front of the products
