@@ -43,7 +43,8 @@ struct DevState {
     int q8_list_n;     // entries appended to the fix-up list in this iteration (k_q8_fixup recomputes them exactly and resets it)
     int q8_unfixed;    // saturated ratio entries beyond the list's capacity: their excess over 3584 is missing from an H numerator
     int q8_fix_done;   // blocks of the running fix-up launch that have finished (the last one resets the list)
-    int pad_;
+    int cq_e;          // ratio scale of MEASURED images that follow klnmf_init_W (mfma.hip.h, k_ratio_scale): the dictionary image is
+                       // H x 2^cq_e / t, so that W.H comes out 2^cq_e times larger and the ratio 2^cq_e times smaller; 0 otherwise
     // prev_error as a two-entry ring for stop rules evaluated inside a multi-block launch (post.hip.h): iteration `it` reads
     // prev2[(it - 1) & 1] -- which no block of its launch writes -- and records its loss in prev2[it & 1]
     double prev2[2];

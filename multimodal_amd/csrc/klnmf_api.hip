@@ -580,6 +580,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.nct = c->nct;
     a.nst = c->nst;
     a.eps = (float)(kEpsRatio * c->v_scale);
+    a.cq_on = c->images_measured ? 1 : 0;
     // fp8 x fp8 column pass with the image written by the W rule (KLNMF_COL8=2): this iteration's scales from the previous
     // iteration's maxima first, then the row pass writes image and maxima
     // (on the fused tail -- post.hip.h -- the maxima go to the 64-row table k_post turns into the next scales, and the image is
@@ -950,7 +951,7 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     static const int post_abl = std::getenv("KLNMF_POST_ABL") ? std::atoi(std::getenv("KLNMF_POST_ABL")) : 0;      // (timing experiments only)
     a.abl = post_abl;
     if (post_abl & 8) { a.do_decide = 0; a.loss_from_parts = 0; }
-    a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne;
+    a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne; a.cq_on = la.cq_on;
     a.tol_abs = la.tol_abs; a.errors = c->errors; a.cap = c->cap;
     a.st = c->st;
     a.H_old = c->H32; a.H_new = c->H32alt;
@@ -999,6 +1000,7 @@ void fast_colpass(klnmf_ctx *c) {
     a.stages_per_chunk = c->stages_per_chunk;
     a.f_pad = c->f_pad;
     a.eps = (float)(kEpsRatio * c->v_scale);
+    a.cq_on = c->images_measured ? 1 : 0;      // (the recomputed ratio must be the row pass's: same images, same denominator eps)
     const int grid = c->ncb * c->nchunks;
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_col);
@@ -1020,7 +1022,8 @@ void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false, const uns
                        (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (opnd_t *)nullptr : c->Ht, c->Ht4,
                        lean ? (opnd_t *)nullptr : c->HTb, c->hsum, c->tcur, c->t_hs, wmax, &c->st->op_range, c->f, c->f_pad,
                        c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
-                       (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad);
+                       (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad,
+                       wmax ? (const DevState *)c->st : (const DevState *)nullptr);      // measured images carry DevState.cq_e
     HIPCHK(hipGetLastError());
     c->images_measured = wmax != nullptr;
 }
@@ -1035,8 +1038,14 @@ void fast_pack_W(klnmf_ctx *c) {
 // Both images of the current (W, H) with scales MEASURED from W's column maxima (a W that no W rule produced: W0 = V.H0^T,
 // klnmf_set_W -- see opnd_t in mfma.hip.h).  They are valid for one update; the update's W rule packs the next W image
 // with the hs-based / row-normalised scale again.
-void measure_and_pack(klnmf_ctx *c) {
+// from_init: W is W0 = V.H0^T of klnmf_init_W -- the first update's ratios are about f / k times 1, and the dictionary image
+// then carries the ratio scale k_ratio_scale derives (mfma.hip.h; KLNMF_RATIO_SCALE=0: never); any other W: scale 1.
+void measure_and_pack(klnmf_ctx *c, bool from_init = false) {
     c->refusals_dirty = true;
+    const bool cq_ok = !(std::getenv("KLNMF_RATIO_SCALE") && std::atoi(std::getenv("KLNMF_RATIO_SCALE")) == 0);
+    hipLaunchKernelGGL(k_ratio_scale, dim3(1), dim3(1024), 0, c->stream, (const float *)c->H32, (int)c->k, c->f, c->f_pad, c->st,
+                       from_init && cq_ok ? 1 : 0);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->wmax, 0, (size_t)c->KP * 4, c->stream));
     HIPCHK(hipMemsetAsync(&c->st->op_range, 0, sizeof(int), c->stream));
     const int rows_grid = (int)std::min<int64_t>(c->n_pad, 1024);
@@ -1282,20 +1291,20 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr, boo
             // a fit on a communicator: one extra block of the first part's summing launch (k_post) reduces the partials into
             // loss_xchg, which is exchanged with the numerator; the stop rule rides in the launch behind the all-reduce
             c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 0, c->st,
-                                       0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0};
+                                       0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0};
             return;
         }
         if (fit && fused_tol && defer_ok) {
             // a fit in one context: nothing needs the loss before the H rule -- it is reduced (and the stop rule applied) by
             // one extra block of the slab-sum launch behind the column pass (launch_sum_partials)
             c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 1, c->st,
-                                       *fused_tol, c->errors, c->cap, c->last_row_ne ? 1 : 0};
+                                       *fused_tol, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0};
             return;
         }
         hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                            (const double2 *)c->loss_part2, c->loss_parts(),
                            (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
-                           fused_tol ? *fused_tol : 0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0);
+                           fused_tol ? *fused_tol : 0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
 }
@@ -2262,7 +2271,7 @@ int klnmf_init_W(klnmf_ctx *c) {
         } else if (c->is_exact()) EXACT_CALL(c, exact_W, c->V, 0);
         else fast_rowpass(c, ROW_INIT);
         c->cur ^= 1;
-        if (!c->is_exact()) measure_and_pack(c);     // W0 = V.H0^T scales with H0: images with measured scales for the first update
+        if (!c->is_exact()) measure_and_pack(c, true);     // W0 = V.H0^T scales with H0: images with measured scales for the first update
     });
 }
 
@@ -2807,7 +2816,8 @@ int klnmf_error(klnmf_ctx *c, double *loss) {
             fast_rowpass(c, ROW_LOSS);
             hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
                                (const double2 *)c->loss_part2, (int64_t)c->nrt,
-                               (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg);
+                               (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, 0, (DevState *)nullptr, 0.0,
+                               (double *)nullptr, (int64_t)0, 0, c->images_measured ? 1 : 0);
             HIPCHK(hipGetLastError());
         }
         double h[2] = {0, 0};
@@ -2831,6 +2841,7 @@ int klnmf_loss_terms(klnmf_ctx *c, double *terms) {
         HIPCHK(hipStreamSynchronize(c->stream));
         double a = 0, b = 0;
         for (const double2 &p : parts) { a += p.x; b += p.y; }
+        if (c->images_measured) a += (double)hs.cq_e * hs.sum_x;      // a ratio-scaled dictionary image (k_ratio_scale): the unscaled ratio's logarithms
         terms[0] = kLn2 * a / c->v_scale;
         terms[1] = b / c->v_scale;
         terms[2] = hs.sum_x / c->v_scale;

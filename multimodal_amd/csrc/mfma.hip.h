@@ -262,6 +262,7 @@ struct RowPassArgs {
     const DevState *st;
     int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
     float eps;                // c * 1e-8 (scaled units)
+    int cq_on;                // the dictionary image carries the ratio scale 2^st->cq_e (k_ratio_scale): the denominator's eps is scaled with it
     // Column-split update pass of the ping-pong kernel (few rows: one workgroup per 256 rows would leave the chip idle):
     // blockIdx.y = column chunk of ct_chunk tiles; the workgroup leaves its part of Q.H^T in gpart[chunk][row][KP] and
     // its loss terms in loss_part[chunk * nrt + rt]; k_wrule_slabs sums the chunks and applies the W rule.  null: whole rows.
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
     float s1 = 0.f;
-    const float eps = a.eps;
+    const float eps = a.eps;                                            // numerator: (x + eps)
+    const float eps_d = a.cq_on ? ldexpf(a.eps, a.st->cq_e) : a.eps;     // denominator: W.H of a ratio-scaled image + 2^cq_e eps
 
     const unsigned char *ht = (const unsigned char *)a.Ht;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
 #ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
                     q[e] = x[e] + d[e];
 #else
-                    const float rinv = __builtin_amdgcn_rcpf(d[e] + eps);
+                    const float rinv = __builtin_amdgcn_rcpf(d[e] + eps_d);
                     const float qq = fmaf(x[e], rinv, eps * rinv);          // (x + eps) * r; same form as mfma4.hip.h
                     q[e] = qq;
                     s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
@@ -551,6 +553,7 @@ struct ColPassArgs {
     int nrt, nct, ncb, nchunks, stages_per_chunk;   // nrt even; a stage = 2 row tiles
     int64_t f_pad;
     float eps;
+    int cq_on;                // see RowPassArgs
 };
 
 template <int KT, int ODD, typename VT, int EP = 0>
@@ -606,7 +609,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-    const float eps = a.eps;
+    const float eps = a.eps;                                            // numerator: (x + eps)
+    const float eps_d = a.cq_on ? ldexpf(a.eps, a.st->cq_e) : a.eps;     // denominator: W.H of a ratio-scaled image + 2^cq_e eps
 
     const unsigned char *wo = (const unsigned char *)a.Wb_old;
     const unsigned char *wn = (const unsigned char *)a.Wb_new;
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
             {
                 // (x + eps) * r as x*r + eps*r: with fp16 V the compiler feeds x to v_fma_mix_f32 in its
                 // storage form and drops the conversion (VALU time adds to matrix time on the SIMD)
-                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps is already in d (pad component)
+                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps_d);      // EP: eps is already in d (pad component)
                 q[e] = fmaf(x[e], rinv, eps * rinv);
             }
             const opx8 b0 = pack8(q), b1 = pack8(q + 8);
@@ -856,11 +860,14 @@ KL_GLOBAL __launch_bounds__(1024) void k_update_pack_H(float *H32, const float *
                                                        const unsigned *wmax, int *op_range, int64_t f,
                                                        int64_t f_pad, int kp, int do_update,
                                                        const DevState *st, int kc, float eps_pad,
-                                                       int nslab = 0, int64_t slab = 0) {
+                                                       int nslab = 0, int64_t slab = 0, const DevState *stq = nullptr) {
     if (st && st->stop) return;
     KL_FP16_SATURATE();
+    // stq != nullptr: the image carries the ratio scale 2^cq_e (k_ratio_scale below) -- entries, eps row and the balance of
+    // the measured scales; hsum stays the row sum of the UNSCALED image (the W rule and the loss's sum(W.H) use it)
+    const int qe = stq ? stq->cq_e : 0;
     if (kc >= 0 && blockIdx.x == 0) {
-        const opnd_t ev = (opnd_t)(eps_pad / kCarrierW);          // x the carrier column of the W image = eps
+        const opnd_t ev = (opnd_t)ldexpf(eps_pad / kCarrierW, qe);          // x the carrier column of the W image = eps (x 2^cq_e)
         for (int64_t j = threadIdx.x; j < f_pad; j += blockDim.x) {
             if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(kc, (int)(j % 32))] = ev;
             if (HTb) HTb[j * kp + kc] = ev;
@@ -917,6 +924,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_update_pack_H(float *H32, const float *
                 int ew = 0, eh = 0;
                 (void)frexpf(wm, &ew);
                 (void)frexpf(rmax, &eh);
+                eh += qe;                                                // the image holds H x 2^cq_e
                 int et = (eh - ew) / 2;                                  // t ~ sqrt(max H / max W)
                 if (eh - et > 15) et = eh - 15;                          // H image peak <= 2^15 first (W saturates, if anything)
                 if (ew + et > 16 && threadIdx.x == 0) atomicAdd(op_range, 1);   // ... and it does: reported by the loop entry points
@@ -925,7 +933,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_update_pack_H(float *H32, const float *
         }
         __syncthreads();
     }
-    const float sc = 1.f / t_a;        // exact: t_a is a power of two
+    const float sc = ldexpf(1.f / t_a, qe);        // exact: t_a is a power of two
     double hsm = 0;
     for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
         const opnd_t v = (opnd_t)(row[j] * sc);
@@ -938,7 +946,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_update_pack_H(float *H32, const float *
     }
     const double ths = block_sum(hsm, red);
     if (threadIdx.x == 0) {
-        hsum[a] = ths;                 // row sum of the IMAGE (scaled): x the W image's scale it is sum_j (W.H)_ij exactly
+        hsum[a] = ldexp(ths, -qe);     // row sum of the IMAGE (scaled by 1 / t_a only): x the W image's scale it is sum_j (W.H)_ij exactly
         tcur[a] = t_a;
     }
 }
@@ -951,6 +959,34 @@ KL_GLOBAL void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
     float m = 0.f;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) m = fmaxf(m, W32[i * kp + c]);
     atomicMax(wmax + c, __float_as_uint(m));
+}
+// The ratio scale of the first update after klnmf_init_W.  W0 = V.H0^T (nmf.py:156) is not the result of a W rule: the model
+// W0.H0 is too small by about f / sum_a rowsum(H0_a) (= f / k for a row-normalised dictionary: every entry of W0 is a weighted
+// MEAN of its row of V, and k such means replace a SUM over f columns), so the first ratios are that much larger than 1 --
+// beyond 65504, the largest f16, from f / k ~ 1000 on with heavy-tailed data (round 4's shape fuzz: k = 1, f = 2755; the
+// saturated operands clip the first H numerator and errors[1] is off by a factor 2, the run recovers two iterations later).
+// One block: cq_e = floor(log2(f / sum of the dictionary's entries)), 0 below 2^7 (ratios up to 500 x their mean still fit) and
+// at most 12.  Derived from the dictionary alone, so that every rank of a row-sharded loop takes the same value.  The image
+// packed next carries 2^cq_e (k_update_pack_H); the update pass then sees W.H x 2^cq_e and a ratio / 2^cq_e: its second
+// product Q.H^T multiplies the two and is unchanged, the H numerator is scaled as a whole and the row normalisation removes
+// it, the loss adds cq_e x sum(x) to its sum of x log2(ratio) (loss_from_parts_block).  enable = 0: writes 0.
+KL_GLOBAL __launch_bounds__(1024) void k_ratio_scale(const float *H32, int k, int64_t f, int64_t f_pad, DevState *st, int enable) {
+    __shared__ double red[16];
+    double s = 0;
+    if (enable)
+        for (int64_t e = threadIdx.x; e < (int64_t)k * f; e += blockDim.x) s += (double)H32[(e / f) * f_pad + e % f];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (enable && t > 0 && t < 1e300) {
+            int ex = 0;
+            (void)frexp((double)f / t, &ex);          // f / t = m 2^ex, m in [0.5, 1)  ->  floor(log2) = ex - 1
+            e = ex - 1;
+            if (e < 7) e = 0;
+            if (e > 12) e = 12;
+        }
+        st->cq_e = e;
+    }
 }
 KL_GLOBAL void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *tcur) {
     KL_FP16_SATURATE();
@@ -1061,6 +1097,7 @@ struct LossArgs {
     double *errors;
     int64_t cap;
     int ne;                   // the partials come from an update pass without the numerator's eps: add DevState.corr_eps
+    int cq_on;                // ... from a pass over a ratio-scaled dictionary image: its ratios are 2^cq_e too small (k_ratio_scale)
 };
 // one block: fixed-order fp64 reduction of the row pass's loss partials, then (decide) the stop rule of nmf.py:214-220
 __device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const DevState *st, double *red) {
@@ -1089,7 +1126,8 @@ __device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const 
     const double ta = block_sum(a, red);
     const double tb = block_sum(b, red);
     if (threadIdx.x == 0) {
-        const double err = (kLn2 * ta + (la.ne ? st->corr_eps : 0.0) + tb - st->sum_x - st->corr_c) * la.inv_c;
+        const double ta_q = la.cq_on ? ta + (double)st->cq_e * st->sum_x : ta;      // sum x log2(ratio) of the unscaled ratio
+        const double err = (kLn2 * ta_q + (la.ne ? st->corr_eps : 0.0) + tb - st->sum_x - st->corr_c) * la.inv_c;
         la.out[0] = err;
         la.out[1] = (double)st->q8_unfixed;      // (row shards: summed by the loss exchange, so that every rank sees when fp8 tiles must be given up)
         if (la.decide) {
@@ -1108,10 +1146,10 @@ KL_GLOBAL __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, in
                                                           const DevState *st, double inv_c,
                                                           double *out, int decide = 0, DevState *st_rw = nullptr,
                                                           double tol_abs = 0.0, double *errors = nullptr,
-                                                          int64_t cap = 0, int ne = 0) {
+                                                          int64_t cap = 0, int ne = 0, int cq_on = 0) {
     if (st->stop) return;
     __shared__ double red[16];
-    const LossArgs la{part, count, inv_c, out, decide, st_rw, tol_abs, errors, cap, ne};
+    const LossArgs la{part, count, inv_c, out, decide, st_rw, tol_abs, errors, cap, ne, cq_on};
     loss_from_parts_block(la, st, red);
 }
 
@@ -1121,7 +1159,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, in
 // C2 iteration, 15 % of one at the reference's own data sizes).  If the rule fires, this iteration's column pass has run
 // for nothing and k_update_pack_H (next on the stream) does not apply it.
 KL_GLOBAL void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
-                                   const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0}) {
+                                   const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0, 0}) {
     if (st && st->stop) return;
     if (la.part != nullptr && blockIdx.x == gridDim.x - 1) {
         __shared__ double red[16];

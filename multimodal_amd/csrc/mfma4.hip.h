@@ -312,7 +312,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
     float s1 = 0.f;
     double s2 = 0.0;
-    const float eps = a.eps;
+    const float eps = a.eps;                                            // numerator: (x + eps)
+    const float eps_d = a.cq_on ? ldexpf(a.eps, a.st->cq_e) : a.eps;     // denominator of a ratio-scaled image (mfma.hip.h, k_ratio_scale)
     const unsigned char *ht = (const unsigned char *)aa.Ht4;
     const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
     // column tiles [ct0, ct1) of this workgroup: all of them, or one chunk of the column-split update pass
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             auto xe = [&](int e) { return (float)(e < 8 ? va[e & 7] : vb[e & 7]); };
 #pragma unroll
             for (int i = -2; i < 17; ++i) {
-                if (i + 2 < 16) { R[i + 2] = __builtin_amdgcn_rcpf(EP ? d[i + 2] : d[i + 2] + eps); asm volatile("" : "+v"(R[i + 2])); }
+                if (i + 2 < 16) { R[i + 2] = __builtin_amdgcn_rcpf(EP ? d[i + 2] : d[i + 2] + eps_d); asm volatile("" : "+v"(R[i + 2])); }
                 float m_ = 0.f;
                 if (i + 1 >= 0 && i + 1 < 16) { m_ = eps * R[i + 1]; asm volatile("" : "+v"(m_)); }
                 if (i >= 0 && i < 16) { L[i] = __builtin_amdgcn_logf(q[i]); asm volatile("" : "+v"(L[i])); }
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 // (x + eps) * r as x*r + eps*r: x is consumed in its fp16 storage form by v_fma_mix_f32 (here
                 // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
                 // adds to the matrix time of the SIMD, every instruction counts
-                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);      // EP: eps came in through MFMA-1
+                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps_d);      // EP: eps came in through MFMA-1
                 // NE (Q8 = 2; klnmf_api.hip chooses it per loop from the data's mean): the ratio as x * r.  Against the reference's
                 // (x + eps) * r that is a relative eps / x per element -- chosen only where eps / mean(V) <= 1e-5 (loss record within
                 // 1.5e-6, factors within 2.5e-5 of their maxima over 50 iterations: DESIGN.md section 8, h33) --, no logarithm sees
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 if constexpr (NE) q[e] = fmaf(x, rinv, zero_f);
                 else q[e] = fmaf(x, rinv, eps * rinv);
 #ifdef KL_ABL_LOGD        // timing-only experiment: the loss term from log2(W.H) (independent of the reciprocal) -- the loss VALUE is then another sum
-                s1 = fmaf(x, __builtin_amdgcn_logf(EP ? d[e] : d[e] + eps), s1);
+                s1 = fmaf(x, __builtin_amdgcn_logf(EP ? d[e] : d[e] + eps_d), s1);
 #else
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
 #endif
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 }
             }
             if constexpr (e < 16) {
-                rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps);
+                rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps_d);
                 asm volatile("" : "+v"(rinv));
             }
         } else {

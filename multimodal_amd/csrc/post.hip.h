@@ -66,6 +66,7 @@ struct PostArgs {
     int abl;                  // timing experiments (KLNMF_POST_ABL): 1 no normalisation pass, 2 no slab pass, 4 no last-block counter
     // ---- loss / stop rule
     const double2 *loss_part; int64_t loss_count; double inv_c; double *loss_xchg; int ne;
+    int cq_on;                // the partials come from a pass over a ratio-scaled dictionary image (LossArgs.cq_on, mfma.hip.h)
     double tol_abs; double *errors; int64_t cap;
     DevState *st;
     // ---- H rule
@@ -103,7 +104,10 @@ __device__ __forceinline__ double post_loss(const PostArgs &a, double *red, doub
     const double sb = ((bu[0] + bu[1]) + (bu[2] + bu[3])) + ((bu[4] + bu[5]) + (bu[6] + bu[7]));
     const double ta = block_sum(sa, red);
     const double tb = block_sum(sb, red);
-    if (threadIdx.x == 0) *bc = (kLn2 * ta + (a.ne ? a.st->corr_eps : 0.0) + tb - a.st->sum_x - a.st->corr_c) * a.inv_c;
+    if (threadIdx.x == 0) {
+        const double ta_q = a.cq_on ? ta + (double)a.st->cq_e * a.st->sum_x : ta;
+        *bc = (kLn2 * ta_q + (a.ne ? a.st->corr_eps : 0.0) + tb - a.st->sum_x - a.st->corr_c) * a.inv_c;
+    }
     __syncthreads();
     return *bc;                   // the same bits in every thread of every block that evaluates it
 }

@@ -1,0 +1,99 @@
+"""Bug hunt: KLdivNMF.fit_transform on the HIP path against the oracle over shapes chosen AT the library's switching points
+(32-row tiles, 32 768 / 65 536 rows for the e4m3 tiles / image, k at multiples of 32, 224/225, 256/257, 512/513, f not a
+multiple of 32, one row, one column, one component) and a seeded random sample in between.  Prints one line per case and a
+summary; exit code 1 if any case leaves its tolerance.
+
+    python3 scripts/shape_fuzz.py [--random 20] [--seed 0] [--precisions f64,f16]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--random', type=int, default=20)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--precisions', default='f64,f16')
+    ap.add_argument('--iters', type=int, default=6)
+    args = ap.parse_args()
+    from multimodal_amd.lib import nmf
+    from oracle import klnmf_oracle as orc
+    edge = [
+        (1, 1, 1), (1, 40, 3), (40, 1, 1), (2, 2, 2), (31, 31, 31), (32, 32, 32), (33, 33, 33), (257, 65, 64), (255, 63, 65),
+        (100, 97, 224), (100, 97, 225), (90, 70, 256), (90, 70, 257), (60, 50, 512), (60, 50, 513),
+        (32767, 40, 5), (32768, 40, 5), (32769, 40, 5), (32769, 33, 40), (65535, 36, 8), (65536, 36, 8), (65537, 36, 8),
+        (65537, 95, 33), (70001, 64, 200), (40000, 300, 50), (66000, 129, 224), (66000, 129, 225), (33000, 2049, 7),
+        # f / k from 2^7 on: the first update's ratio scale (mfma.hip.h, k_ratio_scale)
+        (208, 2755, 1), (822, 1741, 1), (300, 4096, 3), (300, 4097, 32), (2080, 2755, 2), (100, 12000, 5), (70000, 2000, 2),
+    ]
+    rs = np.random.RandomState(args.seed)
+    rnd = []
+    for _ in range(args.random):
+        n = int(np.exp(rs.uniform(np.log(2), np.log(80000))))
+        f = int(np.exp(rs.uniform(np.log(2), np.log(3000))))
+        k = int(np.exp(rs.uniform(np.log(1), np.log(300))))
+        if n * f * k > 6e9:
+            f = max(2, int(6e9 / (n * k)))
+        rnd.append((n, f, k))
+    bad = 0
+    for prec in args.precisions.split(','):
+        for (n, f, k) in edge + rnd:
+            X = orc.synthetic_V(7 + n + f + k, n, f, k)
+            H0 = orc.synthetic_H0(7 + n + f + k, f, k)
+            t0 = time.time()
+            Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=args.iters, tol=0)
+            t_or = time.time() - t0
+            m = nmf.KLdivNMF(n_components=k, max_iter=args.iters, tol=0, precision=prec)
+            m._init_dictionary = H0
+            buf = io.StringIO()
+            try:
+                with contextlib.redirect_stderr(buf):
+                    W, errors = m.fit_transform(X, return_errors=True, scale_W=True)
+            except Exception as e:
+                print('%-4s %6d x %5d k=%3d  EXCEPTION %s' % (prec, n, f, k, str(e)[:150]), flush=True)
+                bad += 1
+                continue
+            errors = np.array(errors)
+            H = m.components_
+            sx = float(X.sum())
+            # losses near zero (an exact fit: k >= min(n, f), one row, one column) are compared on the data's scale; the f16 mode's
+            # loss carries the storage rounding of V (2^-11 per entry: ~1e-7 of sum(x) in the KL)
+            floor_e = (1e-4 if prec != 'f64' else 1e-12) * sx
+            m_ = min(len(errors), len(eo))
+            # tol = 0 stops at the first iteration whose loss does not fall: on a plateau (k = 1 converges in one update) that is
+            # decided by the last bit of a sum, so the two runs may stop one or two iterations apart there
+            plateau = len(eo) >= 2 and abs(eo[-1] - eo[-2]) <= 1e-9 * max(abs(eo[-1]), floor_e)
+            len_ok = len(errors) == len(eo) or (plateau and abs(len(errors) - len(eo)) <= 2) or prec != 'f64' and abs(len(errors) - len(eo)) <= 2 and m_ >= 2 and \
+                abs(eo[m_ - 1] - eo[m_ - 2]) <= 1e-5 * max(abs(eo[m_ - 1]), floor_e)
+            ok = len_ok and np.all(np.isfinite(W)) and np.all(np.isfinite(H))
+            rel_e = float(np.max(np.abs(errors[:m_] - np.array(eo[:m_])) / np.maximum(np.abs(eo[:m_]), floor_e)))
+            same_len = len(errors) == len(eo)
+            wmax, hmax = float(np.abs(Wo).max()), float(np.abs(Ho).max())
+            dW = float(np.abs(W - Wo).max() / max(wmax, 1e-300)) if same_len else 0.0
+            dH = float(np.abs(H - Ho).max() / max(hmax, 1e-300)) if same_len else 0.0
+            final_o = orc.kl_error(X, Wo, Ho)
+            final_g = orc.kl_error(X, W, H)
+            rel_f = abs(final_g - final_o) / max(abs(final_o), floor_e)
+            if prec == 'f64':
+                lim_e, lim_w, lim_f = 1e-9, 1e-7, 1e-9
+            else:
+                lim_e, lim_w, lim_f = 1e-3, 6e-3, 1e-4
+            ok = ok and rel_e <= lim_e and dW <= lim_w and dH <= lim_w and rel_f <= lim_f
+            note = buf.getvalue().strip().replace('\n', ' | ')[:80]
+            print('%-4s %6d x %5d k=%3d  %s  len %d/%d  losses %.1e  W %.1e  H %.1e  final KL %.1e  (oracle %.1f s)  %s' % (
+                prec, n, f, k, 'ok  ' if ok else 'FAIL', len(errors), len(eo), rel_e, dW, dH, rel_f, t_or, note), flush=True)
+            bad += 0 if ok else 1
+    print('%d case(s) outside their tolerance' % bad)
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

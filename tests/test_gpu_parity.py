@@ -952,6 +952,39 @@ def test_f16_ratio_saturates_instead_of_overflowing():
     assert np.abs(W - Wo).max() <= 5e-3 * np.abs(Wo).max()
 
 
+@pytest.mark.parametrize('n,f,k', [(208, 2755, 1), (300, 4096, 3), (300, 4097, 32), (2080, 2755, 2)])
+def test_first_update_after_init_keeps_its_ratios_inside_the_half_range(monkeypatch, n, f, k):
+    """W0 = X.H0^T (nmf.py:156) under-models V by about f / k (every entry of W0 is a weighted MEAN of its row, k of them
+    replace a sum over f columns): the first update's ratios X / (W0.H0) are that much larger than 1 -- with f / k in the
+    thousands beyond 65504, the largest f16 -- found by scripts/shape_fuzz.py (round 4): the saturated operands clipped the
+    first H numerator, errors[1] came out twice the reference's, the factors recovered two updates later.  The dictionary image
+    of that ONE update now carries a power of two (k_ratio_scale, mfma.hip.h): W.H comes out 2^e times larger, the ratio 2^e
+    times smaller, Q.H^T unchanged, the H numerator scaled as a whole (the row normalisation removes it, nmf.py:350), the
+    loss corrected by e sum(x).  Every loss, both factors and the coefficients of a transform then agree with the oracle as
+    for any other shape; KLNMF_RATIO_SCALE=0 shows what the saturation did."""
+    monkeypatch.delenv('KLNMF_RATIO_SCALE', raising=False)
+    X = orc.synthetic_V(7 + n + f + k, n, f, k)
+    H0 = orc.synthetic_H0(7 + n + f + k, f, k)
+    iters = 3
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    for prec in ('f16', 'f16_v32'):
+        m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision=prec)
+        assert len(errors) == len(eo) == iters
+        assert_allclose(errors, eo, rtol=1e-4)
+        assert _rel_to_max(W, Wo) < 5e-3
+        assert _rel_to_max(m.components_, Ho) < 5e-3
+    Wt, et = orc.transform(X, H0, max_iter=iters, tol=0)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16', fit=False, components=H0)
+    assert_allclose(errors, et, rtol=1e-4)
+    assert _rel_to_max(W, Wt) < 5e-3
+    if (n, f, k) == (208, 2755, 1):
+        q0 = orc.ratio_q(X, X.dot(H0.T), H0)
+        assert (q0 > 65504.).sum() > 1000                      # the case IS beyond the half range
+        monkeypatch.setenv('KLNMF_RATIO_SCALE', '0')
+        m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+        assert errors[1] > 1.5 * eo[1]                         # ... and without the scale the first H rule is clipped
+
+
 # ---- e4m3 saturation: counted, and kept out of the result (round 3) ---------------------------------------------------
 def _piece_loop(ctx, iters, after=None):
     """The loop of nmf.py:212-222 through the piece API (klnmf_iter_*), `after(it)` between iterations."""
