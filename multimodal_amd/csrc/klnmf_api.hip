@@ -295,6 +295,7 @@ struct klnmf_ctx {
     opnd_t *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
     int row_gen = 4;
     int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
+    int kc_shape = -1;           // ... as the shape allows it; kc = kc_shape only while the carrier pair fits fp16 (choose_eps_carrier)
     double *hsum = nullptr;
     // per-component power-of-two scales of the fp16 operand images (mfma.hip.h, opnd_t), [KP] each: of the current images;
     // hs-based (from the dictionary's row sums); the constant 2^-13 of a row-normalised dictionary; measured from a W
@@ -1038,13 +1039,35 @@ void fast_pack_W(klnmf_ctx *c) {
 // Both images of the current (W, H) with scales MEASURED from W's column maxima (a W that no W rule produced: W0 = V.H0^T,
 // klnmf_set_W -- see opnd_t in mfma.hip.h).  They are valid for one update; the update's W rule packs the next W image
 // with the hs-based / row-normalised scale again.
+// eps through the matrix product (kc >= 0, k_update_pack_H) is the pair "W image column kc = 2^-10, dictionary image row kc =
+// eps x c x 2^10" (c = the storage factor of V, a power of two fixed by klnmf_set_v_max).  Both must be fp16 numbers: with
+// max(V) below 5e-6 the row value passes 65504 (round 4's data fuzz: V x 1e-6, k = 40 -- eps came out 25 % small, the losses
+// 4 % off), with max(V) above ~1e7 it underflows to 0 and the padded rows of the last row tile divide 0 by 0 (V x 1e6,
+// 70 000 rows: NaN).  Outside [2^-20, 2^15] -- max(V) outside about [1e-5, 3e5] -- the carrier is dropped and the kernels add
+// eps in their fp32 epilogue (the EP = 0 instantiations every shape has; one more VALU instruction per element).  Below
+// 2^-14 the row value is a subnormal half (at 2^-20: 16 steps, eps good to 3 %): V is then 1e11 times eps and more, and all
+// that is asked of eps is to keep 0 / 0 out of the empty rows.
+static void choose_eps_carrier(klnmf_ctx *c) {
+    const double ev = kEpsRatio * c->v_scale / (double)kCarrierW;
+    const bool fits = ev >= 9.5367431640625e-07 && ev <= 32768.0;
+    c->kc = (c->kc_shape >= 0 && fits) ? c->kc_shape : -1;
+}
+
 // from_init: W is W0 = V.H0^T of klnmf_init_W -- the first update's ratios are about f / k times 1, and the dictionary image
 // then carries the ratio scale k_ratio_scale derives (mfma.hip.h; KLNMF_RATIO_SCALE=0: never); any other W: scale 1.
 void measure_and_pack(klnmf_ctx *c, bool from_init = false) {
     c->refusals_dirty = true;
     const bool cq_ok = !(std::getenv("KLNMF_RATIO_SCALE") && std::atoi(std::getenv("KLNMF_RATIO_SCALE")) == 0);
+    // (the eps row of the image is scaled too: it must stay an fp16 number)
+    int e_cap = 12;
+    if (c->kc >= 0) {
+        const double ev = kEpsRatio * c->v_scale / (double)kCarrierW;
+        int ex = 0;
+        (void)std::frexp(32768.0 / ev, &ex);
+        e_cap = std::min(12, std::max(0, ex - 1));
+    }
     hipLaunchKernelGGL(k_ratio_scale, dim3(1), dim3(1024), 0, c->stream, (const float *)c->H32, (int)c->k, c->f, c->f_pad, c->st,
-                       from_init && cq_ok ? 1 : 0);
+                       from_init && cq_ok ? 1 : 0, e_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->wmax, 0, (size_t)c->KP * 4, c->stream));
     HIPCHK(hipMemsetAsync(&c->st->op_range, 0, sizeof(int), c->stream));
@@ -1859,7 +1882,8 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->HTb = (opnd_t *)c->dalloc((size_t)c->f_pad * c->KP * 2);
             // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
             // carrier column at 1) and a spare component inside the MFMA-1 contraction range
-            c->kc = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
+            c->kc_shape = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
+            choose_eps_carrier(c);
             c->hsum = (double *)c->dalloc((size_t)c->KP * 8);
             c->tcur = (float *)c->dalloc((size_t)c->KP * 4);
             c->t_hs = (float *)c->dalloc((size_t)c->KP * 4);
@@ -2074,12 +2098,14 @@ int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
         if (c->v_uploaded) fail(KLNMF_ERR_ARG, "klnmf_set_v_max must precede the first upload");
         if (c->is_exact() || vmax == 0) {
             c->v_scale = 1.0;
+            if (!c->is_exact()) choose_eps_carrier(c);
             return;
         }
         int e = 0;
         (void)std::frexp(vmax, &e);             // vmax = m * 2^e, m in [0.5, 1)
         c->v_scale = std::ldexp(1.0, 15 - e);   // c * vmax in [2^14, 2^15)
         c->v_max = vmax;
+        choose_eps_carrier(c);
         if (c->kc >= 0) fast_pack_H(c, 0);      // the eps row of the dictionary images is in scaled units
     });
 }

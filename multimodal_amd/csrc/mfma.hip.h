@@ -970,7 +970,7 @@ KL_GLOBAL void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
 // packed next carries 2^cq_e (k_update_pack_H); the update pass then sees W.H x 2^cq_e and a ratio / 2^cq_e: its second
 // product Q.H^T multiplies the two and is unchanged, the H numerator is scaled as a whole and the row normalisation removes
 // it, the loss adds cq_e x sum(x) to its sum of x log2(ratio) (loss_from_parts_block).  enable = 0: writes 0.
-KL_GLOBAL __launch_bounds__(1024) void k_ratio_scale(const float *H32, int k, int64_t f, int64_t f_pad, DevState *st, int enable) {
+KL_GLOBAL __launch_bounds__(1024) void k_ratio_scale(const float *H32, int k, int64_t f, int64_t f_pad, DevState *st, int enable, int e_cap) {
     __shared__ double red[16];
     double s = 0;
     if (enable)
@@ -982,8 +982,8 @@ KL_GLOBAL __launch_bounds__(1024) void k_ratio_scale(const float *H32, int k, in
             int ex = 0;
             (void)frexp((double)f / t, &ex);          // f / t = m 2^ex, m in [0.5, 1)  ->  floor(log2) = ex - 1
             e = ex - 1;
+            if (e > e_cap) e = e_cap;          // (12, or what the image's eps row can take)
             if (e < 7) e = 0;
-            if (e > 12) e = 12;
         }
         st->cq_e = e;
     }

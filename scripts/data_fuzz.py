@@ -1,0 +1,94 @@
+"""Bug hunt, part 2: the 16-bit modes' data-dependent machinery (storage factor from max V, the fp8 / no-numerator-eps rules from
+mean and max, saturation paths) against the oracle over DATA families instead of shapes: scale 1e-6 ... 1e6, sparse (95 % zeros),
+heavy-tailed (log-normal), constant columns, zero rows and columns, one huge spike, integer counts.  fit and transform.
+
+    python3 scripts/data_fuzz.py [--precision f16]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def families(rs, n, f, k):
+    base = None
+
+    def low_rank():
+        W = rs.gamma(1.0, 1.0, (n, k))
+        H = rs.gamma(0.5, 1.0, (k, f))
+        return W.dot(H) / k + 0.05 * rs.random_sample((n, f))
+    yield 'low rank + noise', low_rank()
+    yield 'x 1e-6', low_rank() * 1e-6
+    yield 'x 1e+6', low_rank() * 1e6
+    X = low_rank() * (rs.random_sample((n, f)) < 0.05)
+    yield '95 % zeros', X
+    yield 'log-normal (sigma 2)', np.exp(2.0 * rs.standard_normal((n, f)))
+    X = low_rank(); X[:, ::7] = 3.0
+    yield 'constant columns', X
+    X = low_rank(); X[::5, :] = 0.0; X[:, ::9] = 0.0
+    yield 'zero rows and columns', X
+    X = low_rank(); X[n // 2, f // 2] = 1e4 * X.max()
+    yield 'one spike 1e4 x max', X
+    yield 'integer counts (Poisson 0.3)', rs.poisson(0.3, (n, f)).astype(np.float64)
+    yield 'uniform', rs.random_sample((n, f))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--precision', default='f16')
+    ap.add_argument('--iters', type=int, default=8)
+    args = ap.parse_args()
+    from multimodal_amd.lib import nmf
+    from oracle import klnmf_oracle as orc
+    bad = 0
+    for (n, f, k) in [(300, 200, 5), (40000, 64, 8), (70000, 96, 40)]:
+        rs = np.random.RandomState(n + f + k)
+        for name, X in families(rs, n, f, k):
+            H0 = orc.synthetic_H0(11, f, k)
+            for fit in (True, False):
+                if fit:
+                    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=args.iters, tol=0)
+                else:
+                    Wo, eo = orc.transform(X, H0, max_iter=args.iters, tol=0)
+                    Ho = H0
+                m = nmf.KLdivNMF(n_components=k, max_iter=args.iters, tol=0, precision=args.precision)
+                m._init_dictionary = H0
+                if not fit:
+                    m.components_ = H0
+                buf = io.StringIO()
+                try:
+                    with contextlib.redirect_stderr(buf):
+                        W, errors = m.fit_transform(X, return_errors=True, scale_W=True, _fit=fit)
+                except Exception as e:
+                    print('%-6d x %-4d k=%-3d %-28s fit=%d  EXCEPTION %s' % (n, f, k, name, fit, str(e)[:160]), flush=True)
+                    bad += 1
+                    continue
+                errors = np.array(errors)
+                H = m.components_
+                m_ = min(len(errors), len(eo))
+                sx = float(X.sum())
+                floor_e = 1e-4 * sx
+                rel_e = float(np.max(np.abs(errors[:m_] - np.array(eo[:m_])) / np.maximum(np.abs(eo[:m_]), floor_e)))
+                same = len(errors) == len(eo)
+                dW = float(np.abs(W - Wo).max() / max(np.abs(Wo).max(), 1e-300)) if same else float('nan')
+                dH = float(np.abs(H - Ho).max() / max(np.abs(Ho).max(), 1e-300)) if same else float('nan')
+                fo, fg = orc.kl_error(X, Wo, Ho), orc.kl_error(X, W, H)
+                rel_f = abs(fg - fo) / max(abs(fo), floor_e)
+                finite = bool(np.all(np.isfinite(W)) and np.all(np.isfinite(H)) and np.all(np.isfinite(errors)))
+                ok = finite and same and rel_e <= 1e-3 and dW <= 6e-3 and dH <= 6e-3 and rel_f <= 1e-4
+                rep = getattr(m, 'last_fp8_report', None) or {}
+                print('%-6d x %-4d k=%-3d %-28s fit=%d  %s  len %d/%d  losses %.1e  W %.1e  H %.1e  final KL %.1e  fp8 tiles %s ne %s  %s' % (
+                    n, f, k, name, fit, 'ok  ' if ok else 'FAIL', len(errors), len(eo), rel_e, dW, dH, rel_f,
+                    rep.get('tile_iterations'), rep.get('no_numerator_eps'), buf.getvalue().strip().replace('\n', ' | ')[:70]), flush=True)
+                bad += 0 if ok else 1
+    print('%d case(s) outside their tolerance' % bad)
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

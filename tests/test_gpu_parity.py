@@ -985,6 +985,30 @@ def test_first_update_after_init_keeps_its_ratios_inside_the_half_range(monkeypa
         assert errors[1] > 1.5 * eo[1]                         # ... and without the scale the first H rule is clipped
 
 
+@pytest.mark.parametrize('scale', [1e-9, 1e-6, 1e-3, 1e3, 1e6, 1e9])
+@pytest.mark.parametrize('n,f,k', [(300, 96, 40), (70001, 64, 8)])
+def test_data_of_any_magnitude_keeps_the_reference_eps(n, f, k, scale):
+    """The reference's eps = 1e-8 is absolute (nmf.py:325-336): against V of magnitude 1e-6 it is 1 % of every ratio, against V
+    of magnitude 1e6 it only keeps 0 / 0 out of rows without mass (the padding of the last row tile).  The 16-bit modes carry
+    it through the matrix product as an fp16 pair whose row value is eps x (storage factor) x 2^10: found by
+    scripts/data_fuzz.py (round 4) -- beyond 65504 for max(V) < 5e-6 (losses 4-9 % off at V x 1e-6, k = 40) and flushed to
+    zero for max(V) > 1e7 (NaN losses at 70 000 rows x 1e6: the padded rows divided 0 by 0).  Outside the pair's range the
+    kernels now add eps in fp32 (klnmf_api.hip, choose_eps_carrier)."""
+    rs = np.random.RandomState(n + f + k)
+    X = (rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))) * scale
+    H0 = orc.synthetic_H0(11, f, k)
+    iters = 3
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    assert np.isfinite(errors).all() and np.isfinite(W).all() and np.isfinite(m.components_).all()
+    m_ = min(len(errors), len(eo))            # (x 1e-9: the loss is negative at once -- eps dominates -- and both runs stop at 1)
+    assert m_ >= 1 and abs(len(errors) - len(eo)) <= 1
+    assert_allclose(errors[:m_], eo[:m_], rtol=2e-4)
+    if len(errors) == len(eo):
+        assert _rel_to_max(W, Wo) < 5e-3
+        assert _rel_to_max(m.components_, Ho) < 5e-3
+
+
 # ---- e4m3 saturation: counted, and kept out of the result (round 3) ---------------------------------------------------
 def _piece_loop(ctx, iters, after=None):
     """The loop of nmf.py:212-222 through the piece API (klnmf_iter_*), `after(it)` between iterations."""
