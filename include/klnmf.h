@@ -149,6 +149,9 @@ int klnmf_loop_begin(klnmf_ctx *ctx);
  * ALL shards -- sum of V (klnmf_query_f64 KLNMF_QF_SUM_V, all-reduced) and its element count -- so that every rank runs
  * the same kernels and the result does not depend on the partition beyond summation order. */
 int klnmf_loop_begin_sharded(klnmf_ctx *ctx, double sum_v_all, double cells_all);
+/* ... and with the number of entries of V that are > 0 over all shards (klnmf_query_f64 KLNMF_QF_NNZ_V, all-reduced): fp8 ratio
+ * tiles need enough of them per column, not enough rows (sparse data stored densely).  nnz_all < 0: as the call above (dense). */
+int klnmf_loop_begin_sharded_nnz(klnmf_ctx *ctx, double sum_v_all, double cells_all, double nnz_all);
 /* `iters` whole iterations of the open loop at once, enqueued exactly as klnmf_run enqueues them (callers that fence between
  * two parts of one loop: warm-up | timed iterations of bench.py).
  * On a context that holds an RCCL communicator of more than one rank (klnmf_comm_init below) klnmf_loop_begin and
@@ -297,6 +300,8 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
 int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 /*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */
 #define KLNMF_QF_SUM_V            0
+/*   KLNMF_QF_NNZ_V  how many entries of the uploaded V are > 0 as stored (16-bit modes) */
+#define KLNMF_QF_NNZ_V            1
 int klnmf_query_f64(klnmf_ctx *ctx, int what, double *value);
 
 /* ---- measurement -------------------------------------------------------- */

@@ -56,6 +56,7 @@ SIGNATURES = {
                              _c.POINTER(_c.c_int)]),
     'klnmf_loop_begin': (_c.c_int, [_ctx_p]),
     'klnmf_loop_begin_sharded': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double]),
+    'klnmf_loop_begin_sharded_nnz': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double, _c.c_double]),
     'klnmf_run_more': (_c.c_int, [_ctx_p, _i64, _c.c_int, _c.c_double]),
     'klnmf_iter_rowpass': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_iter_decide': (_c.c_int, [_ctx_p, _c.c_double]),
@@ -470,18 +471,26 @@ class Context(object):
         nd = int(n_done.value)
         return [float(errs[i]) for i in range(min(nd, int(max_iter)))], nd, bool(stopped.value)
 
-    def loop_begin(self, sum_v_all=None, cells_all=None):
-        """klnmf_loop_begin; with the all-reduced sum of V and element count: klnmf_loop_begin_sharded (one rank of a
-        row-sharded problem -- every rank then takes the same fp8 decision)."""
+    def loop_begin(self, sum_v_all=None, cells_all=None, nnz_all=None):
+        """klnmf_loop_begin; with the all-reduced sum of V, element count (and count of entries > 0):
+        klnmf_loop_begin_sharded(_nnz) (one rank of a row-sharded problem -- every rank then takes the same fp8 decision)."""
         if sum_v_all is None:
             _check(self._lib.klnmf_loop_begin(self._h))
-        else:
+        elif nnz_all is None:
             _check(self._lib.klnmf_loop_begin_sharded(self._h, float(sum_v_all), float(cells_all)))
+        else:
+            _check(self._lib.klnmf_loop_begin_sharded_nnz(self._h, float(sum_v_all), float(cells_all), float(nnz_all)))
 
     def sum_V(self):
         """Sum of the uploaded V as stored (klnmf_query_f64 KLNMF_QF_SUM_V)."""
         v = _c.c_double(0.0)
         _check(self._lib.klnmf_query_f64(self._h, 0, ctypes.byref(v)))
+        return float(v.value)
+
+    def nnz_V(self):
+        """How many entries of the uploaded V are > 0 as stored (klnmf_query_f64 KLNMF_QF_NNZ_V)."""
+        v = _c.c_double(0.0)
+        _check(self._lib.klnmf_query_f64(self._h, 1, ctypes.byref(v)))
         return float(v.value)
 
     def run_more(self, iters, fit=True, tol_abs=0.0):

@@ -29,6 +29,8 @@ struct DevState {
     double corr_c;     // storage-rounding correction of the loss (0 when V is stored exactly)
     double corr_eps;   // sum over the stored V of x ln(1 + eps/x): what the loss of an update pass WITHOUT the numerator's eps
                        // (ratio x / (W.H + eps): mfma4.hip.h, NE) lacks against the reference's x ln((x + eps) / (W.H + eps))
+    double nnz_x;      // entries of the stored V that are > 0 (counted at upload): the fp8 decision of a loop needs enough of them per
+                       // column, not enough ROWS (klnmf_api.hip, begin_fp8_loop)
     int stop;          // stop rule fired (the `break` of nmf.py:216)
     int n_done;        // updates executed == len(errors)
     int v_overflow;    // uploaded values that exceeded the fp16 range announced with klnmf_set_v_max (saturated)

@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
                                                 const int64_t *row_idx = nullptr, double eps_s = 0.0) {
     __shared__ double red[16];
     const int64_t total = rows * cols;
-    double sx = 0, cc = 0, ce = 0;
+    double sx = 0, cc = 0, ce = 0, nz = 0;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ii = e / cols, jj = e % cols;
@@ -1070,14 +1070,17 @@ __global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int n
         VtA[(rt * nct + ctile) * 1024 + (eA / EPP) * (64 * EPP) + laneA * EPP + (eA % EPP)] = xs;
         if (VtB) VtB[(ctile * nrt + rt) * 1024 + (eB / EPP) * (64 * EPP) + laneB * EPP + (eB % EPP)] = xs;      // only the recomputing column pass reads it
         sx += xt;
+        nz += xt > 0 ? 1.0 : 0.0;
         cc += (xt > 0 && xv > 0) ? xt * log(xt / xv) - (xt - xv) : (xv - xt);
         if (sizeof(VT) == 2 && xt > 0) ce += xt * log1p(eps_s / xt);
     }
     const double tsx = block_sum(sx, red);
     const double tcc = block_sum(cc, red);
     const double tce = block_sum(ce, red);
+    const double tnz = block_sum(nz, red);
     if (threadIdx.x == 0) {
         atomicAdd(&st->sum_x, tsx);
+        atomicAdd(&st->nnz_x, tnz);
         atomicAdd(&st->corr_c, tcc);
         if (sizeof(VT) == 2) atomicAdd(&st->corr_eps, tce);
     }

@@ -177,19 +177,22 @@ class ShardedKLNMF(object):
         err = None
         if multi and hasattr(self.ctx, 'sum_V'):
             # every rank must take the same fp8 decision (16-bit modes): it is made from the sums over ALL shards, as
-            # klnmf_run_sharded does on the native path.  ONE all-reduce carries [sum V, cells, refusal flag]: a rank whose
+            # klnmf_run_sharded does on the native path.  ONE all-reduce carries [sum V, cells, refusal flag, entries > 0]: a rank whose
             # own sum cannot be read joins it with zeros and its flag set, so no rank is ever alone in a collective of
             # another shape
-            vals = [0.0, 0.0, 0.0]
+            vals = [0.0, 0.0, 0.0, 0.0]
             try:
-                vals = [self.ctx.sum_V(), float(self.n_local) * float(self.f), 0.0]
+                cells = float(self.n_local) * float(self.f)
+                # (entries > 0: fp8 tiles need enough of them per column; a context that cannot count them reports a dense shard)
+                nnz = self.ctx.nnz_V() if hasattr(self.ctx, 'nnz_V') else cells
+                vals = [self.ctx.sum_V(), cells, 0.0, nnz]
             except Exception as e:
-                err, vals = e, [0.0, 0.0, 1.0]
+                err, vals = e, [0.0, 0.0, 1.0, 0.0]
             t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.tensor_device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             if err is None and float(t[2].item()) == 0.0:
                 try:
-                    self.ctx.loop_begin(float(t[0].item()), float(t[1].item()))
+                    self.ctx.loop_begin(float(t[0].item()), float(t[1].item()), float(t[3].item()))
                 except Exception as e:         # (reported below, on every rank)
                     err = e
             elif err is None:

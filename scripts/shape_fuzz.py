@@ -66,7 +66,7 @@ def main():
             sx = float(X.sum())
             # losses near zero (an exact fit: k >= min(n, f), one row, one column) are compared on the data's scale; the f16 mode's
             # loss carries the storage rounding of V (2^-11 per entry: ~1e-7 of sum(x) in the KL)
-            floor_e = (1e-4 if prec != 'f64' else 1e-12) * sx
+            floor_e = {'f64': 1e-12, 'f32': 1e-6}.get(prec, 1e-4) * sx
             m_ = min(len(errors), len(eo))
             # tol = 0 stops at the first iteration whose loss does not fall: on a plateau (k = 1 converges in one update) that is
             # decided by the last bit of a sum, so the two runs may stop one or two iterations apart there
@@ -84,6 +84,8 @@ def main():
             rel_f = abs(final_g - final_o) / max(abs(final_o), floor_e)
             if prec == 'f64':
                 lim_e, lim_w, lim_f = 1e-9, 1e-7, 1e-9
+            elif prec == 'f32':
+                lim_e, lim_w, lim_f = 2e-5, 2e-4, 2e-5
             else:
                 lim_e, lim_w, lim_f = 1e-3, 6e-3, 1e-4
             ok = ok and rel_e <= lim_e and dW <= lim_w and dH <= lim_w and rel_f <= lim_f

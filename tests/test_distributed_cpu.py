@@ -295,7 +295,7 @@ class NoSumContext(OracleContext):
             raise RuntimeError("klnmf error -4: hipMemcpyAsync: device lost")
         return float(self.V.sum())
 
-    def loop_begin(self, sum_all=None, cells_all=None):
+    def loop_begin(self, sum_all=None, cells_all=None, nnz_all=None):
         OracleContext.loop_begin(self)
 
 
@@ -325,7 +325,7 @@ def _nosum_worker(rank, world, port, out_dir):
 def test_a_failing_sum_on_one_rank_joins_the_same_collective(tmp_path):
     """an exception from ctx.sum_V() on one rank happened BEFORE the entry's first all-reduce, so that rank
     went straight to the 1-element flag all-reduce while its peers sat in the 2-element one (mismatched collectives).  The
-    flag now rides in the same 3-element all-reduce: every rank raises, nobody hangs."""
+    flag now rides in the same all-reduce (sums, cells, flag, entries > 0): every rank raises, nobody hangs."""
     import torch.multiprocessing as mp
     mp.spawn(_nosum_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]

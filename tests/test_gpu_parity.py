@@ -1009,6 +1009,32 @@ def test_data_of_any_magnitude_keeps_the_reference_eps(n, f, k, scale):
         assert _rel_to_max(m.components_, Ho) < 5e-3
 
 
+def test_sparse_data_stored_densely_keeps_16_bit_ratio_tiles(monkeypatch):
+    """fp8 ratio tiles are admitted from 32 769 rows because the H numerator averages their 3-bit significands over the rows --
+    over the rows that hold something: with 95 % zeros (histogram data stored densely) 70 000 rows are 3 500 entries per
+    column, and the fit converges 2e-4 away from the oracle's KL (scripts/data_fuzz.py, round 4).  The loop's entry now
+    counts the entries > 0 per column (DevState.nnz_x, all-reduced on row shards); dense data of the same shape keeps the
+    fp8 tiles.  KLNMF_Q8_SPARSE_OK=1 shows the old behaviour.  Reference: nmf.py:345-351 (the H rule's sum over samples)."""
+    for name in ('KLNMF_QTILE', 'KLNMF_Q8_SPARSE_OK', 'KLNMF_NE'):
+        monkeypatch.delenv(name, raising=False)
+    n, f, k, iters = 70000, 96, 40, 60
+    rs = np.random.RandomState(3)
+    D = rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
+    X = D * (rs.random_sample((n, f)) < 0.05)
+    H0 = orc.synthetic_H0(11, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    final_o = orc.kl_error(X, Wo, Ho)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    assert m.last_fp8_report['tile_iterations'] == 0
+    assert abs(orc.kl_error(X, W, m.components_) - final_o) <= 1e-4 * final_o
+    monkeypatch.setenv('KLNMF_Q8_SPARSE_OK', '1')
+    m8, W8, e8, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    assert m8.last_fp8_report['tile_iterations'] > 0          # (measured: 1.5e-4 ... 2e-4 off -- what the rule is for)
+    monkeypatch.delenv('KLNMF_Q8_SPARSE_OK')
+    md, Wd, ed, _ = fit_gpu(D, H0, k, 6, 0, precision='f16')
+    assert md.last_fp8_report['tile_iterations'] == 4          # dense data: fp8 tiles from the third iteration on, as before
+
+
 # ---- e4m3 saturation: counted, and kept out of the result (round 3) ---------------------------------------------------
 def _piece_loop(ctx, iters, after=None):
     """The loop of nmf.py:212-222 through the piece API (klnmf_iter_*), `after(it)` between iterations."""
