@@ -69,6 +69,50 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, precision, rtol, wo
         np.testing.assert_allclose(r['W'], W1, rtol=50 * rtol, atol=1e-6 * np.abs(W1).max())
 
 
+def _worker_wide(rank, world, port, n, f, k, iters, out_dir):
+    import torch
+    import torch.distributed as dist
+    from multimodal_amd.distributed import ShardedKLNMF, row_partition
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        X = orc.synthetic_V(7 + n + f + k, n, f, k)
+        H0 = orc.synthetic_H0(7 + n + f + k, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=iters, precision='f16')
+        m.set_v_max(X.max())
+        m.upload_V(X[r0:r1])
+        m.set_H(H0)
+        m.init_W()
+        errors, n_done, stopped = m.run(iters, fit=True, tol=0.0)
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), W=m.gather_W(), H=m.get_H(), errors=np.array(errors))
+        m.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_row_shards_take_the_same_ratio_scale_in_the_first_update(tmp_path):
+    """f / k = 1377: the first update's ratios pass the fp16 range and the dictionary image carries the ratio scale
+    (k_ratio_scale).  The scale is derived from the dictionary alone, so every rank takes the same one whatever its rows
+    hold: the replicas of H stay bit-identical, the all-reduced numerator is scaled as a whole, and losses and factors
+    equal the oracle's as in the single-context test (test_first_update_after_init_keeps_its_ratios_inside_the_half_range)."""
+    import torch.multiprocessing as mp
+    n, f, k, iters, world = 400, 2755, 2, 3, 2
+    mp.spawn(_worker_wide, args=(world, _free_port(), n, f, k, iters, str(tmp_path)), nprocs=world, join=True)
+    X = orc.synthetic_V(7 + n + f + k, n, f, k)
+    H0 = orc.synthetic_H0(7 + n + f + k, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    np.testing.assert_array_equal(res[0]['H'], res[1]['H'])
+    np.testing.assert_array_equal(res[0]['errors'], res[1]['errors'])
+    np.testing.assert_allclose(res[0]['errors'], eo, rtol=1e-4)
+    assert np.abs(res[0]['H'] - Ho).max() < 5e-3 * np.abs(Ho).max()
+    assert np.abs(res[0]['W'] - Wo).max() < 5e-3 * np.abs(Wo).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('precision', ['f16', 'f64'])
 def test_native_collective_path_single_rank_communicator(precision):
