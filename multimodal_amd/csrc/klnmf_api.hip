@@ -317,7 +317,7 @@ struct klnmf_ctx {
     // row shards over the GPUs of a node (klnmf_comm_*, klnmf_run_sharded): this rank's RCCL communicator
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
-    double *comm_scratch = nullptr;       // 2 doubles on the device, owned by the communicator (not by a problem)
+    double *comm_scratch = nullptr;       // 8 doubles on the device, owned by the communicator (not by a problem)
 
     bool is_exact() const { return prec == KLNMF_PREC_F64 || prec == KLNMF_PREC_F32; }
     // fp8 ratio tiles from how many rows per context?  Their e4m3 rounding only enters the H numerator, a sum over all rows
