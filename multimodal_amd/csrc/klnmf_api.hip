@@ -1066,8 +1066,8 @@ void measure_and_pack(klnmf_ctx *c, bool from_init = false) {
         (void)std::frexp(32768.0 / ev, &ex);
         e_cap = std::min(12, std::max(0, ex - 1));
     }
-    hipLaunchKernelGGL(k_ratio_scale, dim3(1), dim3(1024), 0, c->stream, (const float *)c->H32, (int)c->k, c->f, c->f_pad, c->st,
-                       from_init && cq_ok ? 1 : 0, e_cap);
+    hipLaunchKernelGGL(k_ratio_scale, dim3(1), dim3(256), 0, c->stream, (const double *)c->hsum, (const float *)c->tcur, (int)c->k, c->f,
+                       c->st, from_init && cq_ok ? 1 : 0, e_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->wmax, 0, (size_t)c->KP * 4, c->stream));
     HIPCHK(hipMemsetAsync(&c->st->op_range, 0, sizeof(int), c->stream));
