@@ -1829,8 +1829,12 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->v_uploaded = false;
             c->refusals_dirty = true;
             const int total_stages = c->nrt / kStageRowTiles;
-            // bf16 W images are streamed in 64-row stages by global_load_lds in 8 KiB rounds: pad the tail
-            c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + 64;
+            // the fp16 W images are streamed by global_load_lds in whole 8 KiB rounds, i.e. a stage's copy reads on into the rows
+            // behind it: pad the tail by what ONE copy covers.  (64 rows until round 4: at KP = 32 a row is 64 bytes and a copy 128
+            // rows -- the last stage read 2 KiB past the image; found by scripts/shape_fuzz.py as a memory access fault at
+            // 16 305 x 28, k = 8, where the image is exactly 1 MiB and ends on a mapping boundary.)
+            const int64_t copy_rows = (colq_w_area(c->KP) + (int64_t)w_ld(c->KP) * 2 - 1) / ((int64_t)w_ld(c->KP) * 2);
+            c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + std::max<int64_t>(64, copy_rows);
             const size_t vs = c->vsize();
             const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * vs;
             // column pass on the ratios the ping-pong row pass stores (k_colpass_q) where that row pass runs;

@@ -1035,6 +1035,22 @@ def test_sparse_data_stored_densely_keeps_16_bit_ratio_tiles(monkeypatch):
     assert md.last_fp8_report['tile_iterations'] == 4          # dense data: fp8 tiles from the third iteration on, as before
 
 
+@pytest.mark.parametrize('n,f,k', [(16305, 28, 8), (16256, 40, 5), (8128, 64, 32)])
+def test_w_image_tail_padding_covers_a_whole_copy_at_k_le_32(n, f, k):
+    """The column pass streams the fp16 W image in whole 8 KiB global_load_lds rounds: at KP = 32 (k <= 32: 64-byte rows) one
+    copy covers 128 rows, the image's tail padding was 64 -- the last stage read 2 KiB past the allocation.  Harmless unless
+    the image ends on a mapping boundary: 16 305 x 28, k = 8 (image = exactly 1 MiB) gave a GPU memory access fault in
+    scripts/shape_fuzz.py --seed 21 (round 4).  The padding is now one copy's rows; these shapes put the image's end on a
+    power-of-two size."""
+    X = orc.synthetic_V(7 + n + f + k, n, f, k)
+    H0 = orc.synthetic_H0(7 + n + f + k, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=4, tol=0)
+    for prec in ('f16', 'f16_v32'):
+        m, W, errors, _ = fit_gpu(X, H0, k, 4, 0, precision=prec)
+        assert_allclose(errors, eo, rtol=2e-4)
+        assert _rel_to_max(W, Wo) < 5e-3 and _rel_to_max(m.components_, Ho) < 5e-3
+
+
 # ---- e4m3 saturation: counted, and kept out of the result (round 3) ---------------------------------------------------
 def _piece_loop(ctx, iters, after=None):
     """The loop of nmf.py:212-222 through the piece API (klnmf_iter_*), `after(it)` between iterations."""
