@@ -2372,6 +2372,12 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     // 3 500 entries per column, final KL 2e-4 off the oracle's after 100 iterations on fp8 tiles, 1e-7 on 16-bit tiles.  The
     // row threshold of klnmf_set_problem (32 769 / 65 536 rows) is therefore applied to the stored entries per column as
     // well, with a factor 2 of slack (dense data with a few zeros must not flip at the threshold).
+    // ... and by the ratios' own spread: e4m3 has a step of 6-12 % around 1, and a fit whose ratios all sit inside one step of 1
+    // (few components on nearly noise-free low-rank data) loses exactly the deviations the H rule lives on -- a dead zone, not
+    // noise that averages out.  Round 4's shape fuzz: 33 118 x 424 with k = 1 / 2 ends 1.2e-3 / 6e-5 (40 000 x 64, k = 2: 5e-4)
+    // off the oracle's KL on fp8 tiles, 6e-6 on 16-bit tiles; k = 3: 3e-6, k = 5: 1e-5 (CPU emulation of the rounding alone
+    // reproduces the figures: experiments/README.md).  Fewer than four components keep the 16-bit tiles.
+    if (c->k < 4 && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0)) c->q8_loop = false;
     const double per_col = nnz / (double)c->f;
     if (per_col < 0.5 * (c->big ? 65536.0 : 32768.0) && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0))
         c->q8_loop = false;
