@@ -2377,7 +2377,9 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     // noise that averages out.  Round 4's shape fuzz: 33 118 x 424 with k = 1 / 2 ends 1.2e-3 / 6e-5 (40 000 x 64, k = 2: 5e-4)
     // off the oracle's KL on fp8 tiles, 6e-6 on 16-bit tiles; k = 3: 3e-6, k = 5: 1e-5 (CPU emulation of the rounding alone
     // reproduces the figures: experiments/README.md).  Fewer than four components keep the 16-bit tiles.
-    if (c->k < 4 && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0)) c->q8_loop = false;
+    // The same dead zone opens when a handful of columns is fitted almost exactly (103 431 x 8, k = 4: 2.7e-4 off; 41 388 x 3,
+    // k = 10: the loss itself goes to 0): less than one column tile of data keeps the 16-bit tiles too (nothing to gain there).
+    if ((c->k < 4 || c->f < 32) && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0)) c->q8_loop = false;
     const double per_col = nnz / (double)c->f;
     if (per_col < 0.5 * (c->big ? 65536.0 : 32768.0) && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0))
         c->q8_loop = false;

@@ -23,6 +23,10 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--precisions', default='f64,f16')
     ap.add_argument('--iters', type=int, default=6)
+    ap.add_argument('--nmax', type=int, default=80000)
+    ap.add_argument('--fmax', type=int, default=3000)
+    ap.add_argument('--kmax', type=int, default=300)
+    ap.add_argument('--no-edge', action='store_true')
     args = ap.parse_args()
     from multimodal_amd.lib import nmf
     from oracle import klnmf_oracle as orc
@@ -37,15 +41,15 @@ def main():
     rs = np.random.RandomState(args.seed)
     rnd = []
     for _ in range(args.random):
-        n = int(np.exp(rs.uniform(np.log(2), np.log(80000))))
-        f = int(np.exp(rs.uniform(np.log(2), np.log(3000))))
-        k = int(np.exp(rs.uniform(np.log(1), np.log(300))))
+        n = int(np.exp(rs.uniform(np.log(2), np.log(args.nmax))))
+        f = int(np.exp(rs.uniform(np.log(2), np.log(args.fmax))))
+        k = int(np.exp(rs.uniform(np.log(1), np.log(args.kmax))))
         if n * f * k > 6e9:
             f = max(2, int(6e9 / (n * k)))
         rnd.append((n, f, k))
     bad = 0
     for prec in args.precisions.split(','):
-        for (n, f, k) in edge + rnd:
+        for (n, f, k) in ([] if args.no_edge else edge) + rnd:
             X = orc.synthetic_V(7 + n + f + k, n, f, k)
             H0 = orc.synthetic_H0(7 + n + f + k, f, k)
             t0 = time.time()
