@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--fmax', type=int, default=3000)
     ap.add_argument('--kmax', type=int, default=300)
     ap.add_argument('--no-edge', action='store_true')
+    ap.add_argument('--shapes', default='', help='extra shapes, e.g. 64x110000x50,200x65536x8')
     args = ap.parse_args()
     from multimodal_amd.lib import nmf
     from oracle import klnmf_oracle as orc
@@ -47,9 +48,10 @@ def main():
         if n * f * k > 6e9:
             f = max(2, int(6e9 / (n * k)))
         rnd.append((n, f, k))
+    extra = [tuple(int(v) for v in t.split('x')) for t in args.shapes.split(',') if t]
     bad = 0
     for prec in args.precisions.split(','):
-        for (n, f, k) in ([] if args.no_edge else edge) + rnd:
+        for (n, f, k) in ([] if args.no_edge else edge) + extra + rnd:
             X = orc.synthetic_V(7 + n + f + k, n, f, k)
             H0 = orc.synthetic_H0(7 + n + f + k, f, k)
             t0 = time.time()
