@@ -965,8 +965,8 @@ KL_GLOBAL void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
 // MEAN of its row of V, and k such means replace a SUM over f columns), so the first ratios are that much larger than 1 --
 // beyond 65504, the largest f16, from f / k ~ 1000 on with heavy-tailed data (round 4's shape fuzz: k = 1, f = 2755; the
 // saturated operands clip the first H numerator and errors[1] is off by a factor 2, the run recovers two iterations later).
-// One block: cq_e = floor(log2(f / sum of the dictionary's entries)), 0 below 2^7 (ratios up to 500 x their mean still fit) and
-// at most 12.  Derived from the dictionary alone, so that every rank of a row-sharded loop takes the same value.  The image
+// One block: cq_e = floor(log2(f / sum of the dictionary's entries)), 0 below 2^7 (ratios up to 500 x their mean still fit), or
+// what brings the worst case f^2 / sum down to 2^15 if that is more; at most 12.  Derived from the dictionary alone, so that every rank of a row-sharded loop takes the same value.  The image
 // packed next carries 2^cq_e (k_update_pack_H); the update pass then sees W.H x 2^cq_e and a ratio / 2^cq_e: its second
 // product Q.H^T multiplies the two and is unchanged, the H numerator is scaled as a whole and the row normalisation removes
 // it, the loss adds cq_e x sum(x) to its sum of x log2(ratio) (loss_from_parts_block).  enable = 0: writes 0.
@@ -985,8 +985,15 @@ KL_GLOBAL __launch_bounds__(256) void k_ratio_scale(const double *hsum, const fl
             int ex = 0;
             (void)frexp((double)f / t, &ex);          // f / t = m 2^ex, m in [0.5, 1)  ->  floor(log2) = ex - 1
             e = ex - 1;
+            if (e < 7) e = 0;                  // (a mean ratio below 128: ratios 500 x their mean still fit)
+            // ... and the WORST first ratio: a row of V that is one entry x at column j has W0_a = x H0_aj and a ratio of
+            // 1 / sum_a H0_aj^2 there -- f^2 / k for a flat dictionary, 3.4e5 at f = 4096, k = 50 (data fuzz, round 4: one entry
+            // 1e4 x the rest made errors[1] 38 % wrong; log-normal data with sigma 2 the same in small).  The scale that puts
+            // f^2 / sum(H0) at 2^15 leaves the ordinary ratios (f / k) far inside the half range: f16 spans 30 binades.
+            int ex2 = 0;
+            (void)frexp((double)f / t * (double)f, &ex2);      // = m 2^ex2, m in [0.5, 1): ceil(log2) <= ex2
+            if (ex2 - 15 > e) e = ex2 - 15;
             if (e > e_cap) e = e_cap;          // (12, or what the image's eps row can take)
-            if (e < 7) e = 0;
         }
         st->cq_e = e;
     }

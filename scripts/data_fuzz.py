@@ -42,11 +42,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--precision', default='f16')
     ap.add_argument('--iters', type=int, default=8)
+    ap.add_argument('--shapes', default='300x200x5,40000x64x8,70000x96x40')
     args = ap.parse_args()
     from multimodal_amd.lib import nmf
     from oracle import klnmf_oracle as orc
     bad = 0
-    for (n, f, k) in [(300, 200, 5), (40000, 64, 8), (70000, 96, 40)]:
+    for (n, f, k) in [tuple(int(v) for v in t.split('x')) for t in args.shapes.split(',')]:
         rs = np.random.RandomState(n + f + k)
         for name, X in families(rs, n, f, k):
             H0 = orc.synthetic_H0(11, f, k)

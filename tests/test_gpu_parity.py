@@ -1069,6 +1069,34 @@ def test_fewer_than_four_components_keep_16_bit_ratio_tiles(monkeypatch, n, f, k
     assert abs(orc.kl_error(X, W, m.components_) - final_o) <= 1e-4 * final_o
 
 
+@pytest.mark.parametrize('kind', ['one-hot row', 'one spike 1e4 x max'])
+def test_rows_dominated_by_one_entry_keep_their_first_ratio_inside_the_half_range(monkeypatch, kind):
+    """A row of V that is (nearly) one entry x at column j starts from W0_a = x H0_aj (nmf.py:156), so its first ratio there is
+    1 / sum_a H0_aj^2 -- f^2 / k for a flat dictionary: 3.4e5 at f = 4096, k = 50, beyond fp16 although f / k is only 82.
+    scripts/data_fuzz.py (round 4) found it with one entry 1e4 x the maximum: errors[1] 38 % off, factors 4-16 % off.  The
+    first update's ratio scale (k_ratio_scale) now also covers that worst case; KLNMF_RATIO_SCALE=0 shows the clipped result."""
+    monkeypatch.delenv('KLNMF_RATIO_SCALE', raising=False)
+    n, f, k, iters = 1000, 4096, 50, 4
+    rs = np.random.RandomState(n + f + k)
+    X = rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
+    if kind == 'one-hot row':
+        X[5, :] = 0.0
+        X[5, 100] = 7.0
+    else:
+        X[n // 2, f // 2] = 1e4 * X.max()
+    H0 = orc.synthetic_H0(11, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    q0 = orc.ratio_q(X, X.dot(H0.T), H0)
+    assert q0.max() > 65504.                                     # the case IS beyond the half range
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    assert_allclose(errors, eo, rtol=1e-3)
+    assert _rel_to_max(W, Wo) < 5e-3 and _rel_to_max(m.components_, Ho) < 5e-3
+    if kind != 'one-hot row':          # (one clipped row of ordinary magnitude barely shows in the maxima; the spike carries the loss)
+        monkeypatch.setenv('KLNMF_RATIO_SCALE', '0')
+        m, W, e_clipped, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+        assert max(_rel_to_max(W, Wo), _rel_to_max(m.components_, Ho), abs(e_clipped[1] - eo[1]) / eo[1]) > 2e-2
+
+
 # ---- e4m3 saturation: counted, and kept out of the result (round 3) ---------------------------------------------------
 def _piece_loop(ctx, iters, after=None):
     """The loop of nmf.py:212-222 through the piece API (klnmf_iter_*), `after(it)` between iterations."""
