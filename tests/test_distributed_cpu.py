@@ -384,3 +384,51 @@ def test_native_communicator_preflight_is_agreed(tmp_path):
     msgs = [open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read() for r in range(2)]
     assert 'librccl not found' in msgs[1]
     assert 'not usable on another rank' in msgs[0]
+
+
+class CountingContext(OracleContext):
+    """A shard that can count its entries > 0 (klnmf_query_f64 KLNMF_QF_NNZ_V) and records what the loop's entry was given."""
+
+    def sum_V(self):
+        return float(self.V.sum())
+
+    def nnz_V(self):
+        return float((self.V > 0).sum())
+
+    def loop_begin(self, sum_all=None, cells_all=None, nnz_all=None):
+        self.entry = (sum_all, cells_all, nnz_all)
+        OracleContext.loop_begin(self)
+
+
+def _nnz_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n, f, k = 96, 40, 6
+        X = orc.synthetic_V(77, n, f, k)
+        X[:40] *= (np.random.RandomState(3).random_sample((40, f)) < 0.1)      # the first shard is sparse, the second dense
+        r0, r1 = row_partition(n, world)[rank]
+        ctx = CountingContext()
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=2, backend=ctx)
+        m.set_v_max(X.max()); m.upload_V(X[r0:r1]); m.set_H(orc.synthetic_H0(77, f, k)); m.init_W()
+        m.run(2, fit=True, tol=0.0)
+        np.save(os.path.join(out_dir, 'r%d.npy' % rank), np.array(ctx.entry, dtype=np.float64))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_rank_enters_the_loop_with_the_global_count_of_entries(tmp_path):
+    """Round 4: the fp8 decision of a loop needs enough ENTRIES > 0 per column (sparse data stored densely), so the loop's entry
+    all-reduces the shards' counts with their sums (one 4-element all-reduce: sum, cells, refusal flag, entries) and hands
+    every context the same three global numbers -- klnmf_loop_begin_sharded_nnz on the HIP path."""
+    import torch.multiprocessing as mp
+    mp.spawn(_nnz_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    n, f, k = 96, 40, 6
+    X = orc.synthetic_V(77, n, f, k)
+    X[:40] *= (np.random.RandomState(3).random_sample((40, f)) < 0.1)
+    got = [np.load(os.path.join(str(tmp_path), 'r%d.npy' % r)) for r in range(2)]
+    np.testing.assert_array_equal(got[0], got[1])
+    np.testing.assert_allclose(got[0], [X.sum(), n * f, (X > 0).sum()], rtol=1e-12)
