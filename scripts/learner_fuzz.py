@@ -23,6 +23,8 @@ def main():
         (40000, (40, 24), (1.0, 30.0), 10),            # fp8 sizes
         (70000, (96, 32), (1.0, 1.0), 40),
         (150, (500, 7), (1.0, 1.0), 130),
+        (400, (4096, 16), (1.0, 1e3), 3),               # f / k in the thousands: the first update's ratio scale, on a slice too
+        (35000, (2000, 48), (1e-5, 1.0), 10),           # fp8 sizes, one modality of tiny numbers
     ]
     for prec in ('f64', 'f16'):
         os.environ['KLNMF_PRECISION'] = prec
