@@ -11,10 +11,8 @@ Exact fp64 updates, only the ratio that enters the H numerator rounded to e4m3(r
 
 The dead zone of exactly fitted columns is the boundary's asymmetry: with 1 in the middle of a binade the quantiser is uniform around
 it and the errors of a symmetric spread cancel.  v_cvt_scalef32_pk_fp8_f16 uses only the EXPONENT of its scale operand
-(experiments/micro/scale_probe.hip: scale 5.657 and 6 convert like 4), so the factor sqrt(2) cannot be the conversion's scale; it can
-ride in the dictionary image the way the first update's ratio scale does (W.H comes out 1/sqrt(2) smaller, the ratio sqrt(2) larger,
-Q.H^T unchanged, numerator scaled as a whole, loss - 0.5 sum(x), fix-ups x sqrt(2), the init pass x sqrt(2)) at no cost in the
-kernels.  Not built in round 4."""
+(experiments/micro/scale_probe.hip: scale 5.657 and 6 convert like 4), so the factor sqrt(2) cannot be the conversion's scale; it is
+one packed f16 multiply per pair in front of the conversion (mfma.hip.h, kQ8Mid): adopted in round 4 (-0.2 % at C4)."""
 import numpy as np, torch, sys
 sys.path.insert(0,'/root/repo')
 from oracle import klnmf_oracle as orc

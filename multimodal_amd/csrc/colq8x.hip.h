@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void k_q8_fixup(Q8FixArgs a) {
                 for (int c = tid; c < a.k; c += blockDim.x) {      // (several rows may share a column: atomic adds)
                     const float wimg = (float)a.Wb_new[i * a.wld + wb_col((int)(i & 31), c)];
                     const float wprod = used_w8 ? e4m3_value(a.W8[i * a.w8ld + c]) * a.w8s[c] : wimg;
-                    atomicAdd(&a.numer[(int64_t)c * a.f_pad + j], wimg * q_exact - wprod * held);
+                    atomicAdd(&a.numer[(int64_t)c * a.f_pad + j], wimg * (q_exact * kQ8Mid) - wprod * held);      // (the tiles' units: mfma.hip.h, kQ8Mid)
                 }
                 __syncthreads();
             }

@@ -68,6 +68,15 @@ typedef __attribute__((ext_vector_type(4))) opnd_t opx4;
 constexpr float kOpScaleH = 8192.f;              // 2^13
 constexpr float kOpScaleW = 1.f / 8192.f;
 constexpr float kCarrierW = 1.f / 1024.f;
+#ifndef KL_Q8_MID
+#define KL_Q8_MID 1
+#endif
+// KL_Q8_MID: the tiles hold ratio x kQ8Mid / 8 with kQ8Mid = sqrt(2): ratio 1 sits in the middle of an e4m3 binade, where the quantiser is
+// uniform, instead of on the boundary 2^-3, where it steps by 6 % below and 12 % above and biases every accurately fitted column
+// (experiments/fp8_tiles_mid_binade_emulation.py).  The conversion instruction uses only the exponent of its scale operand
+// (experiments/micro/scale_probe.hip), hence a packed multiply in front of it.  The H numerator then comes out sqrt(2) larger as a
+// whole (the row normalisation removes it); the exact fix-ups work in the same units.
+constexpr float kQ8Mid = KL_Q8_MID ? 1.41421356f : 1.f;
 constexpr float kQ8Scale = 8.f;                 // fp8 ratio tiles hold ratio / 8: e4m3 then covers 2^-6 .. 3584 (saturating), full precision from 0.125 on        // eps carrier: W image column kc holds 2^-10, H image row kc eps * 2^10
 // f32 -> f16 conversions that overflow give the largest finite half instead of infinity (MODE bit 23, FP16_OVFL; true
 // infinities stay): a ratio beyond 65504 (x > 0 where W.H ~ 0) or an operand beyond the image range then perturbs one

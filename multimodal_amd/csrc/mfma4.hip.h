@@ -427,8 +427,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             s16x2 w;                          // both halves are written below: no zero-fill instruction for the tied operand
             asm volatile("" : "=v"(w));
 #ifndef KL_OPND_BF16
+#if KL_Q8_MID       // ratio x sqrt(2) / 8: ratio 1 in the MIDDLE of an e4m3 binade (see kQ8Mid in mfma.hip.h)
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]} * f16x2{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]} * f16x2{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, true);
+#else
             w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, kQ8Scale, false);
             w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, kQ8Scale, true);
+#endif
 #endif
             pk[j] = __builtin_bit_cast(unsigned, w);
         }
@@ -589,8 +594,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 for (int j = 0; j < 2; ++j) {
                     s16x2h w;
                     asm volatile("" : "=v"(w));
+#if KL_Q8_MID
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j], b[4 * j + 1]} * f16x2h{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j + 2], b[4 * j + 3]} * f16x2h{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, true);
+#else
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j], b[4 * j + 1]}, kQ8Scale, false);
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j + 2], b[4 * j + 3]}, kQ8Scale, true);
+#endif
                     pk[j] = __builtin_bit_cast(unsigned, w);
                 }
                 (void)qp;

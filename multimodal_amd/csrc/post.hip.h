@@ -272,7 +272,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
                         const float q_exact = fmaf(x, rinv, a.eps * rinv);
                         const float wimg = (float)a.Wb_new[i * a.wld + wb_col((int)(i & 31), comp)];
                         const float wprod = used_w8 ? e4m3_value(a.W8[i * a.w8ld + comp]) * a.w8s[comp] : wimg;
-                        fix += wimg * q_exact - wprod * held;
+                        fix += wimg * (q_exact * kQ8Mid) - wprod * held;      // (the tiles' units: mfma.hip.h, kQ8Mid)
                     }
                     __syncthreads();
                 }
