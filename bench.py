@@ -185,7 +185,7 @@ def parse_args(argv=None):
     p.add_argument('--n', '--rows', dest='n', type=int, default=1000000)
     p.add_argument('--f', '--features', dest='f', type=int, default=4096)
     p.add_argument('--k', '--components', dest='k', type=int, default=200)
-    p.add_argument('--precision', default='f16', choices=['f16', 'f16_v32', 'bf16', 'bf16_v32', 'f32', 'f64'],
+    p.add_argument('--precision', default='f16', choices=['f16', 'bf16', 'f32', 'f64'],
                    help="f16: fp16 MFMA operands (scaled images), fp32 accumulate; 'bf16' is the round-1 name of the same mode")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-rows', type=int, default=100000,
@@ -559,8 +559,7 @@ def main():
         col_ms = prof_tot['colpass_ms'] / max(1, prof_tot['colpass_launches'])
         fast16 = args.precision in ('f16', 'bf16')
         vbytes = 2 if fast16 else 4
-        pingpong = fast16 and k <= 512 and os.environ.get('KLNMF_ROWPASS', '4') == '4'      # (224 < k <= 256 joined in round 3)
-        stored_q = pingpong and (k > 224 or os.environ.get('KLNMF_COLPASS', '2') in ('2', '3'))
+        stored_q = fast16 and k <= 512          # the 16-bit mode keeps the ratio tiles of its row pass for the column pass
         # what the timed loop ran, as the LIBRARY reports it (klnmf_query), not a host-side copy of its rules: the loop's
         # first two iterations keep 16-bit tiles; warm-up and timed iterations are ONE loop on every path, so the warm-up
         # absorbs them when --warmup >= 2
@@ -599,7 +598,7 @@ def main():
         traffic_row, traffic_col, traffic_file, traffic_hash = measured_traffic(args, n_local)
         src_hash = kernel_source_hash()
         roofline = {
-            'kernel': ('k_rowpass4' if pingpong else 'k_rowpass') + ' (W.H -> ratio/loss -> Q.H^T -> W rule'
+            'kernel': 'k_rowpass4' + ' (W.H -> ratio/loss -> Q.H^T -> W rule'
                       + (', ratio tiles stored for the H rule)' if stored_q else ')'),
             'bound': 'mfma' if mfma_bound else 'hbm',
             'achieved': row_tflops if mfma_bound else row_gbs,
@@ -665,7 +664,7 @@ def main():
             'dtype': (('f16 operands, fp32 accumulate; e4m3 ratio tiles and e4m3 W image in the H-numerator product'
                        if col8 else ('f16 operands, fp32 accumulate; e4m3 ratio tiles (converted back to f16) in the H-numerator product'
                                      if frac8 > 0 else 'f16'))
-                      if args.precision in ('f16', 'f16_v32', 'bf16', 'bf16_v32') else args.precision),
+                      if args.precision in ('f16', 'bf16') else args.precision),
             'data': 'synthetic',
             'config': {'workload': 'KL-NMF fit iteration, V %dx%d (row-sharded), k=%d' % (n, f, k),
                        'n': n, 'f': f, 'k': k, 'rows_per_gpu': n_local,

@@ -28,18 +28,31 @@
 #pragma once
 #include "mfma4.hip.h"
 
-// (The ratio tiles are written once by the row pass and read once here; as non-temporal copies the fp8 x fp8 column pass ran
-// 7 % SLOWER -- 0.92 vs 0.86 ms, the row pass behind it 2 % faster, the iteration equal: profiles/r03_ab_nontemporal.txt.)
+// the ratio tiles are written once by the row pass and read once here; as non-temporal copies (-DKL_Q_NT=1) the fp8 x fp8 column
+// pass ran 7 % SLOWER (0.92 vs 0.86 ms; the row pass behind it 2 % faster, the iteration equal): off (profiles/r03_ab_nontemporal.txt)
+#ifndef KL_Q_NT
+#define KL_Q_NT 0
+#endif
+#if KL_Q_NT
+#define KL_Q_NT_MOD " nt"
+#else
+#define KL_Q_NT_MOD ""
+#endif
 
 namespace klnmf {
 
 __host__ __device__ constexpr int colq_w_area(int kp) { return round_up(32 * w_ld(kp) * 2, kGldsRound); }
 __host__ __device__ constexpr int colq_obj_bytes(int kp, int ksplit, int qtile = kQTile) { return colq_w_area(kp) + kWavesPerWG / ksplit * qtile; }
 constexpr int kQTile8 = 1024;                    // bytes of one 32 x 32 fp8 ratio tile (mfma4.hip.h, Q8)
-// LDS objects (stages in flight + 1) of the f16-operand pass on 16-bit / on fp8 ratio tiles, and stages per fence of the latter
+#ifndef KL_COLQ_NB
 #define KL_COLQ_NB 4
+#endif
+#ifndef KL_COLQ8_PAIR       // fp8 ratio tiles (24 KiB objects at KT = 7): stages per fence and objects
 #define KL_COLQ8_PAIR 1
-#define KL_COLQ8_NB 4
+#endif
+#ifndef KL_COLQ8_NB
+#define KL_COLQ8_NB (KL_COLQ8_PAIR == 2 ? 6 : 4)
+#endif
 
 // Ratio-tile bytes the H numerator cannot take as they are: 0x7E = e4m3 448 = a ratio of 3584 or MORE (the row pass's
 // conversion saturates: the excess would be missing), and every byte >= 0x60 = a ratio >= 256 -- a single entry that large
@@ -99,6 +112,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         atomicAdd(&a.st_rw->w8_fallbacks, 1);
         atomicAdd(&a.st_rw->w8_sat_total, a.st->w8_sat);
     }
+#ifdef KL_COL_PRIO       // experiment: static priority for the second-dispatched half of the workgroup
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(KL_COL_PRIO);
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: scalar
     const int r = lane & 31, h = lane >> 5;
@@ -149,6 +165,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
     auto stage_in = [&](int o, int sg) {
         sg = min(sg, send - 1);                    // past the end: re-copy the last stage (uniform instruction count)
+#if !(KL_SADDR & 1)
+        glds_copy_exact<WA, kWavesPerWG>(wn + (int64_t)sg * WST, obj(o), tid);
+        const unsigned char *qs = qt + (int64_t)sg * QTB;
+#pragma unroll
+        for (int pp = 0; pp < QP; ++pp) {
+            const int p = Q8 ? pp : kh * QP + pp;  // KSPLIT = 2: the two waves of a column tile copy one piece each (Q8: the same tile)
+            __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + p * 256),
+                                             (KL_LDS void *)(obj(o) + WA + ctl * QTB + 1024 * p), 16, 0, 0);
+        }
+#else
         // scalar base + this lane's 32-bit offset, M0 from scalars (mfma4.hip.h `dma`)
         const unsigned char *wbase = wn + (int64_t)sg * WST;
         const unsigned t16 = (unsigned)tid * 16u, m0w = lds_addr(obj(o)) + (unsigned)wave * 1024u;
@@ -159,8 +185,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
 #pragma unroll
         for (int pp = 0; pp < QP; ++pp) {
             const int p = Q8 ? pp : kh * QP + pp;  // KSPLIT = 2: the two waves of a column tile copy one piece each (Q8: the same tile)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + ctl * QTB + 1024 * p), "v"(ql32), "s"(qbase + p * 256) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KL_Q_NT_MOD ::"s"(lds_addr(obj(o)) + WA + ctl * QTB + 1024 * p), "v"(ql32), "s"(qbase + p * 256) : "memory");
         }
+#endif
     };
     // one copy instruction of stage sg into object o (the order stage_in issues them in: W_new rounds, then ratio pieces)
     constexpr int WR = WA / kGldsRound;
@@ -204,6 +231,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(ring[0]));
         opx8 b0, b1;
         if constexpr (Q8 != 0) {
+#ifndef KL_OPND_BF16
             typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
             typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
             const u32x2 w0 = __builtin_bit_cast(u32x2, q0), w1 = __builtin_bit_cast(u32x2, q2);
@@ -215,6 +243,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             KL_Q8_PAIR(b0, w0[0], 0, false) KL_Q8_PAIR(b0, w0[0], 1, true) KL_Q8_PAIR(b0, w0[1], 2, false) KL_Q8_PAIR(b0, w0[1], 3, true)
             KL_Q8_PAIR(b1, w1[0], 0, false) KL_Q8_PAIR(b1, w1[0], 1, true) KL_Q8_PAIR(b1, w1[1], 2, false) KL_Q8_PAIR(b1, w1[1], 3, true)
 #undef KL_Q8_PAIR
+#endif
         } else {
             // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
             b0 = __builtin_bit_cast(opx8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -225,7 +254,32 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
             fetch(std::integral_constant<int, j + 2>{});
             constexpr int younger = (j + 2 < N3 ? 2 : N3 - 1 - j);      // fragments issued after fragment j
             lds_wait<2 * younger>(ring[j % 3]);
+#ifdef KL_EMU_W8          // precision experiment: the W_new operand rounded to fp8 (e4m3, image / 256, saturating) as an fp8 column pass would see it
+            {
+                typedef __attribute__((ext_vector_type(2))) short s16x2_;
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+                opx8 &fr = ring[j % 3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s16x2_ w8 = {0, 0};
+                    w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, f16x2_{fr[2 * u], fr[2 * u + 1]}, 256.f, false);
+                    const f16x2_ back = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(unsigned, w8), 256.f, false);
+                    fr[2 * u] = back[0]; fr[2 * u + 1] = back[1];
+                }
+            }
+#endif
             acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+#ifdef KL_COLQ_INTERLEAVE
+            static_for<0, OPS>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int pos = (i * N3) / OPS < N3 - 1 ? (i * N3) / OPS : N3 - 1;
+                if constexpr (pos == j) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (o_next >= 0) piece(o_next, sg_next, I);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+#endif
         });
     };
     auto fence = [&]() {          // my copies of the next stage (pair of stages) have landed; then everybody's
@@ -241,6 +295,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q2(ColPassQArgs a) {
         static_for<0, NB / PAIR>([&](auto I) {
             constexpr int i = PAIR * decltype(I)::value;
             if (s0 + i < send) {                                   // uniform
+#ifdef KL_COLQ_INTERLEAVE
+                if constexpr (PAIR == 1) compute(lds_addr(obj(i)), 32 * (s0 + i), (i + NB - 1) % NB, s0 + i + NB - 1);
+                else
+#endif
                 {
                 static_for<0, PAIR>([&](auto U) {
                     constexpr int u = decltype(U)::value;

@@ -13,9 +13,13 @@
 #pragma once
 #include "colq.hip.h"
 
+#ifndef KL_COL8_PF
 #define KL_COL8_PF 1      // accumulator blocks of W8 fragments requested ahead of their product (round 4, C4, one box: 1 / 2 / 3 blocks
                           // ahead = 0.845 / 0.857 / 0.870 ms -- the pass waits for HBM, not for LDS: profiles/r04_ab_colpass_prefetch.txt)
+#endif
+#ifndef KL_COL8_NB
 #define KL_COL8_NB 4      // LDS objects of the fp8 x fp8 column pass (3 and 5 measured: profiles/r02_ab_fp8_fp8_colpass.txt)
+#endif
 
 namespace klnmf {
 
@@ -30,13 +34,13 @@ __host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 
 // sat != nullptr: entries whose scaled value exceeds e4m3's 448 (they are stored as 448) are counted there -- the image's
 // scales come from the PREVIOUS iteration's maxima with one binade of headroom, so a column that more than doubles in one
 // update clips; the column passes act on the count (k_colpass_q8x returns, the f16-operand pass runs instead).
-// tab64: the block maxima are combined by atomicMax into row (blockIdx & 63) of a
-// [64][KP] table -- 16 blocks per address, 64 x KP addresses: no hot line -- which ONE block of
+// tab64 != nullptr (round 4, post.hip.h): the block maxima are combined by atomicMax into row (blockIdx & 63) of a
+// [64][KP] table instead of one row per block -- 16 blocks per address, 64 x KP addresses: no hot line -- which ONE block of
 // the launch behind the column pass turns into the next iteration's scales (w8s = those scales: computed by k_post from the
 // previous conversion's table into the buffer the host swaps in as w8s).
 __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
-                                                    const float *w8s, const DevState *st, int *sat, int probe_col,
-                                                    unsigned *tab64) {
+                                                    const float *w8s, unsigned *w8max, const DevState *st, int *sat = nullptr,
+                                                    int probe_col = -1, unsigned *tab64 = nullptr) {
     const int ld8 = w8_ld(kp);
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -72,12 +76,14 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     s16x2 w = {0, 0};
+#ifndef KL_OPND_BF16
                     const f16x2 p0 = f16x2{v[q][4 * u], v[q][4 * u + 1]} * inv[2 * u], p1 = f16x2{v[q][4 * u + 2], v[q][4 * u + 3]} * inv[2 * u + 1];
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p0, 1.f, false);
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p1, 1.f, true);
                     const f16x2 top = __builtin_elementwise_max(p0, p1);                    // (448 is an f16 number)
                     nsat += (top[0] > (_Float16)448.f || top[1] > (_Float16)448.f) ? ((p0[0] > (_Float16)448.f) + (p0[1] > (_Float16)448.f)
                                                                                      + (p1[0] > (_Float16)448.f) + (p1[1] > (_Float16)448.f)) : 0;
+#endif
                     out[u] = __builtin_bit_cast(unsigned, w);
                 }
                 // the probe column (an unused pad component; k_colpass_q8x): e4m3 1.0 in every row -- its accumulator is the sum of the
@@ -102,9 +108,39 @@ __global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned c
         for (int e = 0; e < 8; ++e) {
             float m = red[e][c8];
             for (int q = 1; q < rows_per_block; ++q) m = fmaxf(m, red[e][q * groups + c8]);
-            atomicMax(tab64 + (int64_t)(blockIdx.x & 63) * kp + comp + e, __float_as_uint(m));
+            if (tab64 != nullptr) atomicMax(tab64 + (int64_t)(blockIdx.x & 63) * kp + comp + e, __float_as_uint(m));
+            else w8max[(int64_t)blockIdx.x * kp + comp + e] = __float_as_uint(m);      // [block][component]: no atomics, reduced by k_w8_scales
         }
     }
+}
+
+// scales of the e4m3 image from the maxima the previous conversion measured: a power of two with image / scale <= 224
+// (e4m3 reaches 448)
+// column maxima of a slice of the [entries][KP] table (one thread per component: coalesced), combined by atomics
+__global__ void k_w8_reduce(const unsigned *w8max, int64_t entries, int per_block, unsigned *final_max, int kp, const DevState *st) {
+    if (st->stop) return;
+    const int c = threadIdx.x;
+    if (c >= kp) return;
+    const int64_t e0 = (int64_t)blockIdx.x * per_block, e1 = min(entries, e0 + per_block);
+    unsigned mb = 0u;
+    for (int64_t e = e0; e < e1; ++e) mb = max(mb, w8max[e * kp + c]);
+    atomicMax(final_max + c, mb);
+}
+__global__ void k_w8_scales(unsigned *final_max, float *w8s, int kp, DevState *st) {
+    if (st->stop) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) st->w8_sat = 0;                       // the conversion that follows counts its own saturated entries
+    if (c >= kp) return;
+    const float m = __uint_as_float(final_max[c]);
+    final_max[c] = 0u;
+    float s = 1.f;
+    if (m > 0.f) {
+        int e;
+        (void)frexpf(m / 224.f, &e);                 // m / 224 = f * 2^e, f in [0.5, 1)  ->  scale 2^e >= m / 224
+        e = e < -14 ? -14 : (e > 15 ? 15 : e);         // its reciprocal and the scaled values stay f16 numbers
+        s = ldexpf(1.f, e);
+    }
+    w8s[c] = s;
 }
 
 typedef __attribute__((ext_vector_type(2))) int i32x2_t;
@@ -122,16 +158,106 @@ struct ColPass8Args {
 
 
 
-// Ratio entries the fp8 tiles cannot hold or hold too coarsely: the column passes report SUSPECTS -- (row chunk, column tile,
-// physical column) whose bytes included one >= 0x60 --, and k_post (post.hip.h) re-reads that column's bytes over the chunk's
-// rows (the tiles are still in memory) and corrects its numerator row exactly for every byte >= 0x60 at (row i, column j):
+// The exact correction for ratio entries the fp8 tiles could not hold or hold too coarsely (after the slab sum, before the H
+// rule).  The column passes report SUSPECTS -- (row chunk, column tile, physical column) whose bytes included one >= 0x60 --;
+// each block takes suspects round robin, re-reads that column's bytes over the chunk's rows (the tiles are still in memory),
+// and for every byte >= 0x60 at (row i, column j):
 //   q = (x + eps) / (sum_a W_old[i][a] H[a][j] + eps)  from the masters,     held = 8 x e4m3(byte)  (what the tile held)
 //   numer[a][j] += W_new image[i][a] * q  -  (what the product added: its W operand x held)            for every component.
-// Suspects beyond the list's capacity are counted (q8_unfixed): the loop then gives fp8 up.
+// (The masters instead of the f16 operand images: the difference is the operands' own rounding of a ratio that is hundreds
+// of times off -- second order.)  Suspects beyond the list's capacity are counted (q8_unfixed): the loop then gives fp8 up.
+struct Q8FixArgs {
+    DevState *st;
+    const uint2 *list;
+    const unsigned char *Qt;   // fp8 ratio tiles [col tile][row tile][32 rows][32 physical columns]
+    const _Float16 *VtA;       // piece-major 32 x 32 tiles (k_tile_V)
+    const float *W32_old;      // [n_pad][KP]
+    const float *H32;          // [KP][f_pad]  (the OLD dictionary: the H rule has not run yet)
+    const opnd_t *Wb_new;      // [rows][wld] swizzled f16 image of W_new
+    float *numer;              // [KP][f_pad]
+    int nrt, nct, kp, k, wld, stages_per_chunk;
+    int64_t f_pad;
+    float eps;
+    // the fp8 x fp8 pass multiplied the e4m3 image of W_new, not the f16 one: what it added for a listed entry is
+    // e4m3(W8[i][a]) x w8s[a] x held -- that is taken out and W image x exact ratio put in (W8 = nullptr: the f16-operand pass ran)
+    const unsigned char *W8;
+    const float *w8s;
+    int w8ld;
+};
 __device__ __forceinline__ float e4m3_value(unsigned b) {
     const int ex = (int)((b >> 3) & 15u), man = (int)(b & 7u);
     return ex == 0 ? ldexpf((float)man, -9) : ldexpf(1.f + 0.125f * (float)man, ex - 7);
 }
+constexpr int kQ8FixBlocks = 64;      // suspects are dealt round robin; usually the list is empty and every block leaves at once
+__global__ __launch_bounds__(512) void k_q8_fixup(Q8FixArgs a) {
+    if (a.st->stop) return;
+    __shared__ float red[8];
+    __shared__ float q_s;
+    __shared__ int hits[64], nhit;
+    const int n_all = a.st->q8_list_n;
+    if (n_all == 0) return;                                   // (uniform over the grid: nobody resets the list while blocks still start)
+    const int n = n_all < kQ8ListCap ? n_all : kQ8ListCap;
+    const int tid = threadIdx.x;
+    const bool used_w8 = a.W8 != nullptr && a.st->w8_sat == 0;       // (a clipped image: the f16-operand pass ran in its place)
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const int chunk = (int)(a.list[e].x & 0xffffu), pcol = (int)(a.list[e].x >> 16), ct = (int)a.list[e].y;
+        const int64_t j = (int64_t)ct * 32 + (8 * ((pcol >> 2) & 3) + 4 * (pcol >> 4) + (pcol & 3));      // the logical column
+        const int row_lo = chunk * a.stages_per_chunk * 64, row_hi = min(a.nrt * 32, row_lo + a.stages_per_chunk * 64);
+        for (int base = row_lo; base < row_hi; base += 64 * 8) {          // 512 rows per sweep, hits handled 64 at a time
+            if (tid == 0) nhit = 0;
+            __syncthreads();
+            const int row = base + tid;
+            if (row < row_hi) {
+                const unsigned byte = a.Qt[((int64_t)ct * a.nrt + (row >> 5)) * 1024 + (row & 31) * 32 + pcol];
+                if (byte >= 0x60u) {
+                    if (byte >= 0x7eu) atomicAdd(&a.st->q8_sat_total, 1);
+                    const int at = atomicAdd(&nhit, 1);
+                    if (at < 64) hits[at] = (row - base) | ((int)byte << 16);
+                    else atomicAdd(&a.st->q8_unfixed, 1);         // (65 large ratios of one column within 512 rows: not a spike)
+                }
+            }
+            __syncthreads();
+            const int nh = min(nhit, 64);
+            for (int t = 0; t < nh; ++t) {
+                const int64_t i = base + (hits[t] & 0xffff);
+                const float held = kQ8Scale * e4m3_value((unsigned)hits[t] >> 16);
+                float part = 0.f;
+                for (int c = tid; c < a.k; c += blockDim.x) part += a.W32_old[i * a.kp + c] * a.H32[(int64_t)c * a.f_pad + j];
+                part = wave_sum(part);
+                if ((tid & 63) == 0) red[tid >> 6] = part;
+                __syncthreads();
+                if (tid == 0) {
+                    float d = 0.f;
+                    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) d += red[w];
+                    const int ii = (int)(i & 31), cc = (int)(j & 31);
+                    const int laneA = ii + 32 * ((cc >> 2) & 1), eA = 4 * (cc >> 3) + (cc & 3);
+                    const float x = (float)a.VtA[((i >> 5) * a.nct + (j >> 5)) * 1024 + (eA >> 3) * 512 + laneA * 8 + (eA & 7)];
+                    const float rinv = 1.f / (d + a.eps);
+                    q_s = fmaf(x, rinv, a.eps * rinv);
+                }
+                __syncthreads();
+                const float q_exact = q_s;
+                for (int c = tid; c < a.k; c += blockDim.x) {      // (several rows may share a column: atomic adds)
+                    const float wimg = (float)a.Wb_new[i * a.wld + wb_col((int)(i & 31), c)];
+                    const float wprod = used_w8 ? e4m3_value(a.W8[i * a.w8ld + c]) * a.w8s[c] : wimg;
+                    atomicAdd(&a.numer[(int64_t)c * a.f_pad + j], wimg * (q_exact * kQ8Mid) - wprod * held);      // (the tiles' units: mfma.hip.h, kQ8Mid)
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // the block that finishes last empties the list for the next iteration's column pass
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&a.st->q8_fix_done, 1) == (int)gridDim.x - 1) {
+            if (n_all > kQ8ListCap) a.st->q8_unfixed += n_all - kQ8ListCap;
+            a.st->q8_fix_done = 0;
+            a.st->q8_list_n = 0;
+        }
+    }
+}
+
 // KSPLIT = 2 (KT > 8, k <= 512): the 8 waves are 4 column tiles x 2 halves of the component range (the accumulators of a
 // half fit two waves per SIMD); the two waves of a column tile read the same two ratio tiles and copy one each.
 // PROBE: the e4m3 W image carries the probe column (aa.probe, compile-time here: the byte test of the other case would
@@ -211,7 +337,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
 #pragma unroll
         for (int pp = 0; pp < QPW; ++pp) {
             const int p = kh * QPW + pp;               // KSPLIT = 2: the two waves of a column tile copy one tile each
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr(obj(o)) + WA + (2 * ctl + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KL_Q_NT_MOD ::"s"(lds_addr(obj(o)) + WA + (2 * ctl + p) * kQTile8), "v"(l16), "s"(qbase + p * kQTile8) : "memory");
         }
     };
     const int rcol_of_r = 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);      // logical column of this lane's physical column
@@ -257,6 +383,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
             // (189 registers) and the read of the probe register then waited a whole product out -- 12 % of the kernel
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifndef KL_NO_Q8_DETECT
         {
             // The probe: component KP - 1 of the e4m3 W image is 1.0 in every row, so register 15 of the last accumulator block in
             // the lanes h = 1 (component 32 (KT - 1) + 31, feature column r) grew by the sum of this stage's 64 ratio bytes of that
@@ -273,6 +400,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_colpass_q8x(ColPass8Args aa) {
                 for (int e = 0; e < 8; ++e) q8_flag |= q8_sat_mask((unsigned)bo[e]);
             }
         }
+#endif
     };
     auto fence = [&]() {
         __builtin_amdgcn_sched_barrier(0);

@@ -22,11 +22,13 @@
 #include "sparse.hip.h"
 #include "mfma.hip.h"
 #include "mfma4.hip.h"
+#if defined(KL_SPLIT_TU) && !defined(KL_DEV_BUILD)
 // the k_rowpass4 instantiations live in rowpass4_inst_{1,2,3}.hip (built in parallel); here they are only declared
 #include "rowpass4_list.hip.h"
 namespace klnmf {
 KL_RP4_LIST_1(KL_RP4_DECLARE) KL_RP4_LIST_2(KL_RP4_DECLARE) KL_RP4_LIST_3(KL_RP4_DECLARE)
 }  // namespace klnmf
+#endif
 #include "colq.hip.h"
 #include "colq8x.hip.h"
 #include "post.hip.h"
@@ -175,50 +177,7 @@ struct DevBlockCache {
 };
 static DevBlockCache g_block_cache;
 
-// Development switches: what only measurements and tests need.  Read in ONE place (here), afresh at every klnmf_set_problem and
-// loop entry, and honoured only under KLNMF_DEV=1 -- a production process cannot change the library's arithmetic by accident.
-// (User-facing environment: KLNMF_QTILE=16 -- never fp8 ratio tiles -- and KLNMF_ALLOC_CACHE_MB, plus the host layer's
-// KLNMF_PRECISION / KLNMF_DEVICE / KLNMF_LIB / KLNMF_NO_POOL: INTEGRATION.md section 1.)
-struct DevSwitches {
-    int qtile = 0;              // KLNMF_QTILE = 8 / 16: fp8 ratio tiles forced on (from a loop's third iteration) / off      [16: also without KLNMF_DEV]
-    int col8 = -1;              // KLNMF_COL8 = 0: no fp8 x fp8 column pass; 1: at any size; 2: the W rule writes the e4m3 image itself
-    int ne = -1;                // KLNMF_NE = 0 / 1: the update pass without the numerator's eps never / in every fp8 loop
-    bool q8_fixup = true;       // KLNMF_Q8_FIXUP=0: no exact correction of large ratio entries (the tests' control run)
-    bool q8_rules_r4 = false;   // KLNMF_Q8_RULES=1: round 4's data rules at the loop's entry as well as the in-loop monitor (A/B runs)
-    bool q8_monitor = true;     // KLNMF_Q8_MONITOR=0: no monitor
-    bool ratio_scale = true;    // KLNMF_RATIO_SCALE=0: no ratio scale of the first update
-    bool eps_pad = true;        // KLNMF_NO_EPS_PAD=1: eps added in the epilogue instead of riding through MFMA-1
-    int row_split = -1;         // KLNMF_ROW_SPLIT = 0 / N: column-split update pass off / N chunks
-    int row_tail = -1;          // KLNMF_ROW_TAIL = 0: no column-split last partial round
-    int comm_parts = 1;         // KLNMF_COMM_PARTS = P: the numerator in P column parts on a communicator (experimental: one-rank runs only)
-    bool comm_overlap = true;   // KLNMF_COMM_OVERLAP=0: the parts' all-reduces on the loop's own stream
-    bool comm_single = false;   // KLNMF_COMM_SINGLE=1: a one-rank communicator takes the collective path (tests)
-    int graph = 0;              // KLNMF_GRAPH=1: two iterations captured into a hipGraph and replayed (measured: no gain)
-    static DevSwitches read() {
-        DevSwitches d;
-        auto num = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
-        if (num("KLNMF_QTILE", 0) == 16) d.qtile = 16;
-        if (num("KLNMF_DEV", 0) == 0) return d;
-        d.qtile = num("KLNMF_QTILE", 0);
-        d.col8 = num("KLNMF_COL8", -1);
-        d.ne = num("KLNMF_NE", -1);
-        d.q8_fixup = num("KLNMF_Q8_FIXUP", 1) != 0;
-        d.q8_rules_r4 = num("KLNMF_Q8_RULES", 0) != 0;
-        d.q8_monitor = num("KLNMF_Q8_MONITOR", 1) != 0;
-        d.ratio_scale = num("KLNMF_RATIO_SCALE", 1) != 0;
-        d.eps_pad = num("KLNMF_NO_EPS_PAD", 0) == 0;
-        d.row_split = num("KLNMF_ROW_SPLIT", -1);
-        d.row_tail = num("KLNMF_ROW_TAIL", -1);
-        d.comm_parts = num("KLNMF_COMM_PARTS", 1);
-        d.comm_overlap = num("KLNMF_COMM_OVERLAP", 1) != 0;
-        d.comm_single = num("KLNMF_COMM_SINGLE", 0) != 0;
-        d.graph = num("KLNMF_GRAPH", 0);
-        return d;
-    }
-};
-
 struct klnmf_ctx {
-    DevSwitches sw;
     int device = 0;
     int prec = KLNMF_PREC_F64;
     hipStream_t stream = nullptr;
@@ -267,17 +226,24 @@ struct klnmf_ctx {
     // tail_ct_chunk column tiles each) so that they fill the chip; tail_wg = 0: none.  Gpart then holds the tail's slabs.
     int tail_wg = 0, tail_chunks = 1, tail_ct_chunk = 0;
     unsigned char *W8 = nullptr;              // e4m3 image of W_new for the fp8 x fp8 column pass (colq8x.hip.h; KLNMF_COL8=0: off)
+    unsigned *w8max = nullptr;                // [KP] column maxima of the f16 W image, measured by the conversion kernel
     float *w8s = nullptr;                     // [KP] power-of-two scales of the e4m3 image
-    bool w8_meas = false;                     // the maxima table holds a measurement of this loop
+    unsigned *w8fin = nullptr;                // [KP] reduced maxima (zero between uses)
+    bool w8_meas = false;                     // w8max holds a measurement of this loop
+    int w8_blocks = 0;                        // blocks of the last conversion launch (rows of w8max)
     bool w8_tail = false;                     // KLNMF_COL8=2: the W rule writes the e4m3 image itself (whole-row launch); the conversion
                                               // kernel then only covers the rows of the column-split last partial round
+    bool w8_use = false;                      // this iteration's image was written with measured scales: the fp8 x fp8 pass may run
+    int64_t w8_entries = 0;                   // rows of w8max that hold this iteration's maxima
     int64_t loss_parts() const {               // entries of loss_part2 an update pass writes
+        if (!pingpong()) return nrt;
         if (tail_wg > 0) return (int64_t)nrt + (int64_t)(tail_chunks - 1) * (nrt - tail_rt0());
         return (int64_t)nrt * row_chunks;
     }
     int tail_rt0() const { return (((nrt + 7) / 8) - tail_wg) * 8; }
-    void *VtA = nullptr;          // V as 32 x 32 fp16 tiles in the row pass's accumulator order (k_tile_V)
-    unsigned char *Qt = nullptr;  // ratio tiles the row pass leaves for the column pass
+    void *VtA = nullptr, *VtB = nullptr;
+    unsigned char *Qt = nullptr;  // ratio tiles the ping-pong row pass leaves for k_colpass_q (col_gen 2); VtB is then not kept
+    int col_gen = 2;
     // fp8 ratio tiles (1 B per element of V instead of the 16-bit operands) for the H rule.  q8_ok: the problem's shape
     // allows them (klnmf_set_problem); q8_loop: this loop's data do (decided at the loop's entry); they are used from the
     // loop's third iteration on (the first updates from W0 = V.H0^T can carry ratios far beyond fp8's range).
@@ -292,14 +258,6 @@ struct klnmf_ctx {
     bool in_capture = false;                  // a hipGraph capture is recording this context's launches (no synchronising polls)
     // the saturation counters of the last loop as its end found them (DevState is reset by the next entry point)
     int64_t stat_w8_sat = 0, stat_w8_fallbacks = 0, stat_q8_sat = 0, stat_q8_unfixed = 0;
-    // ---- the fp8 monitor (monitor.hip.h): partial sums of the monitored iteration; what k_post is to do with them; the last
-    // loop's record (klnmf_query / klnmf_query_f64)
-    float *mon_part = nullptr;
-    bool mon_pending = false;                 // this iteration's first summing launch turns the partial sums into the statistic
-    int mon_ncols = 0; float mon_noise_scale = 0.f;
-    int64_t mon_checks = 0, stat_mon_checks = 0, stat_mon_trips = 0;
-    double stat_mon_max = 0.0;
-    bool stat_mon_gave_up = false;
     // the refusal counters of DevState (v_overflow, op_range) change only on uploads and image measurements: they are read
     // back (one copy + synchronisation) only when one of those happened since the last check
     bool refusals_dirty = true;
@@ -314,7 +272,8 @@ struct klnmf_ctx {
     float *W32[2] = {nullptr, nullptr};
     opnd_t *Wb[2] = {nullptr, nullptr};
     float *H32 = nullptr;
-    // ---- one launch behind the column pass (post.hip.h) ----
+    // ---- one launch behind the column pass (post.hip.h; KLNMF_FUSE=0: the separate launches of rounds 1-3) ----
+    bool fused = false;                       // this problem runs k_post (ping-pong row pass + stored-ratio column pass)
     float *H32alt = nullptr;                  // the dictionary master is ping-pong there: k_post reads H32, writes H32alt, then they swap
     int64_t loop_hswaps = 0;                  // H rules enqueued since the loop's entry (how many the device executed: n_done -- fetch_results)
     float *loop_h0 = nullptr, *loop_h1 = nullptr;      // H32 / H32alt as the loop found them
@@ -333,7 +292,8 @@ struct klnmf_ctx {
     bool piece_split = false, piece_use8 = false;      // loop in pieces: the numerator was produced in parts (klnmf_iter_colpass_part)
     hipStream_t comm_stream = nullptr;        // all-reduces of the parts before the last one (overlap)
     hipEvent_t ev_part[kPostMaxParts] = {}, ev_ar[kPostMaxParts] = {};
-    opnd_t *Ht4 = nullptr;
+    opnd_t *Ht = nullptr, *Ht4 = nullptr, *HTb = nullptr;
+    int row_gen = 4;
     int kc = -1;                 // eps-carrying pad component of the ping-pong path (k_update_pack_H), -1: none
     int kc_shape = -1;           // ... as the shape allows it; kc = kc_shape only while the carrier pair fits fp16 (choose_eps_carrier)
     double *hsum = nullptr;
@@ -342,6 +302,7 @@ struct klnmf_ctx {
     float *tcur = nullptr, *t_hs = nullptr, *t_unit = nullptr;
     unsigned *wmax = nullptr;
     bool images_measured = false;    // the current images carry measured scales: valid for one update (see opnd_t)
+    unsigned long long *stamps = nullptr;   // diagnostic builds only
     float *NpartF = nullptr, *numerF = nullptr;
     double2 *loss_part2 = nullptr;
 
@@ -369,7 +330,9 @@ struct klnmf_ctx {
     // ping-pong row pass (mfma4.hip.h): fp16-stored V; 8-wave workgroups for KT <= 7, 4-wave ones for 10 <= KT <= 16 (even)
     // big: 224 < k <= 512 (KT = 8 .. 16, even): 4-wave workgroups, FUSED order, component-split column passes
     bool big = false;
+    bool pingpong() const { return prec == KLNMF_PREC_BF16 && row_gen == 4 && (KT <= 7 || big); }
     size_t esize() const { return prec == KLNMF_PREC_F64 ? 8 : 4; }
+    size_t vsize() const { return prec == KLNMF_PREC_BF16 ? 2 : 4; }
 
     void *dalloc(size_t bytes, bool zero = true) {
         if (bytes == 0) bytes = 16;
@@ -433,6 +396,33 @@ EventPair begin_event(klnmf_ctx *c, std::vector<EventPair> &v) {
 }
 
 // ---------------------------------------------------------------- dispatch ---
+template <int KT, int ODD, int MODE, typename VT>
+void launch_rowpass_one(klnmf_ctx *c, const RowPassArgs &a, int grid) {
+    // LDS is static (distinct stage objects, see mfma.hip.h / mfma2.hip.h)
+    hipLaunchKernelGGL((k_rowpass<KT, ODD, MODE, VT>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+}
+
+template <int MODE, typename VT>
+void launch_rowpass_kt(klnmf_ctx *c, const RowPassArgs &a, int grid) {
+    const int odd = 2 * c->KT - c->ks;
+#define KL_ROW_CASE(KTV)                                                        \
+    case KTV:                                                                   \
+        if (odd) launch_rowpass_one<KTV, 1, MODE, VT>(c, a, grid);              \
+        else launch_rowpass_one<KTV, 0, MODE, VT>(c, a, grid);                  \
+        break;
+    switch (c->KT) {
+#ifdef KL_DEV_BUILD          // experiment builds (scripts/ab.sh): only the two headline shapes, a quarter of the compile time
+        KL_ROW_CASE(7)
+#else
+        KL_ROW_CASE(1) KL_ROW_CASE(2) KL_ROW_CASE(3) KL_ROW_CASE(4)
+        KL_ROW_CASE(5) KL_ROW_CASE(6) KL_ROW_CASE(7) KL_ROW_CASE(8)
+#endif
+        default: fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels");
+    }
+#undef KL_ROW_CASE
+    HIPCHK(hipGetLastError());
+}
+
 template <int MODE>
 void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int grid_y = 1) {
     const dim3 grid(grid_x, grid_y);
@@ -517,9 +507,13 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
         else hipLaunchKernelGGL((k_rowpass4<KTV, 0, MODE, 0, 4>), grid, dim3(256), 0, c->stream, a);      \
         break;
     switch (c->KT) {
+#ifdef KL_DEV_BUILD
+        KL_ROW4_CASE(7) KL_ROW4_BIG(16)
+#else
         KL_ROW4_CASE(1) KL_ROW4_CASE(2) KL_ROW4_CASE(3) KL_ROW4_CASE(4)
         KL_ROW4_CASE(5) KL_ROW4_CASE(6) KL_ROW4_CASE(7)
         KL_ROW4_BIG(8) KL_ROW4_BIG(10) KL_ROW4_BIG(12) KL_ROW4_BIG(14) KL_ROW4_BIG(16)
+#endif
         default: fail(KLNMF_ERR_UNSUPP, "ping-pong row pass: 224 < k <= 256 runs on the generation-1 kernel");
     }
 #undef KL_ROW4_BIG
@@ -527,14 +521,50 @@ void launch_rowpass4_kt(klnmf_ctx *c, const RowPass4Args &a, int grid_x, int gri
     HIPCHK(hipGetLastError());
 }
 
+template <int KT, int ODD, typename VT>
+void launch_colpass_one(klnmf_ctx *c, const ColPassArgs &a, int grid) {
+    if (c->kc >= 0) hipLaunchKernelGGL((k_colpass<KT, ODD, VT, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_colpass<KT, ODD, VT, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+}
+
+template <typename VT>
+void launch_colpass_kt(klnmf_ctx *c, const ColPassArgs &a, int grid) {
+    const int odd = 2 * c->KT - c->ks;
+#define KL_COL_CASE(KTV)                                                        \
+    case KTV:                                                                   \
+        if (odd) launch_colpass_one<KTV, 1, VT>(c, a, grid);                    \
+        else launch_colpass_one<KTV, 0, VT>(c, a, grid);                        \
+        break;
+    switch (c->KT) {
+#ifdef KL_DEV_BUILD
+        KL_COL_CASE(7)
+#else
+        KL_COL_CASE(1) KL_COL_CASE(2) KL_COL_CASE(3) KL_COL_CASE(4)
+        KL_COL_CASE(5) KL_COL_CASE(6) KL_COL_CASE(7) KL_COL_CASE(8)
+#endif
+        default: fail(KLNMF_ERR_UNSUPP, "k > 256 is not supported by the bf16 MFMA kernels");
+    }
+#undef KL_COL_CASE
+    HIPCHK(hipGetLastError());
+}
+
 // the probe column of the e4m3 W image (colq8x.hip.h): the last padded component, if neither a real component nor the eps
 // carrier lives there
 int w8_probe_col(const klnmf_ctx *c) { return (c->KP - 1 >= c->k && c->KP - 1 != c->kc) ? c->KP - 1 : -1; }
+
+void w8_make_scales(klnmf_ctx *c, int64_t entries) {
+    const int per_block = entries > 4096 ? 64 : 8;      // (128 rows per block left 8 blocks walking 1024 rows one by one: 58 us)
+    hipLaunchKernelGGL(k_w8_reduce, dim3((unsigned)((entries + per_block - 1) / per_block)), dim3(512), 0, c->stream,
+                       (const unsigned *)c->w8max, entries, per_block, c->w8fin, c->KP, (const DevState *)c->st);
+    hipLaunchKernelGGL(k_w8_scales, dim3(2), dim3(256), 0, c->stream, c->w8fin, c->w8s, c->KP, c->st);
+    HIPCHK(hipGetLastError());
+}
 
 void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     RowPassArgs a{};
     a.VtA = c->VtA;
     a.Qt = (store_q && mode == ROW_UPDATE) ? c->Qt : nullptr;
+    a.Ht = c->Ht;
     a.Wb_old = c->Wb[c->cur];
     a.W32_old = c->W32[c->cur];
     a.Wb_new = c->Wb[c->cur ^ 1];
@@ -544,84 +574,262 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.tcur = c->tcur;
     // the new W image goes with the NEXT dictionary image: row-normalised after an H rule (fit), else the hs-based one
     a.tnext = mode == ROW_UPDATE ? (store_q ? c->t_unit : c->t_hs) : c->tcur;
+    a.stamps = c->stamps;
     a.kc = c->kc;
     a.st = c->st;
     a.nrt = c->nrt;
     a.nct = c->nct;
+    a.nst = c->nst;
     a.eps = (float)(kEpsRatio * c->v_scale);
     a.cq_on = c->images_measured ? 1 : 0;
-    // e4m3 image of W_new written by the W rule itself (KLNMF_COL8=2, whole-row launches): the maxima go to the 64-row table
-    // k_post turns into the next scales, and the image is written from the loop's second iteration on, so that the third can
-    // already multiply it
-    const bool w8_here = c->w8_tail && c->W8 && store_q && mode == ROW_UPDATE && c->row_chunks == 1 && c->q8_loop && c->iter_in_loop >= 1;
-    if (c->w8_tail && mode == ROW_UPDATE) { c->conv_ran = false; c->tail_use8 = false; }
+    // fp8 x fp8 column pass with the image written by the W rule (KLNMF_COL8=2): this iteration's scales from the previous
+    // iteration's maxima first, then the row pass writes image and maxima
+    // (on the fused tail -- post.hip.h -- the maxima go to the 64-row table k_post turns into the next scales, and the image is
+    // written from the loop's second iteration on, so that the third can already multiply it)
+    const bool w8_here = c->w8_tail && c->W8 && store_q && mode == ROW_UPDATE && c->pingpong() && c->row_chunks == 1 &&
+                         (c->fused ? (c->q8_loop && c->iter_in_loop >= 1) : c->q8());
+    if (c->fused && c->w8_tail && mode == ROW_UPDATE) { c->conv_ran = false; c->tail_use8 = false; }
     if (w8_here) {
-        c->tail_use8 = c->w8_meas && c->q8();
-        a.w8tab = c->w8tab;
+        if (c->fused) {
+            c->tail_use8 = c->w8_meas && c->q8();
+            a.w8tab = c->w8tab;
+        } else {
+            c->w8_use = c->w8_meas;
+            if (c->w8_meas) {
+                w8_make_scales(c, c->w8_entries);
+            }
+            a.w8max = c->w8max;
+        }
         a.W8 = c->W8;
         a.w8s = c->w8s;
         a.w8_sat = &c->st->w8_sat;
         a.w8_probe = w8_probe_col(c);
     }
-    if (mode == ROW_UPDATE && a.Qt && c->q8()) c->stat_q8_tiles += 1;      // this update leaves fp8 ratio tiles
+    const int grid = (c->nrt + kWavesPerWG - 1) / kWavesPerWG;
+    if (mode == ROW_UPDATE && a.Qt && c->pingpong() && c->q8()) c->stat_q8_tiles += 1;      // this update leaves fp8 ratio tiles
     EventPair ev{};
     if (c->profiling) ev = begin_event(c, c->ev_row);
-    RowPass4Args a4{a, c->Ht4};
-    const int nw = c->big ? 4 : kWaves4;
-    const int grid4 = (c->nrt + nw - 1) / nw;
-    if (mode == ROW_UPDATE && c->row_chunks > 1) {     // few rows: column chunks in blockIdx.y, W rule from the slabs
-        a4.base.gpart = c->Gpart;
-        a4.base.ct_chunk = c->row_ct_chunk;
-        launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4, c->row_chunks);
-        const int64_t rows = (int64_t)c->nrt * 32;
-        hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
-                           (const float *)c->Gpart, c->row_chunks, rows * c->KP, (const float *)c->W32[c->cur],
-                           c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
-                           (const DevState *)c->st, a.tcur, a.tnext);
-        HIPCHK(hipGetLastError());
+    const bool v16 = c->prec == KLNMF_PREC_BF16;
+    if (c->pingpong()) {                               // ping-pong schedule (mfma4.hip.h), fp16 V only
+        RowPass4Args a4{a, c->Ht4};
+        int nw = c->big ? 4 : kWaves4;
+        // KLNMF_ROW_RPW=N (experiment): N < 8 row tiles per 8-wave workgroup, its last waves idling, so that one round of
+        // workgroups covers more CUs (C2: 196 -> 224 workgroups of 7).  Measured round 4: no gain (row pass 0.135 vs 0.133 ms;
+        // 6 tiles -- two rounds -- 0.185): such a pass is bound by the HBM stream as a whole (4.9 TB/s), not by the number of
+        // CUs that pull on it.  Off unless asked for.
+        if (const char *g = std::getenv("KLNMF_ROW_RPW")) {
+            const int w = std::min(nw, std::max(0, std::atoi(g)));
+            if (w > 0 && !c->big && c->row_chunks == 1 && c->tail_wg == 0) { a4.base.rpw = w; nw = w; }
+        }
+        const int grid4 = (c->nrt + nw - 1) / nw;
+        if (mode == ROW_UPDATE && c->row_chunks > 1) {     // few rows: column chunks in blockIdx.y, W rule from the slabs
+            a4.base.gpart = c->Gpart;
+            a4.base.ct_chunk = c->row_ct_chunk;
+            launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4, c->row_chunks);
+            const int64_t rows = (int64_t)c->nrt * 32;
+            hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
+                               (const float *)c->Gpart, c->row_chunks, rows * c->KP, (const float *)c->W32[c->cur],
+                               c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
+                               (const DevState *)c->st, a.tcur, a.tnext);
+            HIPCHK(hipGetLastError());
+            if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+            return;
+        }
+        if (mode == ROW_UPDATE && c->tail_wg > 0) {
+            // hybrid: the full rounds of workgroups take whole rows; the last partial round (tail_wg < CUs workgroups
+            // that would each run a whole row block's length on an otherwise idle chip) is split into column chunks
+            // and its W rule applied from the slabs
+            launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4 - c->tail_wg);
+            EventPair evt{};
+            if (c->profiling) evt = begin_event(c, c->ev_tail);
+            RowPass4Args t4 = a4;
+            t4.base.wg0 = grid4 - c->tail_wg;
+            t4.base.rt0 = c->tail_rt0();
+            t4.base.gpart = c->Gpart;
+            t4.base.ct_chunk = c->tail_ct_chunk;
+            launch_rowpass4_kt<ROW_UPDATE>(c, t4, c->tail_wg, c->tail_chunks);
+            const int64_t row0 = (int64_t)t4.base.rt0 * 32, rows = (int64_t)(c->nrt - t4.base.rt0) * 32;
+            hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
+                               (const float *)c->Gpart, c->tail_chunks, rows * c->KP,
+                               (const float *)c->W32[c->cur] + row0 * c->KP, c->W32[c->cur ^ 1] + row0 * c->KP,
+                               c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), c->kc,
+                               (const DevState *)c->st, a.tcur, a.tnext);
+            HIPCHK(hipGetLastError());
+            if (w8_here) {         // the rows of the split tail: image and maxima by the conversion kernel (a few thousand rows)
+                const int groups = c->KP / 8, rpb = 256 / groups;
+                const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
+                hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
+                                   c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
+                                   c->fused ? (unsigned *)nullptr : c->w8max + (size_t)t4.base.rt0 * c->KP, (const DevState *)c->st,
+                                   &c->st->w8_sat, w8_probe_col(c), c->fused ? c->w8tab : (unsigned *)nullptr);
+                HIPCHK(hipGetLastError());
+                c->w8_entries = t4.base.rt0 + blocks;
+                c->w8_meas = true;
+                if (c->fused) c->conv_ran = true;
+            }
+            if (c->profiling) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
+            return;
+        }
+        if (w8_here) { c->w8_entries = c->nrt; c->w8_meas = true; if (c->fused) c->conv_ran = true; }
+        switch (mode) {
+            case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
+            case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
+            default: launch_rowpass4_kt<ROW_LOSS>(c, a4, grid4); break;
+        }
         if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
         return;
     }
-    if (mode == ROW_UPDATE && c->tail_wg > 0) {
-        // hybrid: the full rounds of workgroups take whole rows; the last partial round (tail_wg < CUs workgroups
-        // that would each run a whole row block's length on an otherwise idle chip) is split into column chunks
-        // and its W rule applied from the slabs
-        launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4 - c->tail_wg);
-        EventPair evt{};
-        if (c->profiling) evt = begin_event(c, c->ev_tail);
-        RowPass4Args t4 = a4;
-        t4.base.wg0 = grid4 - c->tail_wg;
-        t4.base.rt0 = c->tail_rt0();
-        t4.base.gpart = c->Gpart;
-        t4.base.ct_chunk = c->tail_ct_chunk;
-        launch_rowpass4_kt<ROW_UPDATE>(c, t4, c->tail_wg, c->tail_chunks);
-        const int64_t row0 = (int64_t)t4.base.rt0 * 32, rows = (int64_t)(c->nrt - t4.base.rt0) * 32;
-        hipLaunchKernelGGL(k_wrule_slabs, dim3(grid_for(rows * (c->KP / 4))), dim3(256), 0, c->stream,
-                           (const float *)c->Gpart, c->tail_chunks, rows * c->KP,
-                           (const float *)c->W32[c->cur] + row0 * c->KP, c->W32[c->cur ^ 1] + row0 * c->KP,
-                           c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), c->kc,
-                           (const DevState *)c->st, a.tcur, a.tnext);
-        HIPCHK(hipGetLastError());
-        if (w8_here) {         // the rows of the split tail: image and maxima by the conversion kernel (a few thousand rows)
-            const int groups = c->KP / 8, rpb = 256 / groups;
-            const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
-            hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
-                               c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
-                               (const DevState *)c->st, &c->st->w8_sat, w8_probe_col(c), c->w8tab);
-            HIPCHK(hipGetLastError());
-            c->w8_meas = true;
-            c->conv_ran = true;
-        }
-        if (c->profiling) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
-        return;
-    }
-    if (w8_here) { c->w8_meas = true; c->conv_ran = true; }
     switch (mode) {
-        case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
-        case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
-        default: launch_rowpass4_kt<ROW_LOSS>(c, a4, grid4); break;
+        case ROW_UPDATE:
+            v16 ? launch_rowpass_kt<ROW_UPDATE, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_UPDATE, float>(c, a, grid);
+            break;
+        case ROW_INIT:
+            v16 ? launch_rowpass_kt<ROW_INIT, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_INIT, float>(c, a, grid);
+            break;
+        default:
+            v16 ? launch_rowpass_kt<ROW_LOSS, _Float16>(c, a, grid) : launch_rowpass_kt<ROW_LOSS, float>(c, a, grid);
+            break;
     }
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+}
+
+void launch_sum_partials(klnmf_ctx *c, int64_t count) {
+    const LossArgs la = c->pending_loss;
+    c->pending_loss.part = nullptr;
+    hipLaunchKernelGGL(k_sum_partials_f32, dim3(grid_for(count / 4) + (la.part ? 1 : 0)), dim3(256), 0, c->stream,
+                       (const float *)c->NpartF, c->numerF, count / 4, c->nchunks, (const DevState *)c->st, la);
+    HIPCHK(hipGetLastError());
+}
+
+void fast_colpass_q(klnmf_ctx *c, bool sum_slabs = true) {
+    ColPassQArgs a{};
+    a.Qt = c->Qt;
+    a.Wb_new = c->Wb[c->cur ^ 1];
+    a.Npart = c->NpartF;
+    a.st = c->st;
+    a.nrt = c->nrt;
+    a.nct = c->nct_used;
+    a.ncb = c->ncb;
+    a.nchunks = c->nchunks;
+    a.stages_per_chunk = c->stages_per_chunk;
+    a.f_pad = c->f_pad;
+    a.guard = 0;
+    a.st_rw = c->st;
+    a.q8_list = c->q8() ? c->q8_list : nullptr;       // fp8 tiles: the column pass lists saturated ratio bytes for k_q8_fixup
+    const int grid = c->ncb * c->nchunks;
+    EventPair ev{};
+    bool col8_ran = false;             // this iteration's product was launched on the e4m3 W image
+    auto q8_fixup = [&]() {            // behind the slab sum, before the H rule: the excess of ratios beyond the tiles' 3584
+        if (!a.q8_list) return;
+        const bool off = std::getenv("KLNMF_Q8_FIXUP") && std::atoi(std::getenv("KLNMF_Q8_FIXUP")) == 0;      // (tests: the control run)
+        if (off) { HIPCHK(hipMemsetAsync(&c->st->q8_list_n, 0, sizeof(int), c->stream)); return; }
+        Q8FixArgs fa{c->st, c->q8_list, c->Qt, (const _Float16 *)c->VtA, (const float *)c->W32[c->cur], (const float *)c->H32,
+                     (const opnd_t *)c->Wb[c->cur ^ 1], c->numerF, c->nrt, c->nct, c->KP, (int)c->k, (int)w_ld(c->KP),
+                     c->stages_per_chunk, c->f_pad, (float)(kEpsRatio * c->v_scale), col8_ran ? c->W8 : nullptr, c->w8s,
+                     (int)w8_ld(c->KP)};
+        hipLaunchKernelGGL(k_q8_fixup, dim3(kQ8FixBlocks), dim3(512), 0, c->stream, fa);
+        HIPCHK(hipGetLastError());
+    };
+    // the f16-operand pass on fp8 tiles (guard 2: only if this iteration's e4m3 W image clipped; 0: the regular pass of k <= 96)
+    auto launch_q2_on_fp8 = [&](int guard) {
+        ColPassQArgs g = a;
+        g.guard = guard;
+        switch (c->KT) {
+#define KL_Q2F8(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ8_NB, 1, 1, KL_COLQ8_PAIR>), dim3(grid), dim3(kThreads), 0, c->stream, g); break;
+#define KL_Q2F8_BIG(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, g); break;
+#ifdef KL_DEV_BUILD
+            KL_Q2F8(7) KL_Q2F8_BIG(16)
+#else
+            KL_Q2F8(1) KL_Q2F8(2) KL_Q2F8(3) KL_Q2F8(4) KL_Q2F8(5) KL_Q2F8(6) KL_Q2F8(7)
+            KL_Q2F8_BIG(8) KL_Q2F8_BIG(10) KL_Q2F8_BIG(12) KL_Q2F8_BIG(14) KL_Q2F8_BIG(16)
+#endif
+#undef KL_Q2F8
+#undef KL_Q2F8_BIG
+            default: fail(KLNMF_ERR_UNSUPP, "column pass on fp8 ratio tiles: k <= 224 or 256 < k <= 512");
+        }
+        HIPCHK(hipGetLastError());
+    };
+    auto w8_convert = [&]() {          // e4m3 image of W_new with the current scales + this image's column maxima
+        const int groups = c->KP / 8, rpb = std::max(1, 256 / groups);
+        const int64_t rows = c->n_pad;
+        const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
+        c->w8_blocks = blocks;
+        hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
+                           c->KP, (int)w_ld(c->KP), (const float *)c->w8s, c->w8max, (const DevState *)c->st, &c->st->w8_sat,
+                           w8_probe_col(c));
+        HIPCHK(hipGetLastError());
+    };
+    if (c->W8 && c->q8_loop && !c->w8_tail && c->iter_in_loop == 1 && !c->w8_meas) {
+        // the loop's second iteration (16-bit tiles still): measure the W image's column maxima for the third one's scales
+        w8_convert();
+        c->w8_meas = true;
+    } else if (c->W8 && c->q8()) {
+        // fp8 x fp8 column pass (colq8x.hip.h).  The e4m3 image of W_new is converted behind the row pass with the scales
+        // the PREVIOUS conversion's column maxima give; without a measurement (k <= 224 only) this iteration measures and
+        // runs the f16-operand form.
+        const bool use8 = c->w8_tail ? c->w8_use : c->w8_meas;
+        if (c->w8_tail) {
+            // (image, maxima and scales were handled around the row pass)
+        } else if (use8) {
+            w8_make_scales(c, c->w8_blocks);
+        }           // (else: w8s holds 256 from klnmf_set_problem or the last loop's scales; this image is not used)
+        if (!c->w8_tail) w8_convert();
+        if (!c->w8_tail) c->w8_meas = true;
+        if (use8) {
+        c->stat_col8 += 1;
+        col8_ran = true;
+        if (c->profiling) ev = begin_event(c, c->ev_col);
+        a.guard = 1;                       // (the image's clipped entries are counted by whoever wrote it: conversion kernel or W rule)
+        ColPass8Args a8{a, c->W8, c->w8s, w8_probe_col(c) >= 0 ? 1 : 0};
+#define KL_Q8X(KTV, NBV, KSV) case KTV:                                                                                              \
+            if (a8.probe) hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a8);        \
+            else hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a8);                 \
+            break;
+        if (c->KT == 8 && !c->big) fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: KT = 8 only on the component-split path");
+        switch (c->KT) {
+#ifdef KL_DEV_BUILD
+            KL_Q8X(7, KL_COL8_NB, 1) KL_Q8X(16, 3, 2)
+#else
+            KL_Q8X(1, KL_COL8_NB, 1) KL_Q8X(2, KL_COL8_NB, 1) KL_Q8X(3, KL_COL8_NB, 1) KL_Q8X(4, KL_COL8_NB, 1)
+            KL_Q8X(5, KL_COL8_NB, 1) KL_Q8X(6, KL_COL8_NB, 1) KL_Q8X(7, KL_COL8_NB, 1)
+            KL_Q8X(8, 3, 2) KL_Q8X(10, 3, 2) KL_Q8X(12, 3, 2) KL_Q8X(14, 3, 2) KL_Q8X(16, 3, 2)
+#endif
+#undef KL_Q8X
+            default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: k <= 224 or 256 < k <= 512");
+        }
+        HIPCHK(hipGetLastError());
+        if (a.guard == 1) launch_q2_on_fp8(2);      // runs only if the conversion counted saturated entries (then the pass above returned)
+        if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+        if (!sum_slabs) return;
+        launch_sum_partials(c, (int64_t)c->KP * c->f_pad);
+        q8_fixup();
+        return;
+        }
+    }
+    if (c->profiling) ev = begin_event(c, c->ev_col);
+#define KL_COLQ_CASE(KTV)                                                                                          \
+    case KTV:                                                                                                      \
+        if (c->q8()) hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ8_NB, 1, 1, KL_COLQ8_PAIR>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        else if (c->col_gen == 3) hipLaunchKernelGGL((k_colpass_q<KTV>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+        else hipLaunchKernelGGL((k_colpass_q2<KTV, KL_COLQ_NB>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
+        break;
+    switch (c->KT) {
+#define KL_COLQ_BIG(KTV) case KTV: hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, a); break;
+#ifdef KL_DEV_BUILD
+        KL_COLQ_CASE(7) KL_COLQ_BIG(16)
+#else
+        KL_COLQ_CASE(1) KL_COLQ_CASE(2) KL_COLQ_CASE(3) KL_COLQ_CASE(4) KL_COLQ_CASE(5) KL_COLQ_CASE(6) KL_COLQ_CASE(7)
+        KL_COLQ_BIG(8) KL_COLQ_BIG(10) KL_COLQ_BIG(12) KL_COLQ_BIG(14) KL_COLQ_BIG(16)
+#endif
+#undef KL_COLQ_BIG
+        default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: 224 < k <= 256 runs on the recomputing kernel");
+    }
+#undef KL_COLQ_CASE
+    HIPCHK(hipGetLastError());
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (!sum_slabs) return;          // the H rule sums them itself (fast_pack_H from_slabs)
+    launch_sum_partials(c, (int64_t)c->KP * c->f_pad);
+    q8_fixup();
 }
 
 // ---- the fused iteration tail (post.hip.h): column pass of one column part, then k_post -----------------------------------
@@ -643,42 +851,6 @@ ColPassQArgs colq_part_args(klnmf_ctx *c, const klnmf_ctx::PartCfg &p) {
     return a;
 }
 
-// ---- the fp8 monitor (monitor.hip.h) -------------------------------------------------------------------------------------------
-void monitor_setup(klnmf_ctx *c) {
-    c->mon_part = nullptr;
-    c->mon_pending = false;
-    if (!c->q8_ok) return;
-    c->mon_part = (float *)c->dalloc((size_t)kMonBlocks * 2 * 2 * c->KP * 32 * 4);
-}
-// fp8 iterations 1 .. 4 of a loop and every eighth after them (the defects it looks for are properties of the data and of the
-// fit's state, which moves slowly); the poll that acts on it keeps the same cadence (poll_fp8_overflow)
-bool monitor_due(int64_t n8) { return n8 >= 1 && (n8 <= 4 || (n8 & 7) == 0); }
-// behind the row pass (and the conversion of the e4m3 W image) of a fit iteration on fp8 tiles, before its column pass
-void launch_monitor(klnmf_ctx *c, bool use8) {
-    c->mon_pending = false;
-    if (!c->mon_part || !c->sw.q8_monitor || !c->q8() || c->in_capture) return;
-    if (!monitor_due(c->stat_q8_tiles)) return;
-    MonArgs a{};
-    a.st = c->st; a.Qt = c->Qt; a.VtA = (const _Float16 *)c->VtA; a.W32_old = c->W32[c->cur]; a.H_old = c->H32;
-    a.Wb_new = c->Wb[c->cur ^ 1]; a.W8 = use8 ? c->W8 : nullptr; a.w8s = c->w8s; a.part = c->mon_part;
-    a.nrt = c->nrt; a.nct = c->nct; a.kp = c->KP; a.k = (int)c->k; a.wld = (int)w_ld(c->KP); a.w8ld = (int)w8_ld(c->KP);
-    a.f_pad = c->f_pad;
-    const int tiles = (int)((c->f + 31) / 32);                       // column tiles that hold data
-    a.ct = (int)((c->mon_checks * 5 + 1) % tiles);                   // rotates with the checks (5: coprime to the usual tile counts)
-    a.ncols = (int)std::min<int64_t>(32, c->f - (int64_t)a.ct * 32);
-    a.nrt_data = (int)((c->n + 31) / 32);                            // row tiles that hold data: the sample walks (and wraps inside) them
-    a.nsamp = std::min(2 * kMonBlocks, a.nrt_data) & ~1;
-    if (a.nsamp < 2) return;
-    a.rot = (int)((c->mon_checks * 7) % a.nrt_data);
-    a.eps = (float)(kEpsRatio * c->v_scale);
-    hipLaunchKernelGGL(k_q8_monitor, dim3(kMonBlocks), dim3(256), 0, c->stream, a);
-    HIPCHK(hipGetLastError());
-    c->mon_pending = true;
-    c->mon_ncols = a.ncols;
-    c->mon_noise_scale = (float)std::min(0.5, (double)(a.nsamp / 2) * 32.0 / (double)c->n);
-    c->mon_checks += 1;
-}
-
 // the e4m3 image of W_new for this iteration's fp8 x fp8 column pass (once per iteration, before the first part's pass):
 // converted with the scales k_post derived from the PREVIOUS conversion's maxima; returns whether the fp8 x fp8 pass may run
 bool fused_w8_stage(klnmf_ctx *c) {
@@ -692,7 +864,7 @@ bool fused_w8_stage(klnmf_ctx *c) {
     const int64_t rows = c->n_pad;
     const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
     hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
-                       c->KP, (int)w_ld(c->KP), (const float *)c->w8s, (const DevState *)c->st,
+                       c->KP, (int)w_ld(c->KP), (const float *)c->w8s, (unsigned *)nullptr, (const DevState *)c->st,
                        &c->st->w8_sat, w8_probe_col(c), c->w8tab);
     HIPCHK(hipGetLastError());
     c->w8_meas = true;
@@ -715,8 +887,12 @@ void fused_colpass_part(klnmf_ctx *c, const klnmf_ctx::PartCfg &p, bool use8) {
             if (fp8_tiles) hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2, 1, 1>), dim3(grid), dim3(kThreads), 0, c->stream, g);      \
             else hipLaunchKernelGGL((k_colpass_q2<KTV, 3, 2>), dim3(grid), dim3(kThreads), 0, c->stream, g);                      \
             break;
+#ifdef KL_DEV_BUILD
+            KL_PQ2(7) KL_PQ2_BIG(16)
+#else
             KL_PQ2(1) KL_PQ2(2) KL_PQ2(3) KL_PQ2(4) KL_PQ2(5) KL_PQ2(6) KL_PQ2(7)
             KL_PQ2_BIG(8) KL_PQ2_BIG(10) KL_PQ2_BIG(12) KL_PQ2_BIG(14) KL_PQ2_BIG(16)
+#endif
 #undef KL_PQ2
 #undef KL_PQ2_BIG
             default: fail(KLNMF_ERR_UNSUPP, "stored-ratio column pass: k <= 224 or 256 < k <= 512");
@@ -732,9 +908,13 @@ void fused_colpass_part(klnmf_ctx *c, const klnmf_ctx::PartCfg &p, bool use8) {
             if (a8.probe) hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 1>), dim3(grid), dim3(kThreads), 0, c->stream, a8);     \
             else hipLaunchKernelGGL((k_colpass_q8x<KTV, NBV, KSV, 0>), dim3(grid), dim3(kThreads), 0, c->stream, a8);              \
             break;
+#ifdef KL_DEV_BUILD
+            KL_PQ8X(7, KL_COL8_NB, 1) KL_PQ8X(16, 3, 2)
+#else
             KL_PQ8X(1, KL_COL8_NB, 1) KL_PQ8X(2, KL_COL8_NB, 1) KL_PQ8X(3, KL_COL8_NB, 1) KL_PQ8X(4, KL_COL8_NB, 1)
             KL_PQ8X(5, KL_COL8_NB, 1) KL_PQ8X(6, KL_COL8_NB, 1) KL_PQ8X(7, KL_COL8_NB, 1)
             KL_PQ8X(8, 3, 2) KL_PQ8X(10, 3, 2) KL_PQ8X(12, 3, 2) KL_PQ8X(14, 3, 2) KL_PQ8X(16, 3, 2)
+#endif
 #undef KL_PQ8X
             default: fail(KLNMF_ERR_UNSUPP, "fp8 x fp8 column pass: k <= 224 or 256 < k <= 512");
         }
@@ -769,11 +949,9 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     a.w8_block = (a.do_sum && last_sum && c->conv_ran && c->w8tab != nullptr) ? 1 : 0;
     a.last_sum = (a.do_sum && last_sum) ? 1 : 0;
     a.it = (int)(c->iter_in_loop & 1);
-    a.mon = MonPost{nullptr, 0, 0.f, kMonThreshold};
-    if (a.do_sum && c->mon_pending) {
-        a.mon = MonPost{c->mon_part, c->mon_ncols, c->mon_noise_scale, kMonThreshold};
-        c->mon_pending = false;
-    }
+    static const int post_abl = std::getenv("KLNMF_POST_ABL") ? std::atoi(std::getenv("KLNMF_POST_ABL")) : 0;      // (timing experiments only)
+    a.abl = post_abl;
+    if (post_abl & 8) { a.do_decide = 0; a.loss_from_parts = 0; }
     a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne; a.cq_on = la.cq_on;
     a.tol_abs = la.tol_abs; a.errors = c->errors; a.cap = c->cap;
     a.st = c->st;
@@ -781,7 +959,8 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     a.Ht4 = c->Ht4; a.hsum = c->hsum; a.tcur = c->tcur; a.t_hs = c->t_hs;
     a.f = c->f; a.f_pad = c->f_pad; a.kp = c->KP; a.k = (int)c->k; a.kc = c->kc;
     a.eps_pad = (float)(kEpsRatio * c->v_scale);
-    const bool fix = a.do_sum && c->q8() && c->q8_list != nullptr && c->sw.q8_fixup;      // (KLNMF_Q8_FIXUP=0: the tests' control run)
+    const bool fix = a.do_sum && c->q8() && c->q8_list != nullptr &&
+                     !(std::getenv("KLNMF_Q8_FIXUP") && std::atoi(std::getenv("KLNMF_Q8_FIXUP")) == 0);      // (tests: the control run)
     a.list = fix ? c->q8_list : nullptr;
     a.Qt = c->Qt; a.VtA = (const _Float16 *)c->VtA; a.W32_old = c->W32[c->cur]; a.Wb_new = c->Wb[c->cur ^ 1];
     a.W8 = use8 ? c->W8 : nullptr; a.w8s = c->w8s; a.w8ld = (int)w8_ld(c->KP); a.wld = (int)w_ld(c->KP);
@@ -790,7 +969,8 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     if (a.do_sum && !fix && c->q8() && c->q8_list != nullptr)      // fix-ups switched off: the list must still be emptied
         HIPCHK(hipMemsetAsync(&c->st->q8_list_n, 0, sizeof(int), c->stream));
     // one block per component row, one float4 per thread and trip: 1024 threads for rows of 4096 columns and more
-    const int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
+    int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
+    if (const char *g = std::getenv("KLNMF_HRULE_THREADS")) hthreads = std::min(1024, std::max(64, (std::atoi(g) / 64) * 64));
     const int blocks = (int)c->k + a.w8_block + a.loss_block;
     hipLaunchKernelGGL(k_post, dim3((unsigned)blocks), dim3(hthreads), 0, c->stream, a);
     HIPCHK(hipGetLastError());
@@ -805,14 +985,45 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     }
 }
 
-void fast_pack_H(klnmf_ctx *c, const unsigned *wmax = nullptr) {
-    // the dictionary's fp16 tile images, row sums and image scales from its fp32 master (no update: the H rule of a loop runs in
-    // k_post).  One block per component row; its passes over the row are a chain of memory round trips, so a long row gets more
-    // threads (fewer elements per thread and pass)
-    const int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
-    hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(hthreads), 0, c->stream, c->H32, (const float *)c->numerF,
-                       c->Ht4, c->hsum, c->tcur, c->t_hs, wmax, &c->st->op_range, c->f, c->f_pad, c->KP, 0,
-                       (const DevState *)nullptr, c->kc, (float)(kEpsRatio * c->v_scale), 0, (int64_t)c->KP * c->f_pad,
+void fast_colpass(klnmf_ctx *c) {
+    if (c->Qt) { fast_colpass_q(c); return; }
+    ColPassArgs a{};
+    a.VtB = c->VtB;
+    a.HTb = c->HTb;
+    a.Wb_old = c->Wb[c->cur];
+    a.Wb_new = c->Wb[c->cur ^ 1];
+    a.Npart = c->NpartF;
+    a.st = c->st;
+    a.nrt = c->nrt;
+    a.nct = c->nct_used;
+    a.ncb = c->ncb;
+    a.nchunks = c->nchunks;
+    a.stages_per_chunk = c->stages_per_chunk;
+    a.f_pad = c->f_pad;
+    a.eps = (float)(kEpsRatio * c->v_scale);
+    a.cq_on = c->images_measured ? 1 : 0;      // (the recomputed ratio must be the row pass's: same images, same denominator eps)
+    const int grid = c->ncb * c->nchunks;
+    EventPair ev{};
+    if (c->profiling) ev = begin_event(c, c->ev_col);
+    if (c->prec == KLNMF_PREC_BF16) launch_colpass_kt<_Float16>(c, a, grid);
+    else launch_colpass_kt<float>(c, a, grid);
+    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    launch_sum_partials(c, (int64_t)c->KP * c->f_pad);
+}
+
+void fast_pack_H(klnmf_ctx *c, int do_update, bool from_slabs = false, const unsigned *wmax = nullptr) {
+    // ping-pong row pass + stored-ratio column pass read only the Ht4 tile images (KLNMF_ROWPASS / KLNMF_COLPASS are read
+    // once, in klnmf_set_problem, so the choice cannot change under a context)
+    const bool lean = c->pingpong() && c->Qt != nullptr;
+    // one block per component row; its three passes over the row are a chain of memory round trips, so a long row gets more
+    // threads (fewer elements per thread and pass): KLNMF_HRULE_THREADS overrides
+    int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
+    if (const char *g = std::getenv("KLNMF_HRULE_THREADS")) hthreads = std::min(1024, std::max(64, (std::atoi(g) / 64) * 64));
+    hipLaunchKernelGGL(k_update_pack_H, dim3((unsigned)c->k), dim3(hthreads), 0, c->stream, c->H32,
+                       (const float *)(from_slabs ? c->NpartF : c->numerF), lean ? (opnd_t *)nullptr : c->Ht, c->Ht4,
+                       lean ? (opnd_t *)nullptr : c->HTb, c->hsum, c->tcur, c->t_hs, wmax, &c->st->op_range, c->f, c->f_pad,
+                       c->KP, do_update, do_update ? (const DevState *)c->st : (const DevState *)nullptr, c->kc,
+                       (float)(kEpsRatio * c->v_scale), from_slabs ? c->nchunks : 0, (int64_t)c->KP * c->f_pad,
                        wmax ? (const DevState *)c->st : (const DevState *)nullptr);      // measured images carry DevState.cq_e
     HIPCHK(hipGetLastError());
     c->images_measured = wmax != nullptr;
@@ -846,7 +1057,7 @@ static void choose_eps_carrier(klnmf_ctx *c) {
 // then carries the ratio scale k_ratio_scale derives (mfma.hip.h; KLNMF_RATIO_SCALE=0: never); any other W: scale 1.
 void measure_and_pack(klnmf_ctx *c, bool from_init = false) {
     c->refusals_dirty = true;
-    const bool cq_ok = c->sw.ratio_scale;
+    const bool cq_ok = !(std::getenv("KLNMF_RATIO_SCALE") && std::atoi(std::getenv("KLNMF_RATIO_SCALE")) == 0);
     // (the eps row of the image is scaled too: it must stay an fp16 number)
     int e_cap = 12;
     if (c->kc >= 0) {
@@ -864,33 +1075,32 @@ void measure_and_pack(klnmf_ctx *c, bool from_init = false) {
     hipLaunchKernelGGL(k_colmax_W, dim3(rows_grid, (c->KP + 255) / 256), dim3(256), 0, c->stream,
                        (const float *)c->W32[c->cur], c->n_pad, c->KP, c->wmax);
     HIPCHK(hipGetLastError());
-    fast_pack_H(c, c->wmax);
+    fast_pack_H(c, 0, false, c->wmax);
     fast_pack_W(c);
 }
 
-// When a loop gives the fp8 regime up for its remaining iterations: bulk saturation of the ratio tiles (more entries per
-// iteration than the fix-up list holds: the range rule at the loop's entry normally excludes such matrices), or the monitor's
-// statistic above its threshold (monitor.hip.h).  Polled on the monitor's cadence -- fp8 iterations 1 .. 4 and every eighth
-// after them (one DevState read-back and stream synchronisation each).
+// Bulk saturation of the fp8 ratio tiles (more entries per iteration than k_q8_fixup's list holds: the data rule at the
+// loop's entry normally excludes such matrices): the loop gives the tiles up for its remaining iterations.  Polled at fp8
+// iterations 1, 2, 4, 8 and then every 16th (one DevState read-back each) -- bulk saturation is a property of the data and
+// the first updates, not something that develops late.
 // Row shards: every rank must drop the tiles in the SAME iteration (they would run different kernels otherwise, and the
 // replicas of H would drift apart): the count travels as the second double of the loss exchange -- every loss launch leaves
 // this rank's q8_unfixed in loss_xchg[1], the all-reduce (native or torch) sums it -- and `agreed` polls read that sum.
 void poll_fp8_overflow(klnmf_ctx *c, bool agreed = false) {
     if (!c->q8_loop || !c->q8() || c->in_capture) return;
     const int64_t n8 = c->stat_q8_tiles;
-    if (!monitor_due(n8)) return;
+    if (!(n8 == 1 || n8 == 2 || n8 == 4 || n8 == 8 || (n8 & 15) == 0)) return;
     if (agreed) {
         double h[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(h, c->loss_xchg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (h[1] > 0) { c->q8_loop = false; c->stat_mon_gave_up = true; }
+        if (h[1] > 0) c->q8_loop = false;
         return;
     }
     DevState hs{};
     HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    // 16-bit tiles from the next iteration on (klnmf_query reports the counts and the statistic)
-    if (hs.q8_unfixed > 0 || hs.mon_trips > 0) { c->q8_loop = false; c->stat_mon_gave_up = true; }
+    if (hs.q8_unfixed > 0) c->q8_loop = false;        // 16-bit tiles from the next iteration on (klnmf_query reports the count)
 }
 
 // ------------------------------------------------------------ exact pieces ---
@@ -904,12 +1114,14 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
                        (T *)c->HT, c->k, c->f, (const DevState *)c->st);
 #define KL_SPQ_ARGS (const int64_t *)c->sp_indptr, (const int64_t *)c->sp_indices, (const T *)c->sp_data, \
         (const T *)c->W[c->cur], (const T *)c->HT, (T *)c->sp_q, c->sp_row_loss, c->k, (T)eps, write_q, (const DevState *)c->st
-    // fp64: 32 entries per trip (half the registers, twice the waves per SIMD: sparse.hip.h)
+    // fp64: 32 entries per trip (half the registers, twice the waves per SIMD: sparse.hip.h); KLNMF_SPQ_NB=64 keeps 64
+    static const bool nb64 = std::getenv("KLNMF_SPQ_NB") && std::atoi(std::getenv("KLNMF_SPQ_NB")) == 64;
     constexpr int NBD = sizeof(T) == 8 ? 32 : 64;
     const int kc = (int)((c->k + 63) / 64);
 #define KL_SPQ_LAUNCH(KCV)                                                                                              \
     do {                                                                                                                \
-        hipLaunchKernelGGL((k_sp_q<T, KCV, NBD>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);           \
+        if (nb64) hipLaunchKernelGGL((k_sp_q<T, KCV, 64>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);   \
+        else hipLaunchKernelGGL((k_sp_q<T, KCV, NBD>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);      \
     } while (0)
     if (kc <= 1) KL_SPQ_LAUNCH(1);
     else if (kc == 2) KL_SPQ_LAUNCH(2);
@@ -937,8 +1149,19 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
     HIPCHK(hipGetLastError());
 }
 
-// k_gemm: 64 x 64 tiles, the inner product on the fp64 / fp32 MFMA (exact.hip.h)
-#define KL_GEMM_TT(tt, T, EPI, grid, stream, ...) hipLaunchKernelGGL((k_gemm<T, EPI, 4, true>), grid, dim3(256), 0, stream, __VA_ARGS__)
+// k_gemm with 64 x 64 (tt = 4) or 128 x 128 (tt = 8) tiles
+// ... 64 x 64 tiles: the inner product on the fp64 / fp32 MFMA (KLNMF_GEMM_MFMA=0: the VALU form)
+static bool gemm_mfma64() {
+    static const bool on = !(std::getenv("KLNMF_GEMM_MFMA") && std::atoi(std::getenv("KLNMF_GEMM_MFMA")) == 0);
+    return on;
+}
+#define KL_GEMM_TT(tt, T, EPI, grid, stream, ...)                                                          \
+    do {                                                                                                   \
+        if ((tt) == 8) hipLaunchKernelGGL((k_gemm<T, EPI, 8>), grid, dim3(256), 0, stream, __VA_ARGS__);    \
+        else if (gemm_mfma64())                                                                            \
+            hipLaunchKernelGGL((k_gemm<T, EPI, 4, true>), grid, dim3(256), 0, stream, __VA_ARGS__);         \
+        else hipLaunchKernelGGL((k_gemm<T, EPI, 4>), grid, dim3(256), 0, stream, __VA_ARGS__);              \
+    } while (0)
 
 // dec.on: the stop rule rides in the one-block loss reduction (single-context loops: no k_decide launch)
 template <typename T>
@@ -1068,41 +1291,45 @@ void reset_state(klnmf_ctx *c) {
     HIPCHK(hipGetLastError());
 }
 
-// fused_tol != nullptr (klnmf_run): the stop rule rides in the launch that reduces the loss (no k_decide launch)
+void piece_decide(klnmf_ctx *c, double tol_abs);
+// fused_tol != nullptr (klnmf_run): the stop rule rides in the loss kernel of the bf16 modes (no k_decide launch)
 void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol = nullptr, bool defer_to_post = false) {
     // the W rule is the same for fit and transform (nmf.py:251-253); a fit also keeps the ratios for the H rule
     if (c->is_exact()) {
-        // fused_tol (single-context loops): the stop rule in the loss reduction's launch, no k_decide
+        // fused_tol (single-context loops): the stop rule in the loss reduction's launch, no k_decide (KLNMF_EXACT_FUSE=0: apart)
+        static const bool xfuse = !(std::getenv("KLNMF_EXACT_FUSE") && std::atoi(std::getenv("KLNMF_EXACT_FUSE")) == 0);
         DecideArgs dec{0, nullptr, 0.0, nullptr, 0};
-        if (fused_tol) dec = DecideArgs{1, c->st, *fused_tol, c->errors, c->cap};
+        if (fused_tol && xfuse) dec = DecideArgs{1, c->st, *fused_tol, c->errors, c->cap};
         EXACT_CALL(c, exact_Q, 1, kEpsRatio, dec);
         EXACT_CALL(c, exact_W, c->sparse ? c->sp_q : c->Q, 1);
-        return;
+        if (fused_tol && !xfuse) piece_decide(c, *fused_tol);
+    } else {
+        const bool measured = c->images_measured;
+        fast_rowpass(c, ROW_UPDATE, fit);
+        // measured image scales live for one update: the new W image already carries the hs-based scale (tnext); in a fit
+        // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
+        if (measured && !fit) fast_pack_H(c, 0);
+        static const bool defer_ok = !(std::getenv("KLNMF_LOSS_DEFER") && std::atoi(std::getenv("KLNMF_LOSS_DEFER")) == 0);
+        if (fit && defer_to_post && c->fused) {
+            // a fit on a communicator: one extra block of the first part's summing launch (k_post) reduces the partials into
+            // loss_xchg, which is exchanged with the numerator; the stop rule rides in the launch behind the all-reduce
+            c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 0, c->st,
+                                       0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0};
+            return;
+        }
+        if (fit && fused_tol && defer_ok) {
+            // a fit in one context: nothing needs the loss before the H rule -- it is reduced (and the stop rule applied) by
+            // one extra block of the slab-sum launch behind the column pass (launch_sum_partials)
+            c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 1, c->st,
+                                       *fused_tol, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0};
+            return;
+        }
+        hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
+                           (const double2 *)c->loss_part2, c->loss_parts(),
+                           (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
+                           fused_tol ? *fused_tol : 0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0);
+        HIPCHK(hipGetLastError());
     }
-    const bool measured = c->images_measured;
-    fast_rowpass(c, ROW_UPDATE, fit);
-    // measured image scales live for one update: the new W image already carries the hs-based scale (tnext); in a fit
-    // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
-    if (measured && !fit) fast_pack_H(c);
-    if (fit && defer_to_post) {
-        // a fit on a communicator: one extra block of the first part's summing launch (k_post) reduces the partials into
-        // loss_xchg, which is exchanged with the numerator; the stop rule rides in the launch behind the all-reduce
-        c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 0, c->st,
-                                   0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0};
-        return;
-    }
-    if (fit && fused_tol) {
-        // a fit in one context: nothing needs the loss before the H rule -- it is reduced (and the stop rule applied) by
-        // k_post behind the column pass (piece_fit_tail)
-        c->pending_loss = LossArgs{(const double2 *)c->loss_part2, c->loss_parts(), 1.0 / c->v_scale, c->loss_xchg, 1, c->st,
-                                   *fused_tol, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0};
-        return;
-    }
-    hipLaunchKernelGGL(k_loss_from_parts, dim3(1), dim3(1024), 0, c->stream,
-                       (const double2 *)c->loss_part2, c->loss_parts(),
-                       (const DevState *)c->st, 1.0 / c->v_scale, c->loss_xchg, fused_tol ? 1 : 0, c->st,
-                       fused_tol ? *fused_tol : 0.0, c->errors, c->cap, c->last_row_ne ? 1 : 0, measured ? 1 : 0);
-    HIPCHK(hipGetLastError());
 }
 
 void piece_decide(klnmf_ctx *c, double tol_abs) {
@@ -1115,18 +1342,18 @@ const LossArgs kNoLoss{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0}
 
 void piece_colpass(klnmf_ctx *c) {
     if (c->is_exact()) { EXACT_CALL(c, exact_N, c->cur ^ 1); return; }
+    if (!c->fused) { fast_colpass(c); return; }
     // (the pieces of a loop sequenced by the caller: the numerator is summed here, exchanged by the caller, applied by
     // piece_update_H; the loss was left in loss_xchg by piece_rowpass)
     const bool use8 = fused_w8_stage(c);
     if (use8) c->stat_col8 += 1;
-    launch_monitor(c, use8);
     fused_colpass_part(c, c->whole, use8);
     launch_post(c, POST_SUM, &c->whole, 1, kNoLoss, false, use8, true);
 }
 
 // one column part of the split layout (the caller exchanges it while the next part computes)
 void piece_colpass_part(klnmf_ctx *c, int p) {
-    if (c->is_exact() || c->nparts_cfg <= 1) {
+    if (c->is_exact() || !c->fused || c->nparts_cfg <= 1) {
         if (p != 0) fail(KLNMF_ERR_ARG, "klnmf_iter_colpass_part: this problem has one part");
         piece_colpass(c);
         return;
@@ -1135,7 +1362,6 @@ void piece_colpass_part(klnmf_ctx *c, int p) {
     if (p == 0) {
         c->piece_use8 = fused_w8_stage(c);
         if (c->piece_use8) c->stat_col8 += 1;
-        launch_monitor(c, c->piece_use8);
     }
     fused_colpass_part(c, c->parts[p], c->piece_use8);
     launch_post(c, POST_SUM, &c->parts[p], 1, kNoLoss, false, c->piece_use8, p == c->nparts_cfg - 1);
@@ -1144,8 +1370,9 @@ void piece_colpass_part(klnmf_ctx *c, int p) {
 
 void piece_update_H(klnmf_ctx *c) {
     if (c->is_exact()) EXACT_CALL(c, exact_H);
-    else if (c->piece_split) launch_post(c, POST_RULE, c->parts, c->nparts_cfg, kNoLoss, false, false, false);
-    else launch_post(c, POST_RULE, &c->whole, 1, kNoLoss, false, false, false);
+    else if (c->fused && c->piece_split) launch_post(c, POST_RULE, c->parts, c->nparts_cfg, kNoLoss, false, false, false);
+    else if (c->fused) launch_post(c, POST_RULE, &c->whole, 1, kNoLoss, false, false, false);
+    else fast_pack_H(c, 1);
     c->piece_split = false;
 }
 
@@ -1153,19 +1380,24 @@ void piece_update_H(klnmf_ctx *c) {
 // tolerance ride in c->pending_loss when the stop rule is deferred to here)
 void piece_fit_tail(klnmf_ctx *c) {
     if (c->is_exact()) {
+        static const bool xfuse = !(std::getenv("KLNMF_EXACT_FUSE") && std::atoi(std::getenv("KLNMF_EXACT_FUSE")) == 0);
         // the H rule sums the row chunks' slabs itself where that is a few thousand loads per row (the reference's own data
         // scale: one launch less of 7); beyond, one block per row walking the slabs is slower than the wide sum kernel
         // (1000 x 2000, k = 50, 16 slabs: 97 vs 73 us per iteration)
-        const bool slabs = !c->sparse && c->hseg_n == 1 && (int64_t)c->nsplit * c->f <= 8192;
+        const bool slabs = xfuse && !c->sparse && c->hseg_n == 1 && (int64_t)c->nsplit * c->f <= 8192;
         EXACT_CALL(c, exact_N, c->cur ^ 1, !slabs);
         EXACT_CALL(c, exact_H, slabs);
+        return;
+    }
+    if (!c->fused) {
+        piece_colpass(c);
+        piece_update_H(c);
         return;
     }
     const LossArgs la = c->pending_loss;
     c->pending_loss.part = nullptr;
     const bool use8 = fused_w8_stage(c);
     if (use8) c->stat_col8 += 1;
-    launch_monitor(c, use8);
     fused_colpass_part(c, c->whole, use8);
     launch_post(c, POST_FULL, &c->whole, 1, la, la.part != nullptr, use8, true);
 }
@@ -1187,8 +1419,6 @@ void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopp
     if (stopped) *stopped = hs.stop;
     c->stat_w8_sat = hs.w8_sat_total; c->stat_w8_fallbacks = hs.w8_fallbacks;
     c->stat_q8_sat = hs.q8_sat_total; c->stat_q8_unfixed = hs.q8_unfixed;
-    c->stat_mon_checks = hs.mon_checks; c->stat_mon_trips = hs.mon_trips;
-    { float m; std::memcpy(&m, &hs.mon_stat_bits, 4); c->stat_mon_max = (double)m; }
     // the current W is the one the last *executed* update wrote
     c->cur = (c->loop_start_cur + (int)(hs.n_done & 1)) & 1;
     // ... and so is the current dictionary master: k_post swaps H32 / H32alt per ENQUEUED H rule, the device performed
@@ -1216,10 +1446,15 @@ void place_block(klnmf_ctx *c, const S *dsrc, int64_t rows, int64_t cols, int64_
             hipLaunchKernelGGL((k_place_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
                                (float *)c->V, c->f, dsrc, rows, cols, ld, row0, col0, scale, row_idx);
             break;
-        default:
-            hipLaunchKernelGGL((k_tile_V<S>), dim3(grid), dim3(256), 0, c->stream,
-                               (_Float16 *)c->VtA, c->nrt, c->nct, dsrc, rows, cols,
+        case KLNMF_PREC_BF16:
+            hipLaunchKernelGGL((k_tile_V<_Float16, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (_Float16 *)c->VtA, (_Float16 *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
                                ld, row0, col0, scale * c->v_scale, c->st, row_idx, kEpsRatio * c->v_scale);
+            break;
+        default:
+            hipLaunchKernelGGL((k_tile_V<float, S>), dim3(grid), dim3(256), 0, c->stream,
+                               (float *)c->VtA, (float *)c->VtB, c->nrt, c->nct, dsrc, rows, cols,
+                               ld, row0, col0, scale * c->v_scale, c->st, row_idx);      // same units as the fp16 storage
             break;
     }
     HIPCHK(hipGetLastError());
@@ -1399,7 +1634,7 @@ int klnmf_device_info(int device, char *arch, int arch_len, int *cu_count, uint6
 int klnmf_create(klnmf_ctx **out, int device, int precision, void *stream) {
     return guarded([&] {
         if (!out) fail(KLNMF_ERR_ARG, "null out pointer");
-        if (precision < KLNMF_PREC_F64 || precision > KLNMF_PREC_F16)
+        if (precision < KLNMF_PREC_F64 || precision > KLNMF_PREC_BF16_V32)
             fail(KLNMF_ERR_ARG, "unknown precision mode");
         int ndev = 0;
         HIPCHK(hipGetDeviceCount(&ndev));
@@ -1434,6 +1669,40 @@ int klnmf_destroy(klnmf_ctx *c) {
         if (!c) return;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+#ifdef KL_STAMPS
+        if (c->stamps && c->nrt > 0) {
+            std::vector<unsigned long long> hs((size_t)c->nrt * 8);
+            (void)hipMemcpy(hs.data(), c->stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+            double sum[8] = {0};
+            for (int i = 0; i < c->nrt; ++i) for (int j = 0; j < 8; ++j) sum[j] += (double)hs[(size_t)i * 8 + j];
+            const double tiles = (double)c->nct;
+            if (c->pingpong() && c->KT > 8)
+                std::fprintf(stderr, "[stampsF] per tile per wave (cycles): vmcnt wait %.0f | barrier %.0f | stores+loads+copies issue %.0f | MFMA-2 + epilogue %.0f | MFMA-1 %.0f || kernel %.0f cycles, %d tiles\n",
+                             sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles, sum[4] / c->nrt / tiles, sum[0] / c->nrt / tiles,
+                             sum[1] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
+            else if (c->row_gen == 4 && c->prec == KLNMF_PREC_BF16 && c->KT <= 7) {
+                double pro = 0, epi = 0;
+                for (int i = 0; i < c->nrt; ++i) { pro += (double)(hs[(size_t)i * 8 + 7] >> 32); epi += (double)(hs[(size_t)i * 8 + 7] & 0xffffffffull); }
+                std::fprintf(stderr, "[stamps4] per wave: prologue %.0f cycles, epilogue %.0f cycles\n", pro / c->nrt, epi / c->nrt);
+#ifdef KL_STAMPS2
+                std::fprintf(stderr, "[stamps4] epilogue: loss sums %.0f | old W loads landed %.0f | W rule, stores, drain %.0f\n",
+                             sum[2] / c->nrt, sum[5] / c->nrt, epi / c->nrt - sum[2] / c->nrt - sum[5] / c->nrt);
+#endif
+                for (int w = 0; w < 8; ++w) {          // per wave of the workgroup (waves 0-3 = X, 4-7 = Y): who waits for whom
+                    double sw[8] = {0}; int cnt = 0;
+                    for (int i = w; i < c->nrt; i += 8) { for (int j = 0; j < 8; ++j) sw[j] += (double)hs[(size_t)i * 8 + j]; ++cnt; }
+                    if (cnt) std::fprintf(stderr, "[stamps4] wave %d: M %.0f | E %.0f | V wait %.0f | barrier after M %.0f | after E %.0f | kernel %.0f\n", w,
+                                          sw[0] / cnt / tiles, sw[1] / cnt / tiles, sw[2] / cnt / tiles, sw[3] / cnt / tiles, sw[4] / cnt / tiles, sw[6] / cnt);
+                }
+                std::fprintf(stderr, "[stamps4] per tile per wave (cycles): M segment %.0f | E segment %.0f | V wait %.0f | copy wait %.0f | barrier after M %.0f | barrier after E %.0f || kernel %.0f cycles, %d tiles\n",
+                             sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[5] / c->nrt / tiles,
+                             sum[3] / c->nrt / tiles, sum[4] / c->nrt / tiles, sum[6] / c->nrt, c->nct);
+            } else
+            std::fprintf(stderr, "[stamps] per tile per wave (cycles): prime+V %.0f | MFMA1 %.0f | epilogue %.0f | MFMA2 %.0f || per stage: barrier wait %.0f, compute %.0f || kernel %.0f cycles, %d stages\n",
+                         sum[0] / c->nrt / tiles, sum[1] / c->nrt / tiles, sum[2] / c->nrt / tiles, sum[3] / c->nrt / tiles,
+                         sum[4] / c->nrt / c->nst, sum[5] / c->nrt / c->nst, sum[6] / c->nrt, c->nst);
+        }
+#endif
         c->free_all();
         if (c->comm || c->comm_scratch) {
             try { comm_release(c); } catch (...) {}
@@ -1454,7 +1723,6 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
                                    "shard the rows or use the 16-bit mode");
         HIPCHK(hipStreamSynchronize(c->stream));
         c->free_all();
-        c->sw = DevSwitches::read();
         c->Gpart = nullptr; c->row_chunks = 1; c->tail_wg = 0; c->tail_chunks = 1;
         c->Wpart = nullptr; c->wsplit = 1;
         c->hseg_n = 1; c->hpart = nullptr;
@@ -1475,20 +1743,26 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->W[0] = c->dalloc((size_t)n * k * es);
             c->W[1] = c->dalloc((size_t)n * k * es);
             c->H = c->dalloc((size_t)k * f * es);
-            // 64 x 64 output tiles (k_gemm).  Measured (profiles/r04_exact_modes.txt): with the register prefetch they win over
-            // 128 x 128 tiles at every shape tried (2000 x 4096, k = 200, fp64: 440 us per iteration against 455, 537 before):
-            // four waves per SIMD hide more than the halved LDS traffic gains.
+            // 128 x 128 output tiles (8 x 8 per thread: k_gemm) where both output dimensions are long enough to fill them;
+            // KLNMF_GEMM_TT=4 keeps the 64 x 64 tiles of rounds 1-3 everywhere
+            const bool tt4 = std::getenv("KLNMF_GEMM_TT") && std::atoi(std::getenv("KLNMF_GEMM_TT")) == 4;
+            const bool tt8 = std::getenv("KLNMF_GEMM_TT") && std::atoi(std::getenv("KLNMF_GEMM_TT")) == 8;      // (force, for A/B runs)
             auto tiles_of = [](int64_t M, int64_t N, int64_t TL) { return ((M + TL - 1) / TL) * ((N + TL - 1) / TL); };
-            c->q_tt = 4;
+            // ... i.e. where the grid of 128 x 128 tiles (times the contraction split, if the GEMM has one) still covers the chip
+            // Measured (profiles/r04_exact_modes.txt): with the register prefetch the 64 x 64 tiles win at every shape tried
+            // (2000 x 4096, k = 200, fp64: 440 us per iteration against 455 with 128 x 128 tiles, 537 before): four waves per
+            // SIMD hide more than the halved LDS traffic gains.  128 x 128 tiles only on request (KLNMF_GEMM_TT=8).
+            (void)tt4;
+            c->q_tt = (tt8 && n >= 96 && f >= 96) ? 8 : 4;
             const int64_t smax = (n + 63) / 64;          // at least four contraction steps per chunk
             auto n_split = [&](int tt) {
                 const int64_t tiles = tiles_of(k, f, 16 * tt);
-                int64_t s = (4 * (int64_t)c->cu_count + tiles - 1) / tiles;
+                int64_t s = ((tt == 8 ? 2 : 4) * (int64_t)c->cu_count + tiles - 1) / tiles;
                 if (s > smax) s = smax;
                 if (s < 1) s = 1;
                 return s;
             };
-            c->n_tt = 4;
+            c->n_tt = (tt8 && k >= 96 && f >= 96) ? 8 : 4;
             int64_t s = n_split(c->n_tt);
             int64_t chunk = (n + s - 1) / s;
             chunk = (chunk + GK - 1) / GK * GK;
@@ -1501,15 +1775,16 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->hpart = c->hseg_n > 1 ? (double *)c->dalloc(sizeof(double) * (size_t)k * c->hseg_n) : nullptr;
             c->numer = c->dalloc((size_t)k * f * es);
             // W rule: n*k/4096 output tiles, each contracting over all of f.  With fewer tiles than CUs split f so that
-            // the grid covers the chip about twice.
+            // the grid covers the chip about twice (KLNMF_W_SPLIT = 0 / N forces it off / to N chunks).
             {
                 auto w_split = [&](int tt) {
                     const int64_t wt = tiles_of(k, n, 16 * tt);
-                    int64_t w = wt < c->cu_count ? (2 * (int64_t)c->cu_count + wt - 1) / wt : 1;
+                    int64_t w = wt < c->cu_count ? ((tt == 8 ? 1 : 2) * (int64_t)c->cu_count + wt - 1) / wt : 1;
                     return std::min<int64_t>(w, (f + 4 * GK - 1) / (4 * GK));
                 };
-                c->w_tt = 4;
+                c->w_tt = (tt8 && n >= 96 && k >= 96) ? 8 : 4;
                 int64_t ws = w_split(c->w_tt);
+                if (const char *g = std::getenv("KLNMF_W_SPLIT")) ws = std::max(1, std::atoi(g));
                 ws = std::min<int64_t>(ws, (f + 4 * GK - 1) / (4 * GK));
                 while (ws > 1 && ws * n * k * (int64_t)es > ((int64_t)256 << 20)) --ws;
                 int64_t wch = (f + ws - 1) / ws;
@@ -1522,24 +1797,34 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->loss_part_count = ((f + GT - 1) / GT) * ((n + GT - 1) / GT);
             c->loss_part = (double *)c->dalloc(sizeof(double) * c->loss_part_count);
         } else {
+            c->row_gen = 4;          // (a pooled context keeps its handle across problems: an override of an earlier problem must not stick)
+            c->col_gen = 2;
+            if (const char *g = std::getenv("KLNMF_ROWPASS")) c->row_gen = std::atoi(g);
+            if (const char *g = std::getenv("KLNMF_COLPASS")) c->col_gen = std::atoi(g);
             c->KT = (int)((k + 31) / 32);
             c->ks = (int)((k + 15) / 16);
             c->big = false;
-            if (k > 512) fail(KLNMF_ERR_UNSUPP, "k > 512 runs in KLNMF_PREC_F32 / F64 (the 16-bit MFMA kernels cover k <= 512)");
             if (c->KT >= 8) {
-                // 224 < k <= 512: 4-wave workgroups of the row pass (whole register file per wave, FUSED order) and the
-                // component-split column passes; component tiles in pairs, the W.H contraction over all of them
-                c->big = true;
-                c->KT = 2 * (int)((k + 63) / 64);
-                c->ks = 2 * c->KT;
+                // 224 < k <= 512: 4-wave workgroups of the ping-pong row pass (whole register file per wave, FUSED order) and
+                // the component-split column passes; component tiles in pairs, the W.H contraction over all of them.
+                // (Round 3: KT = 8 joined -- 224 < k <= 256 ran the generation-1 kernels with a second copy of V before.)
+                const bool can = c->prec == KLNMF_PREC_BF16 && c->row_gen == 4 && k <= 512;
+                if (c->KT > 8 && !can)
+                    fail(KLNMF_ERR_UNSUPP, "k > 256 runs in KLNMF_PREC_BF16 (k <= 512, ping-pong row pass) or KLNMF_PREC_F32/F64");
+                if (can) {
+                    c->big = true;
+                    c->KT = 2 * (int)((k + 63) / 64);
+                    c->ks = 2 * c->KT;
+                }
             }
             c->KP = 32 * c->KT;
             // both passes work on 64-row / 64-column stages: pad to 64 (zero padding is inert)
             c->n_pad = (n + 63) / 64 * 64;
-            c->f_pad = (f + 127) / 128 * 128;            // the row pass walks 4 column tiles per loop body
+            c->f_pad = (f + 127) / 128 * 128;            // the ping-pong row pass walks 4 column tiles per loop body
             c->nrt = (int)(c->n_pad / 32);
             c->nct = (int)(c->f_pad / 32);
             c->nct_used = (int)((f + 63) / 64 * 2);      // column tiles that hold data (column pass)
+            c->nst = c->nct / 2;
             c->v_scale = 1.0;
             c->v_uploaded = false;
             c->refusals_dirty = true;
@@ -1550,34 +1835,43 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // 16 305 x 28, k = 8, where the image is exactly 1 MiB and ends on a mapping boundary.)
             const int64_t copy_rows = (colq_w_area(c->KP) + (int64_t)w_ld(c->KP) * 2 - 1) / ((int64_t)w_ld(c->KP) * 2);
             c->w_rows = (int64_t)total_stages * 32 * kStageRowTiles + std::max<int64_t>(64, copy_rows);
-            const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * 2;
-            // fp8 ratio tiles: only the H numerator -- a sum over all rows -- sees their 3-bit significands; its relative
-            // error falls like 0.036 sqrt(2 / n), so they are used from 32 769 / 65 536 rows per context on (row_chunks_possible_q8;
-            // KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
-            const bool col8_off = c->sw.col8 == 0;
+            const size_t vs = c->vsize();
+            const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * vs;
+            // column pass on the ratios the ping-pong row pass stores (k_colpass_q) where that row pass runs;
+            // otherwise the recomputing one, which needs the second, column-tiled copy of V
+            const bool stored_q = c->pingpong() && (c->col_gen >= 2 || c->big);
+            // fp8 ratio tiles: only the H numerator -- a sum over all rows -- sees their 4-bit significands; its relative
+            // error falls like 0.036 sqrt(2 / n) (5e-5 at 1M rows, 2e-4 at 65 536: below the operands' own rounding), so
+            // they are used from 65 536 rows per context on (KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
+            const bool col8_off = std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 0;
             const bool q8_kt = !c->big || !col8_off;      // (k > 224: fp8 tiles only with the fp8 x fp8 column pass)
-            c->q8_ok = q8_kt && c->row_chunks_possible_q8(n, c->big);
-            if (c->sw.qtile != 0) c->q8_ok = q8_kt && c->sw.qtile == 8;
+            c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->big) && c->row_chunks_possible_q8(n, c->big);
+            if (const char *g = std::getenv("KLNMF_QTILE")) c->q8_ok = stored_q && q8_kt && (c->col_gen == 2 || c->big) && std::atoi(g) == 8;
             c->q8_loop = false;
             c->iter_in_loop = 0;
             c->v_max = 0.0;
-            c->ne_ok = c->q8_ok && !c->big;      // (q8_ok: enough rows for fp8 ratio tiles -- where the NE kernels exist)
+            c->ne_ok = c->q8_ok && !c->big && c->vsize() == 2;      // (q8_ok: enough rows for fp8 ratio tiles -- where the NE kernels exist)
             c->VtA = c->dalloc(vbytes, false);
+            c->VtB = stored_q ? nullptr : c->dalloc(vbytes, false);
             fill_v_tiles(c, c->VtA, vbytes);
-            c->Qt = (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile);      // (fp8 tiles use the first half of the buffer)
-            c->W8 = nullptr; c->w8s = nullptr; c->w8_meas = false;
+            if (c->VtB) fill_v_tiles(c, c->VtB, vbytes);
+            c->Qt = stored_q ? (unsigned char *)c->dalloc((size_t)c->nrt * c->nct * kQTile) : nullptr;      // (fp8 tiles use half of each slot)
+            c->W8 = nullptr; c->w8max = nullptr; c->w8s = nullptr; c->w8fin = nullptr; c->w8_meas = false;
             c->q8_list = c->q8_ok ? (uint2 *)c->dalloc(sizeof(uint2) * kQ8ListCap) : nullptr;
-            // fp8 x fp8 column pass (e4m3 image of W_new): where the H-numerator product is worth the conversion launch --
-            // k > 96 and 65 536 rows or more; below that the f16-operand column pass reads the fp8 tiles (C2, k = 50: 0.053 ms
-            // against 0.050 + 0.03 ms of conversions; profiles/r03_c2_schedules.txt)
-            const bool col8_size = c->big || (c->KT >= 4 && n >= 65536) || c->sw.col8 >= 1;
+            // fp8 x fp8 column pass (e4m3 image of W_new): where the H-numerator product is worth three more small launches per
+            // iteration (conversion, maxima, scales) -- k > 96 and 65 536 rows or more; below that the f16-operand column pass
+            // reads the fp8 tiles (C2, k = 50: 0.053 ms against 0.050 + 0.03 ms of conversions; profiles/r03_c2_schedules.txt)
+            const bool col8_size = c->big || (c->KT >= 4 && n >= 65536) || (std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) >= 1);
             if (c->q8_ok && !col8_off && col8_size) {
                 c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * w8_ld(c->KP) + 65536);
+                c->w8max = (unsigned *)c->dalloc(((size_t)c->nrt + kW8Blocks) * c->KP * 4);
                 // who writes the e4m3 image: the conversion kernel behind the row pass (default) or the row pass's W rule itself
-                // (KLNMF_COL8=2, k <= 224: one pass over W less and no conversion launch -- +0.6 % at n = 10^6, -0.8 % on a
-                // 125 000-row shard where the tail weighs more: profiles/r03_ab_w8_from_w_rule.txt; not the default)
-                c->w8_tail = !c->big && c->sw.col8 == 2;
+                // (KLNMF_COL8=2, k <= 224: one pass over W less and no conversion launch, counted and probed like the kernel's
+                // image since round 3 -- +0.6 % at n = 10^6, -0.8 % on a 125 000-row shard where the tail weighs more:
+                // profiles/r03_ab_w8_from_w_rule.txt; not the default)
+                c->w8_tail = !c->big && std::getenv("KLNMF_COL8") && std::atoi(std::getenv("KLNMF_COL8")) == 2;
                 c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
+                c->w8fin = (unsigned *)c->dalloc((size_t)c->KP * 4);      // (dalloc hands out zero-filled blocks)
                 const std::vector<float> unit8((size_t)c->KP, 256.f);
                 HIPCHK(hipMemcpyAsync(c->w8s, unit8.data(), unit8.size() * 4, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
@@ -1587,10 +1881,12 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
                 c->Wb[i] = (opnd_t *)c->dalloc((size_t)c->w_rows * w_ld(c->KP) * 2);
             }
             c->H32 = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
+            c->Ht = (opnd_t *)c->dalloc((size_t)c->nst * h_stage_bytes(c->KP) + kGldsRound);
             c->Ht4 = (opnd_t *)c->dalloc((size_t)c->nct * h4_tile_bytes(c->KP) + kObj4);
-            // eps through a pad component (k_update_pack_H): the row pass's W epilogue keeps the carrier column at 2^-10; needs
-            // a spare component inside the MFMA-1 contraction range
-            c->kc_shape = (k < 16 * c->ks && c->sw.eps_pad) ? (int)k : -1;
+            c->HTb = (opnd_t *)c->dalloc((size_t)c->f_pad * c->KP * 2);
+            // eps through a pad component (k_update_pack_H): needs the ping-pong row pass (its W epilogue keeps the
+            // carrier column at 1) and a spare component inside the MFMA-1 contraction range
+            c->kc_shape = (c->pingpong() && k < 16 * c->ks && !std::getenv("KLNMF_NO_EPS_PAD")) ? (int)k : -1;
             choose_eps_carrier(c);
             c->hsum = (double *)c->dalloc((size_t)c->KP * 8);
             c->tcur = (float *)c->dalloc((size_t)c->KP * 4);
@@ -1604,13 +1900,18 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
                     HIPCHK(hipMemcpyAsync(t, unit.data(), unit.size() * 4, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
             }
+#ifdef KL_STAMPS
+            c->stamps = (unsigned long long *)c->dalloc((size_t)c->nrt * 8 * 8);
+#endif
             // column pass decomposition: column blocks of 8 tiles x row chunks; keep the grid a
             // multiple of 8 (XCD remap) and close to a multiple of the CU count
             const int ctw = c->big ? kWavesPerWG / 2 : kWavesPerWG;      // column tiles per workgroup (colq.hip.h, KSPLIT)
             c->ncb = (c->nct_used + ctw - 1) / ctw;
+            int64_t wg_per_cu = 1;       // workgroups per CU the decomposition aims at (one is resident per CU; 2 measured 1-3 % slower)
+            if (const char *g = std::getenv("KLNMF_COL_WG_PER_CU")) wg_per_cu = std::max(1, std::atoi(g));
             auto chunks_for = [&](int ncb) {      // row chunks of a column pass over `ncb` column blocks: the grid fills the chip once
-                int nch = 8;                      // (one workgroup is resident per CU; two per CU measured 1-3 % slower)
-                while ((int64_t)nch * ncb < c->cu_count && nch * 2 <= total_stages) nch += 8;
+                int nch = 8;
+                while ((int64_t)nch * ncb < wg_per_cu * c->cu_count && nch * 2 <= total_stages) nch += 8;
                 while (nch > 8 && ((int64_t)nch * ncb) % c->cu_count != 0 &&
                        (int64_t)(nch - 8) * ncb >= c->cu_count) nch -= 8;
                 if (nch > total_stages) nch = total_stages > 0 ? ((total_stages + 7) / 8) * 8 : 8;
@@ -1621,7 +1922,12 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             c->stages_per_chunk = (total_stages + nch - 1) / nch;
             c->whole = klnmf_ctx::PartCfg{0, c->ncb, 0, c->nct_used, 0, (int)f, (int)c->f_pad, nch, c->stages_per_chunk, 0, 0};
             // column parts for loops on a communicator (overlap of the numerator's all-reduce with the column pass)
-            c->nparts_cfg = std::min(std::min(kPostMaxParts, std::max(1, c->sw.comm_parts)), c->ncb);
+            c->fused = stored_q && (c->col_gen == 2 || c->big) &&
+                       !(std::getenv("KLNMF_FUSE") && std::atoi(std::getenv("KLNMF_FUSE")) == 0);
+            c->nparts_cfg = 1;
+            if (const char *g = std::getenv("KLNMF_COMM_PARTS")) c->nparts_cfg = std::min(kPostMaxParts, std::max(1, std::atoi(g)));
+            if (!c->fused) c->nparts_cfg = 1;
+            c->nparts_cfg = std::min(c->nparts_cfg, c->ncb);
             int64_t split_numer = 0, split_slabs = 0;
             if (c->nparts_cfg > 1) {
                 for (int p = 0; p < c->nparts_cfg; ++p) {
@@ -1643,24 +1949,23 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             }
             c->NpartF = (float *)c->dalloc((size_t)std::max<int64_t>((int64_t)nch * c->KP * c->f_pad, split_slabs) * 4);
             c->numerF = (float *)c->dalloc((size_t)std::max<int64_t>((int64_t)c->KP * c->f_pad, split_numer) * 4);
-            c->H32alt = (float *)c->dalloc((size_t)c->KP * c->f_pad * 4);
+            c->H32alt = c->fused ? (float *)c->dalloc((size_t)c->KP * c->f_pad * 4) : nullptr;
             c->loop_hswaps = 0;
             c->w8tab = nullptr; c->w8s_next = nullptr; c->conv_ran = false;
-            if (c->W8) {
+            if (c->fused && c->W8) {
                 c->w8tab = (unsigned *)c->dalloc((size_t)kW8TabRows * c->KP * 4);      // (zero-filled)
                 c->w8s_next = (float *)c->dalloc((size_t)c->KP * 4);
                 HIPCHK(hipMemcpyAsync(c->w8s_next, c->w8s, (size_t)c->KP * 4, hipMemcpyDeviceToDevice, c->stream));
             }
-            monitor_setup(c);
             // Column-split update pass: with fewer than half as many 8-wave workgroups as CUs (n < ~32 000 rows; the
             // reference's own data sets have 10^2..10^3) split every row block's columns over blockIdx.y so that the grid
-            // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N (development switch) forces it off / to N chunks.
+            // fills the chip once.  KLNMF_ROW_SPLIT = 0 / N forces it off / to N chunks.
             c->row_chunks = 1;
             c->row_ct_chunk = c->nct;
-            if (!c->big && !c->q8_ok) {
+            if (c->pingpong() && !c->big && kWaves4 == 8 && !c->q8_ok) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 int want = (2 * nwg <= c->cu_count) ? c->cu_count / nwg : 1;
-                if (c->sw.row_split >= 0) want = std::max(1, c->sw.row_split);
+                if (const char *g = std::getenv("KLNMF_ROW_SPLIT")) want = std::max(1, std::atoi(g));
                 want = std::min(want, c->nct / 4);
                 const int64_t slab_bytes = (int64_t)c->nrt * 32 * c->KP * 4;
                 while (want > 1 && want * slab_bytes > (int64_t)256 << 20) --want;
@@ -1672,13 +1977,13 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             }
             // Hybrid update pass: more workgroups than CUs, and a last partial round of at most half the CUs (one
             // workgroup per CU: 254 registers).  Its workgroups are split into as many column chunks as fill the chip
-            // once (n = 10^6: 67 workgroups x 3 chunks; 90 000 rows: 96 x 2).  KLNMF_ROW_TAIL = 0 (development switch): off.
+            // once (n = 10^6: 67 workgroups x 3 chunks; 90 000 rows: 96 x 2).  KLNMF_ROW_TAIL = 0 switches it off.
             c->tail_wg = 0; c->tail_chunks = 1; c->tail_ct_chunk = c->nct;
-            if (!c->big && c->row_chunks == 1) {
+            if (c->pingpong() && !c->big && kWaves4 == 8 && c->row_chunks == 1) {
                 const int nwg = (c->nrt + kWaves4 - 1) / kWaves4;
                 const int rem = nwg % c->cu_count;
                 int want = (nwg > c->cu_count && rem > 0) ? c->cu_count / rem : 1;
-                if (c->sw.row_tail >= 0) want = std::min(want, std::max(1, c->sw.row_tail));
+                if (const char *g = std::getenv("KLNMF_ROW_TAIL")) want = std::min(want, std::max(1, std::atoi(g)));
                 want = std::min(std::min(want, 4), c->nct / 4);
                 if (want > 1) {
                     c->tail_ct_chunk = 4 * ((c->nct / 4 + want - 1) / want);
@@ -1805,7 +2110,7 @@ int klnmf_set_v_max(klnmf_ctx *c, double vmax) {
         c->v_scale = std::ldexp(1.0, 15 - e);   // c * vmax in [2^14, 2^15)
         c->v_max = vmax;
         choose_eps_carrier(c);
-        if (c->kc >= 0) fast_pack_H(c);      // the eps row of the dictionary images is in scaled units
+        if (c->kc >= 0) fast_pack_H(c, 0);      // the eps row of the dictionary images is in scaled units
     });
 }
 
@@ -1818,7 +2123,9 @@ int klnmf_reset_V(klnmf_ctx *c) {
         if (c->is_exact()) {
             HIPCHK(hipMemsetAsync(c->V, 0, (size_t)c->n * c->f * c->esize(), c->stream));
         } else {
-            fill_v_tiles(c, c->VtA, (size_t)c->nrt * c->nct * 1024 * 2);
+            const size_t vbytes = (size_t)c->nrt * c->nct * 1024 * c->vsize();
+            fill_v_tiles(c, c->VtA, vbytes);
+            if (c->VtB) fill_v_tiles(c, c->VtB, vbytes);
         }
         HIPCHK(hipMemsetAsync(&c->st->sum_x, 0, sizeof(double) * 4, c->stream));         // sum_x, corr_c, corr_eps, nnz_x
         HIPCHK(hipMemsetAsync(&c->st->v_overflow, 0, sizeof(int), c->stream));
@@ -1888,7 +2195,7 @@ int klnmf_set_H(klnmf_ctx *c, const void *src, int dtype) {
         if (!c->is_exact()) HIPCHK(hipMemsetAsync(c->H32, 0, (size_t)c->KP * c->f_pad * 4, c->stream));
         set_matrix(c, src, dtype, c->k, c->f, c->H, c->H32, c->f_pad);
         if (!c->is_exact()) {
-            fast_pack_H(c);          // hs-based scales (also leaves them in t_hs)
+            fast_pack_H(c, 0);          // hs-based scales (also leaves them in t_hs)
             measure_and_pack(c);        // the W that is there (zeros, W0 of another dictionary, a klnmf_set_W) goes with it
         }
     });
@@ -1919,7 +2226,7 @@ int klnmf_set_H_device(klnmf_ctx *c, const void *dsrc, int dtype, int64_t ld, in
         }
         if (last) {
             if (!c->is_exact()) {
-                fast_pack_H(c);
+                fast_pack_H(c, 0);
                 measure_and_pack(c);
             }
             HIPCHK(hipStreamSynchronize(c->stream));      // the caller's buffer may go away
@@ -2011,7 +2318,7 @@ static Refusals read_refusals(klnmf_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     Refusals r;
     r.op_range = ds.op_range;
-    r.v_overflow = c->v_uploaded ? ds.v_overflow : 0;
+    r.v_overflow = (c->prec == KLNMF_PREC_BF16 && c->v_uploaded) ? ds.v_overflow : 0;
     return r;
 }
 static void raise_refusals(klnmf_ctx *c, const Refusals &r) {
@@ -2026,48 +2333,26 @@ static void raise_refusals(klnmf_ctx *c, const Refusals &r) {
 }
 static void check_v_overflow(klnmf_ctx *c) { raise_refusals(c, read_refusals(c)); }
 
-// Loop entry points only (klnmf_run, klnmf_run_sharded, klnmf_loop_begin): may THIS loop use fp8 ratio tiles (e4m3 of
-// ratio x sqrt(2) / 8, from its third iteration on)?  Three things decide, in this order:
-//   shape   q8_ok of klnmf_set_problem: enough rows per context that the tiles' bytes matter (32 769 / 65 536);
-//   range   the tiles end at 3584 / sqrt(2) (saturating): data whose largest entry is more than 256 times the mean entry can hold
-//           ratios beyond that for many iterations (a spike the model has not fitted yet) -- those keep the 16-bit tiles.  What
-//           still saturates in a loop that passed is corrected exactly (fix-up list) or, in bulk, ends the fp8 regime;
-//   what the e4m3 rounding does to THIS data's H numerator is not guessed here but MEASURED while the loop runs: the monitor
-//           (monitor.hip.h, launch_monitor) -- a loop that fails it continues on 16-bit tiles.  Round 4 held five more data
-//           rules at this place (components, columns, stored entries per column, ...), each added after a fuzz case had
-//           ended 2e-4 .. 1.2e-3 off the oracle; KLNMF_Q8_RULES=1 (development switch) re-applies the three that round 5's
-//           monitor replaced, for A/B runs.
-// KLNMF_QTILE = 8 (development) forces the tiles on, = 16 off.  `sum_x_global` / `cells_global` / `nnz_global`: the sums over ALL
-// ranks' shards (the sharded loop passes the all-reduced values, so that every rank takes the same path); negative: this
-// context's own.  `ok_all`: the conjunction of every rank's q8_ok (shards that straddle the row threshold must not mix tile
-// formats: since round 4 fp8-tile numerators are sqrt(2) larger than 16-bit-tile ones); negative: this context's own.
-static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cells_global = -1.0, double nnz_global = -1.0,
-                           int ok_all = -1) {
-    c->sw = DevSwitches::read();
+// Loop entry points only (klnmf_run, klnmf_run_sharded, klnmf_loop_begin): does THIS loop use fp8 ratio tiles?  Their range
+// ends at 3584 (saturating): data whose largest entry is more than 256 times the mean entry can hold ratios beyond that for
+// many iterations (a spike the model has not fitted yet) -- those keep the 16-bit tiles.  KLNMF_QTILE = 8 forces the tiles on
+// (from the third iteration), = 16 off.  `sum_x_global` / `cells_global`: the sums over ALL ranks' shards (the sharded loop
+// passes the all-reduced values, so that every rank takes the same path); negative: this context's own.
+static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cells_global = -1.0, double nnz_global = -1.0) {
     c->q8_loop = false;
     c->iter_in_loop = 0;
     c->w8_meas = false;
+    c->w8_use = false;
     c->stat_q8_tiles = 0;
     c->stat_col8 = 0;
     c->ne_loop = false;
     c->last_row_ne = false;
-    c->mon_checks = 0;
-    c->mon_pending = false;
-    c->stat_mon_gave_up = false;
-    if (c->is_exact() || !c->q8_ok || ok_all == 0) return;
-    if (c->W8 != nullptr && c->w8tab != nullptr) {
-        // a loop that stopped inside k_post can leave the conversion's maxima table filled and the scale buffers swapped an odd
-        // number of times: every loop starts from an empty table and unit scales (its second iteration measures)
-        const std::vector<float> unit8((size_t)c->KP, 256.f);
-        HIPCHK(hipMemsetAsync(c->w8tab, 0, (size_t)kW8TabRows * c->KP * 4, c->stream));
-        HIPCHK(hipMemcpyAsync(c->w8s, unit8.data(), unit8.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->w8s_next, unit8.data(), unit8.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        c->conv_ran = false;
-    }
-    if (c->sw.qtile != 0) {
-        c->q8_loop = c->sw.qtile == 8;
-        c->ne_loop = c->q8_loop && c->ne_ok && c->sw.ne == 1;
+    if (c->is_exact() || !c->q8_ok) return;
+    const char *ne_env = std::getenv("KLNMF_NE");          // 0: never, 1: in every loop on fp8 tiles (tests), unset: by the data's mean (below)
+    const char *g = std::getenv("KLNMF_QTILE");
+    if (g) {
+        c->q8_loop = std::atoi(g) == 8;
+        c->ne_loop = c->q8_loop && c->ne_ok && ne_env && std::atoi(ne_env) == 1;
         return;
     }
     double sum_x = sum_x_global, cells = cells_global, nnz = nnz_global;
@@ -2082,18 +2367,28 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     if (nnz < 0) nnz = cells;                 // (a caller that all-reduced only the two sums: dense data assumed)
     const double mean = sum_x / c->v_scale / cells;
     c->q8_loop = c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean;
-    if (c->sw.q8_rules_r4) {
-        // round 4's data rules (kept for A/B runs against the monitor): fewer than four components or less than one column tile
-        // of data (dead zones of the e4m3 step around ratio 1), fewer stored entries per column than half the row threshold
-        if (c->k < 4 || c->f < 32) c->q8_loop = false;
-        if (nnz / (double)c->f < 0.5 * (c->big ? 65536.0 : 32768.0)) c->q8_loop = false;
-    }
+    // The tiles' 3-bit significands are averaged away by the H numerator's sum over the rows -- over the rows that HOLD
+    // something: a zero entry's ratio is 0 whatever the tile format.  Round 4's data fuzz (70 000 x 96, 95 % zeros, k = 40):
+    // 3 500 entries per column, final KL 2e-4 off the oracle's after 100 iterations on fp8 tiles, 1e-7 on 16-bit tiles.  The
+    // row threshold of klnmf_set_problem (32 769 / 65 536 rows) is therefore applied to the stored entries per column as
+    // well, with a factor 2 of slack (dense data with a few zeros must not flip at the threshold).
+    // ... and by the ratios' own spread: e4m3 has a step of 6-12 % around 1, and a fit whose ratios all sit inside one step of 1
+    // (few components on nearly noise-free low-rank data) loses exactly the deviations the H rule lives on -- a dead zone, not
+    // noise that averages out.  Round 4's shape fuzz: 33 118 x 424 with k = 1 / 2 ends 1.2e-3 / 6e-5 (40 000 x 64, k = 2: 5e-4)
+    // off the oracle's KL on fp8 tiles, 6e-6 on 16-bit tiles; k = 3: 3e-6, k = 5: 1e-5 (CPU emulation of the rounding alone
+    // reproduces the figures: experiments/README.md).  Fewer than four components keep the 16-bit tiles.
+    // The same dead zone opens when a handful of columns is fitted almost exactly (103 431 x 8, k = 4: 2.7e-4 off; 41 388 x 3,
+    // k = 10: the loss itself goes to 0): less than one column tile of data keeps the 16-bit tiles too (nothing to gain there).
+    if ((c->k < 4 || c->f < 32) && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0)) c->q8_loop = false;
+    const double per_col = nnz / (double)c->f;
+    if (per_col < 0.5 * (c->big ? 65536.0 : 32768.0) && !(std::getenv("KLNMF_Q8_SPARSE_OK") && std::atoi(std::getenv("KLNMF_Q8_SPARSE_OK")) != 0))
+        c->q8_loop = false;
     // The ratio without the numerator's eps (NE kernels, k <= 224): x / (W.H + eps) differs from the reference's
-    // (x + eps) / (W.H + eps) by a relative eps / x per element.  Simulated in fp64 over 50 iterations (DESIGN_APPENDIX.md, h33)
+    // (x + eps) / (W.H + eps) by a relative eps / x per element.  Simulated in fp64 over 50 iterations
     // the loss record moves by 0.06 .. 0.15 x eps / mean(V) and the factors by 0.5 .. 2.3 x eps / mean(V) of their maxima:
     // taken where eps / mean(V) <= 1e-5, i.e. 1.5e-6 and 2.5e-5 -- below the fp8 tiles' own floor (h29).
     c->ne_loop = c->q8_loop && c->ne_ok && mean >= 1.0e5 * kEpsRatio;
-    if (c->sw.ne >= 0) c->ne_loop = c->q8_loop && c->ne_ok && c->sw.ne == 1;
+    if (ne_env) c->ne_loop = c->q8_loop && c->ne_ok && std::atoi(ne_env) == 1;
 }
 
 // ---- a loop on this context's RCCL communicator (klnmf_comm_init): entry and iteration, shared by klnmf_run_sharded (the
@@ -2101,7 +2396,11 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
 // KLNMF_COMM_SINGLE=1 (tests): a ONE-rank communicator takes the collective path too -- the same agreement block, grouped
 // all-reduces (in place, on the loop's own buffers, counts and types) and decision kernel that N ranks execute; RCCL refuses
 // two ranks on one device, so this is the only way a one-GPU box ever runs these lines.
-static bool comm_multi(const klnmf_ctx *c) { return c->comm != nullptr && (c->comm_size > 1 || DevSwitches::read().comm_single); }
+static bool comm_single_collectives() {
+    const char *g = std::getenv("KLNMF_COMM_SINGLE");
+    return g && std::atoi(g) != 0;
+}
+static bool comm_multi(const klnmf_ctx *c) { return c->comm != nullptr && (c->comm_size > 1 || comm_single_collectives()); }
 
 // Loop entry.  Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
 // (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8 decision
@@ -2113,14 +2412,11 @@ static void comm_loop_entry(klnmf_ctx *c) {
     DevState ds{};
     HIPCHK(hipMemcpyAsync(&ds, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    // (h[2]: a rank whose shard is too short for fp8 ratio tiles -- shards differ by a row tile and the last takes the remainder, so
-    // they can straddle the row threshold -- keeps EVERY rank on 16-bit tiles: the numerators of the two formats differ by sqrt(2))
-    double h[6] = {(double)(mine.v_overflow != 0), (double)(mine.op_range != 0), c->q8_ok ? 0.0 : 1.0,
-                   ds.sum_x, (double)c->n * (double)c->f, ds.nnz_x};
+    double h[5] = {(double)(mine.v_overflow != 0), (double)(mine.op_range != 0), ds.sum_x, (double)c->n * (double)c->f, ds.nnz_x};
     HIPCHK(hipMemcpyAsync(c->comm_scratch, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
     RCCLCHK(rccl().GroupStart());
-    ncclResult_t r1 = rccl().AllReduce(c->comm_scratch, c->comm_scratch, 3, ncclDouble, ncclMax, c->comm, c->stream);
-    ncclResult_t r2 = rccl().AllReduce(c->comm_scratch + 3, c->comm_scratch + 3, 3, ncclDouble, ncclSum, c->comm, c->stream);
+    ncclResult_t r1 = rccl().AllReduce(c->comm_scratch, c->comm_scratch, 2, ncclDouble, ncclMax, c->comm, c->stream);
+    ncclResult_t r2 = rccl().AllReduce(c->comm_scratch + 2, c->comm_scratch + 2, 3, ncclDouble, ncclSum, c->comm, c->stream);
     ncclResult_t r3 = rccl().GroupEnd();            // always closed, whatever the calls inside returned
     RCCLCHK(r1); RCCLCHK(r2); RCCLCHK(r3);
     HIPCHK(hipMemcpyAsync(h, c->comm_scratch, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -2132,14 +2428,18 @@ static void comm_loop_entry(klnmf_ctx *c) {
                        : "another rank's shard of V exceeds the maximum given to klnmf_set_v_max: the sharded loop is refused on every rank");
     }
     c->refusals_dirty = false;
-    begin_fp8_loop(c, h[3], h[4], h[5], h[2] == 0.0 ? 1 : 0);
+    begin_fp8_loop(c, h[2], h[3], h[4]);
 }
 
 // One iteration: row pass -> column pass (it does not depend on the stop decision) -> ONE grouped RCCL launch on the
 // context's stream (the k real rows of the numerator -- the 16-bit modes lay it out [KP][f_pad], rows beyond k are padding --
 // and the two doubles of the loss) -> stop rule on identical inputs -> H rule.
+static bool comm_overlap_on() {
+    const char *g = std::getenv("KLNMF_COMM_OVERLAP");
+    return !(g && std::atoi(g) == 0);
+}
 static void comm_iteration(klnmf_ctx *c, int fit, double tol_abs) {
-    if (fit && !c->is_exact()) {
+    if (fit && c->fused) {
         // Fused tail with column parts (post.hip.h).  Per part: column pass -> k_post(SUM): slabs -> this part's numerator
         // [KP][ld] (contiguous: one ncclAllReduce), fix-ups; the first part's launch also leaves the loss in loss_xchg.  The
         // all-reduce of every part but the last goes to the communicator's own stream behind an event and runs while the
@@ -2149,13 +2449,12 @@ static void comm_iteration(klnmf_ctx *c, int fit, double tol_abs) {
         // concurrently); k_post(RULE) then takes the stop decision from the exchanged loss and applies the H rule.
         const int P = c->nparts_cfg > 1 ? c->nparts_cfg : 1;
         const klnmf_ctx::PartCfg *parts = P > 1 ? c->parts : &c->whole;
-        const bool overlap = P > 1 && c->sw.comm_overlap && c->comm_stream != nullptr;
+        const bool overlap = P > 1 && comm_overlap_on() && c->comm_stream != nullptr;
         piece_rowpass(c, fit, nullptr, true);
         const LossArgs la = c->pending_loss;
         c->pending_loss.part = nullptr;
         const bool use8 = fused_w8_stage(c);
         if (use8) c->stat_col8 += 1;
-        launch_monitor(c, use8);
         for (int p = 0; p < P; ++p) {
             fused_colpass_part(c, parts[p], use8);
             launch_post(c, POST_SUM, &parts[p], 1, p == 0 ? la : kNoLoss, false, use8, p == P - 1);
@@ -2227,15 +2526,11 @@ int klnmf_loop_begin_sharded(klnmf_ctx *c, double sum_x_all, double cells_all) {
 }
 
 int klnmf_loop_begin_sharded_nnz(klnmf_ctx *c, double sum_x_all, double cells_all, double nnz_all) {
-    return klnmf_loop_begin_agreed(c, sum_x_all, cells_all, nnz_all, -1);
-}
-
-int klnmf_loop_begin_agreed(klnmf_ctx *c, double sum_x_all, double cells_all, double nnz_all, int fp8_shape_all) {
     return guarded([&] {
         need_problem(c);
         if (!(sum_x_all >= 0) || !(cells_all > 0)) fail(KLNMF_ERR_ARG, "klnmf_loop_begin_sharded: the all-reduced sums must be given");
         check_v_overflow(c);
-        begin_fp8_loop(c, sum_x_all * c->v_scale, cells_all, nnz_all, fp8_shape_all);      // (the caller's sums are in the data's own units)
+        begin_fp8_loop(c, sum_x_all * c->v_scale, cells_all, nnz_all);      // (the caller's sums are in the data's own units)
         reset_state(c);
         c->loop_start_cur = c->cur;
         c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;
@@ -2257,7 +2552,9 @@ int klnmf_run_more(klnmf_ctx *c, int64_t iters, int fit, double tol_abs) {
             }
             return;
         }
+        const bool fused = !c->is_exact();
         for (int64_t it = 0; it < iters; ++it) {
+            (void)fused;
             piece_rowpass(c, fit, &tol_abs);      // (every mode: the stop rule rides in the loss reduction's launch)
             if (fit) piece_fit_tail(c);
             c->cur ^= 1;
@@ -2300,7 +2597,7 @@ int klnmf_exchange_parts(klnmf_ctx *c, int *nparts, int64_t *offsets, int64_t *c
     return guarded([&] {
         need_problem(c);
         if (!nparts || !offsets || !counts) fail(KLNMF_ERR_ARG, "klnmf_exchange_parts: null pointer");
-        const bool split = !c->is_exact() && c->nparts_cfg > 1;
+        const bool split = !c->is_exact() && c->fused && c->nparts_cfg > 1;
         *nparts = split ? c->nparts_cfg : 1;
         for (int p = 0; p < *nparts; ++p) {
             if (split) {
@@ -2361,7 +2658,9 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         // bf16 modes: the stop rule inside the loss kernel -- one launch fewer per iteration (a small problem's
         // iteration IS its kernel latencies: 7 launches of 4-10 us each).  Summing the column pass's slabs inside the
         // H rule as well (from_slabs) was measured and is NOT used: its k blocks walk the slabs serially, 47 -> 68 us.
+        const bool fused = !c->is_exact();
         auto one_iteration = [&] {
+            (void)fused;
             piece_rowpass(c, fit, &tol_abs);      // (every mode: the stop rule rides in the loss reduction's launch)
             if (fit) piece_fit_tail(c);
             c->cur ^= 1;
@@ -2379,10 +2678,11 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         // and replayed.  The first two iterations run eagerly (they may carry the measured image scales of W0 and the
         // re-pack that follows them).  KLNMF_GRAPH=0 turns it off, =1 forces it for any size.
         int64_t it = 0;
+        const char *genv = std::getenv("KLNMF_GRAPH");
         // Measured (scripts/small_problem_timing.py, 200 x 450 .. 10 000 x 4096): 29.5 us per iteration replayed against
         // 28.3 eager -- the iteration is the kernels' own few microseconds and their dependent boundaries, which a graph
         // keeps (MI355X_MICROARCH.md: "dependent kernel boundary ... eager = hipGraph"), not host launch cost.  Off unless asked for.
-        const bool want_graph = c->stream != nullptr && !c->profiling && max_iter >= 12 && c->sw.graph != 0;
+        const bool want_graph = c->stream != nullptr && !c->profiling && max_iter >= 12 && genv && std::atoi(genv) != 0;
         if (want_graph) {
             for (; it < 2; ++it) one_iteration();
             hipGraph_t graph = nullptr;
@@ -2527,7 +2827,7 @@ int klnmf_exchange_buffers(klnmf_ctx *c, void **loss_ptr, void **numer_ptr, int6
         } else {
             if (numer_ptr) *numer_ptr = c->numerF;
             int64_t cnt = (int64_t)c->KP * c->f_pad;        // (the split layout of klnmf_exchange_parts may be longer: whole column blocks)
-            if (c->nparts_cfg > 1)
+            if (c->fused && c->nparts_cfg > 1)
                 cnt = std::max(cnt, c->parts[c->nparts_cfg - 1].numer_off + (int64_t)c->KP * c->parts[c->nparts_cfg - 1].ld);
             if (numer_count) *numer_count = cnt;
             if (numer_is_f64) *numer_is_f64 = 0;
@@ -2793,9 +3093,6 @@ int klnmf_query(klnmf_ctx *c, int what, int64_t *value) {
             case KLNMF_Q_RATIO_SATURATED: *value = c->stat_q8_sat; break;
             case KLNMF_Q_RATIO_UNFIXED: *value = c->stat_q8_unfixed; break;
             case KLNMF_Q_NO_NUM_EPS: *value = c->ne_loop ? 1 : 0; break;
-            case KLNMF_Q_MON_CHECKS: *value = c->stat_mon_checks; break;
-            case KLNMF_Q_MON_TRIPS: *value = c->stat_mon_trips; break;
-            case KLNMF_Q_MON_GAVE_UP: *value = c->stat_mon_gave_up ? 1 : 0; break;
             case KLNMF_Q_COMM_RANKS: {
                 int cnt = 1;
                 if (c->comm) RCCLCHK(rccl().CommCount(c->comm, &cnt));
@@ -2811,8 +3108,6 @@ int klnmf_query_f64(klnmf_ctx *c, int what, double *value) {
     return guarded([&] {
         need_problem(c);
         if (!value) fail(KLNMF_ERR_ARG, "null value");
-        if (what == KLNMF_QF_MON_STAT) { *value = c->stat_mon_max; return; }
-        if (what == KLNMF_QF_MON_THRESHOLD) { *value = (double)kMonThreshold; return; }
         if (what != KLNMF_QF_SUM_V && what != KLNMF_QF_NNZ_V) fail(KLNMF_ERR_ARG, "klnmf_query_f64: unknown item");
         if (c->is_exact()) { *value = 0.0; return; }
         DevState ds{};

@@ -1,0 +1,1202 @@
+// bf16-MFMA kernels of the KL-NMF update for gfx950 (CDNA4).
+//
+// One fit iteration = a row pass over V and a column pass for the H rule.  This file
+// holds the generation-1 row pass, the recomputing column pass and the first column pass on stored ratios;
+// the product kernels of the bf16 mode are the ping-pong row pass (mfma4.hip.h), which also stores the
+// ratio tiles, and the pipelined column pass that streams them (colq.hip.h).
+//
+//   k_rowpass  a wave owns 32 sample rows (its W block stays in registers as the
+//              MFMA B operand) and streams the dictionary through LDS, 64 feature
+//              columns per stage.  Per 32x32 tile: (W.H)^T by MFMA -> ratio
+//              Q=(V+eps)/(WH+eps) and the loss terms in the accumulator registers
+//              -> Q (bf16, still in registers, "accumulator as next operand") is
+//              the B operand of the second MFMA chain G^T += H_tile . Q^T.  After
+//              the last stage W_new = W * G.        nmf.py:325-343, 297-310
+//   k_colpass  the mirror image: a wave owns 32 feature columns (its H block in
+//              registers) and streams W_old / W_new row tiles through LDS;
+//              recomputes Q from W_old (quirk q2: OLD Q, NEW W) and accumulates
+//              W_new^T . Q for its columns over a chunk of rows -> one fp32 slab
+//              per row chunk (deterministic two-stage reduction).   nmf.py:349
+//
+// V storage: 16-bit modes keep V as fp16 of c*V, c a power of two chosen from
+// max(V) (klnmf_set_v_max) so that c*max(V) is in [2^14, 2^15): same bytes as
+// bf16 but 3 more significand bits (the loss is evaluated on V as stored, see
+// DESIGN.md "loss with rounded V").  The whole problem then runs in scaled units
+// (W' = cW, eps' = c*eps; H and Q are scale-free) and W / the loss are divided
+// by c on the way out -- exact, c is a power of two.
+//
+// With these two kernels neither W.H nor Q goes to HBM and V is stored twice, pre-tiled so that each
+// lane's 16 elements of a 32x32 tile are contiguous in exactly the MFMA
+// accumulator order of the pass that reads it (layout A: sample on the lane,
+// layout B: feature on the lane) -> every V access is a fully coalesced
+// 16-byte-per-lane stream (row pass: global_load_lds into a wave-private LDS
+// slot one stage ahead; column pass: straight to registers).
+//
+// MFMA: v_mfma_f32_32x32x16_f16.  Operand maps (guide section 3):
+//   A[row = l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col = l&31], j = 0..7
+//   D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg = 0..15
+#pragma once
+#include "common.hip.h"
+
+namespace klnmf {
+
+// MFMA operand element of the 16-bit modes: IEEE half (11 significant bits) with power-of-two scaling of the images
+// and saturating conversion (MODE.FP16_OVFL), not bf16 (8 bits): same matrix rate (v_mfma_f32_32x32x16_f16), 8x smaller
+// operand rounding.  Scaling (exact, powers of two): per component a a factor t_a;  W image = half(W32 * t_a),
+// H image = half(H / t_a)  -- the product of the two scales is 1 for every component, so W.H, the ratio, the loss terms
+// and every rule are unscaled; only the two places that turn an accumulator back into a master apply a per-component
+// factor (the W rule: G * t_a; the H rule: its factor is constant along a dictionary row and cancels in the row
+// normalisation).  Which t_a:
+//   * from the second update of a loop on,  t_a = hs_a * 2^-13  with hs_a the power of two >= rowsum(H_a) (1 for a
+//     row-normalised dictionary): H image entries <= 2^13, and after any W rule sum_a W_ia rowsum(H_a) = rowsum(V_i)
+//     (nmf.py:342 with the ratio of the same W), so W32_ia hs_a <= 2 rowsum(c V_i) <= f 2^16: W image <= 8 f;
+//     (V, hence W32, in the storage factor's units: max(c V) in [2^14, 2^15) in BOTH 16-bit modes, whatever V is stored as);
+//   * a W that did not come out of a W rule (W0 = V.H0^T of an unnormalised H0, klnmf_set_W) obeys no such bound: its
+//     images use MEASURED, balanced scales -- t_a = the power of two nearest sqrt(max_j H_aj / max_i W32_ia), so that both
+//     images of component a peak at the same magnitude sqrt(max W max H) -- for the one update they live (k_colmax_W).
+#ifdef KL_OPND_BF16        // experiment builds only (scripts/build_variant.sh): the round-1 operand type, for A/B timing
+typedef __bf16 opnd_t;
+#define KL_MFMA_BUILTIN __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define KL_MFMA_ASM "v_mfma_f32_32x32x16_bf16"
+#else
+typedef _Float16 opnd_t;
+#define KL_MFMA_BUILTIN __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define KL_MFMA_ASM "v_mfma_f32_32x32x16_f16"
+#endif
+typedef __attribute__((ext_vector_type(8))) opnd_t opx8;
+typedef __attribute__((ext_vector_type(4))) opnd_t opx4;
+constexpr float kOpScaleH = 8192.f;              // 2^13
+constexpr float kOpScaleW = 1.f / 8192.f;
+constexpr float kCarrierW = 1.f / 1024.f;
+#ifndef KL_Q8_MID
+#define KL_Q8_MID 1
+#endif
+// KL_Q8_MID: the tiles hold ratio x kQ8Mid / 8 with kQ8Mid = sqrt(2): ratio 1 sits in the middle of an e4m3 binade, where the quantiser is
+// uniform, instead of on the boundary 2^-3, where it steps by 6 % below and 12 % above and biases every accurately fitted column
+// (experiments/fp8_tiles_mid_binade_emulation.py).  The conversion instruction uses only the exponent of its scale operand
+// (experiments/micro/scale_probe.hip), hence a packed multiply in front of it.  The H numerator then comes out sqrt(2) larger as a
+// whole (the row normalisation removes it); the exact fix-ups work in the same units.
+constexpr float kQ8Mid = KL_Q8_MID ? 1.41421356f : 1.f;
+constexpr float kQ8Scale = 8.f;                 // fp8 ratio tiles hold ratio / 8: e4m3 then covers 2^-6 .. 3584 (saturating), full precision from 0.125 on        // eps carrier: W image column kc holds 2^-10, H image row kc eps * 2^10
+// f32 -> f16 conversions that overflow give the largest finite half instead of infinity (MODE bit 23, FP16_OVFL; true
+// infinities stay): a ratio beyond 65504 (x > 0 where W.H ~ 0) or an operand beyond the image range then perturbs one
+// update instead of poisoning the factors with inf - inf.  Set once per kernel (the mode is per wave).
+#define KL_FP16_SATURATE() asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define KL_LDS __attribute__((address_space(3)))
+#define KL_GLB __attribute__((address_space(1)))
+
+constexpr int kWavesPerWG = 8;
+constexpr int kThreads = 64 * kWavesPerWG;       // 512
+constexpr int kStageCols = 64;                   // feature columns per LDS stage (row pass)
+constexpr int kHRow = kStageCols + 8;            // padded image row: 144 B = 36 dwords (4 x odd:
+constexpr int kHRowB = kHRow * 2;                //   16 rows read with ds_read_b128 hit 16 distinct bank quads)
+// Dictionary stage image [component][64 columns]: inside every group of 16 columns the
+// four 4-column blocks are stored in the order 0,2,1,3, so that the MFMA-2 A fragment of
+// lane half h (logical columns 4h..4h+3 and 8+4h..8+4h+3 of the group) is 16 contiguous
+// bytes -> one ds_read_b128.  (Two 8-byte reads get fused into ds_read2_b64, which costs
+// 2-4x the LDS cycles per byte and saturated the LDS array: profiles/r01_*.)  The MFMA-1
+// transposed reads address 4-column blocks individually, so they just follow the permutation.
+__host__ __device__ constexpr int h_col_perm(int c) {           // logical column (0..63) -> physical
+    return (c & ~15) | ((((c >> 2) & 1) << 1 | ((c >> 3) & 1)) << 2) | (c & 3);
+}
+// element offset of (component a, column c) inside a 32-column tile image of the ping-pong row pass (mfma4.hip.h)
+__host__ __device__ constexpr int h4_elem_rt(int a, int c) {
+    return a * 32 + ((((h_col_perm(c) >> 3) ^ ((a >> 2) & 3)) << 3) | (h_col_perm(c) & 7));
+}
+constexpr int kStageRowTiles = 2;                // 32-row tiles per LDS stage (column pass)
+constexpr int kGldsRound = kThreads * 16;        // bytes one global_load_lds round moves (8 KiB)
+
+__host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// bf16 W image [sample row][component]: row stride KP elements, +32 when KP/32 is even, so that the stride
+// is 16 or 48 dwords (mod 64 banks): the 4 consecutive rows x 64 B of a transposed read (column pass,
+// MFMA-3) then cover all 64 banks once.  The 16 rows of a ds_read_b128 lane group (MFMA-1') would collide
+// 4-way on such a stride, so the 16-byte chunk c of row i is stored at chunk c ^ ((i>>2)&3) -- the same
+// swizzle as the dictionary tile images of mfma4.hip.h.  (Padded 464-byte rows were conflict-free for the
+// row reads only: PMC showed a third of the column pass's LDS cycles as bank conflicts.)
+__host__ __device__ constexpr int w_ld(int kp) { return kp + ((kp / 32) % 2 == 0 ? 32 : 0); }
+// element offset of component `comp` inside row `row` (row stride not included)
+__host__ __device__ constexpr int wb_col(int row, int comp) {
+    return ((((comp >> 3) ^ ((row >> 2) & 3)) << 3) | (comp & 7));
+}
+__host__ __device__ constexpr int h_stage_bytes(int kp) { return kp * kHRowB; }
+__host__ __device__ constexpr int h_stage_lds(int kp) { return round_up(h_stage_bytes(kp), kGldsRound); }
+__host__ __device__ constexpr int w_stage_bytes(int kp) { return kStageRowTiles * 32 * w_ld(kp) * 2; }
+__host__ __device__ constexpr int w_stage_lds(int kp) { return round_up(w_stage_bytes(kp), kGldsRound); }
+
+enum RowMode { ROW_UPDATE = 0, ROW_INIT = 1, ROW_LOSS = 2 };
+
+// The two waves that share a SIMD (wave w and w+4 of the 8-wave workgroup) run the same
+// barrier-synchronised program; with equal priority they alternate on the matrix pipe, so each
+// MFMA phase takes twice its pipe time and the VALU-heavy epilogues collide as well (in-kernel
+// stamps: MFMA-1 827 cycles for 416 of pipe work).  A static priority for waves 4-7 lets their
+// phase run first and the partner fill the gaps: the pair drifts half a phase apart.
+// s_setprio ignores EXEC, so the condition must be provably wave-uniform (readfirstlane).
+// depth of the LDS operand-fragment ring of the row pass (reads run KL_RING-1 MFMAs ahead)
+#ifndef KL_RING
+#define KL_RING 3
+#endif
+#ifndef KL_SKEW
+#define KL_SKEW 0
+#endif
+#ifndef KL_PRIO
+#define KL_PRIO 1
+#endif
+#define KL_WAVE_PRIORITY()                                                                  \
+    do {                                                                                    \
+        if (KL_PRIO > 0 && __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256)         \
+            __builtin_amdgcn_s_setprio(KL_PRIO);                                            \
+    } while (0)
+
+// ---- small device helpers ---------------------------------------------------
+__device__ __forceinline__ opx8 tr_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+    // two ds_read_b64_tr_b16: each gives this lane one column of a 4-row x 16-col block
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p1);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(opx8, v);
+}
+__device__ __forceinline__ opx8 b64_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+    s16x4 lo = *(const KL_LDS s16x4 *)p0;
+    s16x4 hi = *(const KL_LDS s16x4 *)p1;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(opx8, v);
+}
+__device__ __forceinline__ opx8 pack8(const float *q) {
+    opx8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (opnd_t)q[j];
+    return r;
+}
+
+// 16 V elements of this lane for one 32x32 tile, as fp32.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct VRegsF16 { f16x8 a, b; };
+struct VRegsF32 { f32x4 a, b, c, d; };
+template <typename VT> struct VTraits;
+template <> struct VTraits<_Float16> {
+    typedef VRegsF16 Regs;
+    static constexpr int kLaneBytes = 32;
+    // global tile = [16-byte piece p][lane][16 B] (k_tile_V): every load instruction of a wave moves 1 KiB of CONTIGUOUS
+    // memory = 8 whole cache lines (lane-major tiles -- [lane][32 B] -- made each of the two instructions touch all 16 lines
+    // of the tile and use half of each)
+    static __device__ __forceinline__ Regs load(const void *tile, int lane) {
+        const unsigned char *p = (const unsigned char *)tile + lane * 16;
+        Regs r; r.a = *(const f16x8 *)p; r.b = *(const f16x8 *)(p + 1024); return r;
+    }
+    // tile image in LDS as written by stage_v_tile(): two 1 KiB halves, lane-linear
+    static __device__ __forceinline__ Regs load_lds(const KL_LDS unsigned char *tile, int lane) {
+        Regs r;
+        r.a = *(const KL_LDS f16x8 *)(tile + lane * 16);
+        r.b = *(const KL_LDS f16x8 *)(tile + 1024 + lane * 16);
+        return r;
+    }
+    static __device__ __forceinline__ void unpack(const Regs &r, float *x) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { x[i] = (float)r.a[i]; x[8 + i] = (float)r.b[i]; }
+    }
+};
+template <> struct VTraits<float> {
+    typedef VRegsF32 Regs;
+    static constexpr int kLaneBytes = 64;
+    static __device__ __forceinline__ Regs load(const void *tile, int lane) {
+        const unsigned char *p = (const unsigned char *)tile + lane * 16;
+        Regs r; r.a = *(const f32x4 *)p; r.b = *(const f32x4 *)(p + 1024); r.c = *(const f32x4 *)(p + 2048); r.d = *(const f32x4 *)(p + 3072);
+        return r;
+    }
+    static __device__ __forceinline__ Regs load_lds(const KL_LDS unsigned char *tile, int lane) {
+        Regs r;
+        r.a = *(const KL_LDS f32x4 *)(tile + lane * 16);
+        r.b = *(const KL_LDS f32x4 *)(tile + 1024 + lane * 16);
+        r.c = *(const KL_LDS f32x4 *)(tile + 2048 + lane * 16);
+        r.d = *(const KL_LDS f32x4 *)(tile + 3072 + lane * 16);
+        return r;
+    }
+    static __device__ __forceinline__ void unpack(const Regs &r, float *x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = r.a[i]; x[4 + i] = r.b[i]; x[8 + i] = r.c[i]; x[12 + i] = r.d[i]; }
+    }
+};
+
+// Copy `rounds` x 8 KiB from global to LDS with global_load_lds_dwordx4 (LDS
+// image == global image; destination is wave-uniform base + lane*16).
+__device__ __forceinline__ void glds_copy(const unsigned char *gsrc, KL_LDS unsigned char *ldst,
+                                          int rounds, int tid) {
+    const int wave_base = (tid & ~63) * 16;
+    for (int r = 0; r < rounds; ++r) {
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kGldsRound + tid * 16),
+                                         (KL_LDS void *)(ldst + r * kGldsRound + wave_base), 16, 0, 0);
+    }
+}
+
+// One wave-private V tile (kLaneBytes / 16 pieces of 1 KiB, each lane-linear) -> LDS.
+template <int LANE_BYTES>
+__device__ __forceinline__ void stage_v_tile(const unsigned char *gtile, KL_LDS unsigned char *ldst, int lane) {
+#pragma unroll
+    for (int p = 0; p < LANE_BYTES / 16; ++p)
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gtile + 1024 * p + lane * 16),      // (the LDS image IS the global one)
+                                         (KL_LDS void *)(ldst + 1024 * p), 16, 0, 0);
+}
+
+#ifdef KL_STAMPS
+#define KL_STAMP(var)                                                                   \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define KL_STAMP(var) do { } while (0)
+#endif
+
+struct RowPassArgs {
+    const void *VtA;          // [nrt][nct] tiles of 16 values per lane (layout A), stored piece-major: [16-byte piece][64 lanes][16 B]
+    const opnd_t *Ht;         // [nst][KP][kHRow] dictionary stage images
+    const opnd_t *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
+    const float *W32_old;     // [n_pad][KP]
+    opnd_t *Wb_new;
+    float *W32_new;
+    double2 *loss_part;       // [nrt] (sum x*log2 q, sum y)
+    const double *hsum;       // [KP] row sums of the 16-bit dictionary image (for sum(W.H)), see row_sum_wh
+    unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
+    unsigned char *Qt;            // ratio tiles for k_colpass_q ([nct][nrt][2 KiB], see there), or null (ping-pong pass only)
+    const float *tcur;            // [KP] per-component scale t_a of the CURRENT images (W image = W32 * t, H image = H / t; see opnd_t)
+    const float *tnext;           // [KP] scale the W rule packs the NEW W image with (the next dictionary image's)
+    int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
+    const DevState *st;
+    int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
+    float eps;                // c * 1e-8 (scaled units)
+    int cq_on;                // the dictionary image carries the ratio scale 2^st->cq_e (k_ratio_scale): the denominator's eps is scaled with it
+    // Column-split update pass of the ping-pong kernel (few rows: one workgroup per 256 rows would leave the chip idle):
+    // blockIdx.y = column chunk of ct_chunk tiles; the workgroup leaves its part of Q.H^T in gpart[chunk][row][KP] and
+    // its loss terms in loss_part[chunk * nrt + rt]; k_wrule_slabs sums the chunks and applies the W rule.  null: whole rows.
+    // A launch may cover only the workgroups from wg0 on (hybrid update pass: the full rounds of workgroups run whole
+    // rows, the last partial round runs column-split so that it fills the chip: klnmf_api.hip, fast_rowpass); the split
+    // launch then addresses gpart and the chunks' extra loss parts relative to its first row tile rt0 = 8 * wg0:
+    // gpart[chunk][rt - rt0 ...], loss_part[nrt + (chunk - 1) * (nrt - rt0) + rt - rt0] for chunk >= 1.
+    float *gpart;
+    int ct_chunk;
+    int wg0, rt0;
+    // row tiles per workgroup of the ping-pong pass (0 = its wave count).  One round of workgroups that leaves CUs idle
+    // (50 000 rows = 196 workgroups of 8 row tiles on 256 CUs) is spread over more of them with 7, 6, ... row tiles per
+    // workgroup, the workgroup's last waves idling: such problems are HBM-bound per CU (klnmf_api.hip, fast_rowpass)
+    int rpw;
+    // fp8 x fp8 column pass (colq8x.hip.h): the W rule also leaves the e4m3 image of W_new (f16 image / w8s[component],
+    // exactly as k_w8_from_wb converts it) and this wave's column maxima of the f16 image; null: not written
+    unsigned char *W8;
+    const float *w8s;         // [KP]
+    unsigned *w8max;          // [nrt][KP] float bit patterns
+    unsigned *w8tab;          // != nullptr: the maxima go by atomicMax into row (rt & 63) of this [64][KP] table instead (post.hip.h)
+    int *w8_sat;              // entries of this image beyond e4m3's 448 (stored as 448) are counted here, as k_w8_from_wb does
+    int w8_probe;             // the image's probe column (colq8x.hip.h; e4m3 1.0 in every row): KP - 1 or -1 (none)
+};
+
+// LDS per stage buffer: [dictionary image | V tiles of the 8 waves (16-bit V only)]
+template <typename VT> __host__ __device__ constexpr int row_v_area() {
+    return sizeof(VT) == 2 ? kWavesPerWG * 2 * 64 * 32 : 0;
+}
+template <typename VT> __host__ __device__ constexpr int row_lds_bytes(int kp) {
+    return 2 * (h_stage_lds(kp) + row_v_area<VT>());
+}
+
+// KS = 2*KT - ODD MFMA k-steps cover ceil(k/16) blocks of 16 components.
+template <int KT, int ODD, int MODE, typename VT>
+__global__ __launch_bounds__(kThreads, 2) void k_rowpass(RowPassArgs a) {
+    constexpr int KP = 32 * KT;
+    constexpr int KS = 2 * KT - ODD;
+    constexpr int STG = h_stage_lds(KP);
+    constexpr int ROUNDS = STG / kGldsRound;
+    constexpr int WLD = w_ld(KP);
+    typedef VTraits<VT> VTr;
+    constexpr bool VIA_LDS = sizeof(VT) == 2;
+    constexpr int TB = 64 * VTr::kLaneBytes;            // bytes of one V tile
+    constexpr int BUF = STG + row_v_area<VT>();         // one stage buffer
+    // Two DISTINCT LDS objects, one per stage buffer: hipcc can then prove that the
+    // ds_reads of the current stage do not alias the global_load_lds writes of the
+    // next one and does not drain vmcnt before every read (one dynamic array would).
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[BUF];
+    if (a.st->stop) return;
+    KL_WAVE_PRIORITY();
+    KL_FP16_SATURATE();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rt_raw = blockIdx.x * kWavesPerWG + wave;
+    const bool active = rt_raw < a.nrt;                   // wave-uniform
+    const int rt = active ? rt_raw : a.nrt - 1;           // idle waves redo the last tile, store nothing
+
+    // per-lane LDS offsets (bytes) inside a stage image [KP][kHRow]
+    //  tr read (MFMA1 A operand): rows = components; this lane addresses row q, cols 4p..4p+3 of its 16-lane group's block
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    const int off_tr = (8 * h + tq) * kHRowB + h_col_perm(16 * half + 4 * tp) * 2;
+    //  row read (MFMA2 A operand): row = component r, 16 contiguous bytes of its 16-column group
+    const int off_row = r * kHRowB + 16 * h;
+
+    opx8 wf[KS];
+    if (MODE != ROW_INIT) {
+        const opnd_t *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(wrow + wb_col(r, 16 * s + 8 * h));
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    float s1 = 0.f;
+    const float eps = a.eps;                                            // numerator: (x + eps)
+    const float eps_d = a.cq_on ? ldexpf(a.eps, a.st->cq_e) : a.eps;     // denominator: W.H of a ratio-scaled image + 2^cq_e eps
+
+    const unsigned char *ht = (const unsigned char *)a.Ht;
+    const unsigned char *vt = (const unsigned char *)a.VtA + (int64_t)rt * a.nct * TB;
+    const int voff = STG + wave * 2 * TB;                 // this wave's V tiles inside a buffer
+    typename VTr::Regs vreg[2];
+#ifdef KL_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk0; KL_STAMP(tk0);
+#endif
+
+    // issue the copies of stage `st` into `buf`
+    auto stage_in = [&](KL_LDS unsigned char *buf, int st) {
+#ifdef KL_ABL_NOHDMA      // ablation build: dictionary images copied for the first stages only (timing only)
+        if (st < 2)
+#endif
+        glds_copy(ht + (int64_t)st * h_stage_bytes(KP), buf, ROUNDS, tid);
+        const unsigned char *vn = vt + (int64_t)(2 * st) * TB;
+#ifdef KL_ABL_NOVDMA
+        if (st < 2)
+#endif
+        if (VIA_LDS) {
+            stage_v_tile<VTr::kLaneBytes>(vn, buf + voff, lane);
+            stage_v_tile<VTr::kLaneBytes>(vn + TB, buf + voff + TB, lane);
+        }
+    };
+    // the two 32x32 tiles of the stage resident in `img`
+    auto compute = [&](const KL_LDS unsigned char *img) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // The tile consumes a fixed sequence of LDS operand fragments: KS for
+            // MFMA1 (transposed reads), then 2*KT for MFMA2 (row reads).  Reads run
+            // two MFMAs ahead of their consumer through a 3-slot register ring.
+            const KL_LDS unsigned char *p1 = img + off_tr + (32 * u) * 2;
+            const KL_LDS unsigned char *p2 = img + off_row + (32 * u) * 2;
+            constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
+            constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
+            opx8 ring[KL_RING];
+            auto fetch = [&](int idx) {                    // idx is a compile-time constant after unrolling
+#ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
+                if (idx < N1 + N2) { ring[idx % KL_RING] = wf[idx % KS]; asm volatile("" : "+v"(ring[idx % KL_RING])); }
+                return;
+#endif
+                if (idx < N1) {
+                    ring[idx % KL_RING] = tr_pair(p1 + (16 * idx) * kHRowB, p1 + (16 * idx + 4) * kHRowB);
+                } else if (idx < N1 + N2) {
+                    const int j = idx - N1, m = j >> 1, hh = j & 1;
+                    ring[idx % KL_RING] = *(const KL_LDS opx8 *)(p2 + (32 * m) * kHRowB + 32 * hh);
+                }
+            };
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+            KL_STAMP(t0);
+#pragma unroll
+            for (int i = 0; i < KL_RING - 1; ++i) fetch(i);
+            float x[16], q[16];
+            if (VIA_LDS) {
+                const typename VTr::Regs vr = VTr::load_lds(img + voff + u * TB, lane);
+                VTr::unpack(vr, x);
+            } else {
+                VTr::unpack(vreg[u], x);
+            }
+            KL_STAMP(t1);
+            if (MODE == ROW_INIT) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) q[e] = x[e];
+            } else {
+                f32x16 d;   // (starting the accumulator at eps would save an add per element but
+                            //  costs 16 live VGPRs for the splat: spills at KT=7, measured -25 %)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d[e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    fetch(s + KL_RING - 1);
+                    d = KL_MFMA_BUILTIN(ring[s % KL_RING], wf[s], d, 0, 0, 0);
+                }
+                KL_STAMP(t2);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+#ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
+                    q[e] = x[e] + d[e];
+#else
+                    const float rinv = __builtin_amdgcn_rcpf(d[e] + eps_d);
+                    const float qq = fmaf(x[e], rinv, eps * rinv);          // (x + eps) * r; same form as mfma4.hip.h
+                    q[e] = qq;
+                    s1 = fmaf(x[e], __builtin_amdgcn_logf(qq), s1);
+#endif
+                }
+            }
+            if (MODE != ROW_LOSS) {
+                const opx8 b0 = pack8(q), b1 = pack8(q + 8);
+                KL_STAMP(t3);
+#pragma unroll
+                for (int j = 0; j < N2; ++j) {
+                    fetch(N1 + j + KL_RING - 1);
+                    acc[j >> 1] = KL_MFMA_BUILTIN(ring[(N1 + j) % KL_RING], (j & 1) ? b1 : b0,
+                                                                          acc[j >> 1], 0, 0, 0);
+                }
+                KL_STAMP(t4);
+            }
+#ifdef KL_STAMPS
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+#endif
+        }
+    };
+    // one stage: start the next stage's copies into the other buffer, compute on this one
+    auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int st) {
+        typename VTr::Regs vnext[2];
+        const bool more = st + 1 < a.nst;
+        if (more) {
+            stage_in(nxt, st + 1);
+            if (!VIA_LDS) {
+                const unsigned char *vn = vt + (int64_t)(2 * st + 2) * TB;
+                vnext[0] = VTr::load(vn, lane);
+                vnext[1] = VTr::load(vn + TB, lane);
+            }
+        }
+        unsigned long long tb0 = 0, tb1 = 0, tb2 = 0;
+        KL_STAMP(tb0);
+#if KL_SKEW > 0
+        // phase skew: waves 4-7 start each stage KL_SKEW*64 cycles late so that their MFMA
+        // blocks fall into the partner wave's epilogue instead of colliding with its MFMAs
+        if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_sleep(KL_SKEW);
+#endif
+        compute(cur);
+        if (!VIA_LDS && more) { vreg[0] = vnext[0]; vreg[1] = vnext[1]; }
+        KL_STAMP(tb1);
+        __syncthreads();   // drains the copies (hipcc adds vmcnt(0)) and frees `cur` for reuse
+        KL_STAMP(tb2);
+#ifdef KL_STAMPS
+        ph[4] += tb2 - tb1; ph[5] += tb1 - tb0;
+#endif
+    };
+
+    KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
+    KL_LDS unsigned char *B = (KL_LDS unsigned char *)bufB;
+    stage_in(A, 0);
+    if (!VIA_LDS) {
+        vreg[0] = VTr::load(vt, lane);
+        vreg[1] = VTr::load(vt + TB, lane);
+    }
+    __syncthreads();
+    for (int st = 0; st < a.nst; st += 2) {
+        stage(A, B, st);
+        if (st + 1 < a.nst) stage(B, A, st + 1);
+    }
+
+#ifdef KL_STAMPS
+    {
+        unsigned long long tk1; KL_STAMP(tk1);
+        ph[6] = tk1 - tk0;
+        if (a.stamps && lane == 0 && active)
+            for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
+    }
+#endif
+    if (!active) return;
+    if (MODE != ROW_INIT) {
+        // sum_j (W.H)_ij = sum_a W_ia * rowsum(H)_a (the reference's sparse branch uses the
+        // same identity, nmf.py:303-304); with the bf16 operands the MFMA sees, so it equals
+        // the accumulated W.H up to fp32 summation order.  Lane (r,h) holds W[r][16s+8h+j].
+        double s2d = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s2d = fma((double)(float)wf[s][j], a.hsum[16 * s + 8 * h + j], s2d);
+        const double s1w = wave_sum((double)s1);
+        s2d = wave_sum(s2d);
+        if (lane == 0) a.loss_part[rt] = make_double2(s1w, s2d);
+    }
+    if (MODE != ROW_LOSS) {
+        // acc[m] reg (g,t): component 32m + 8g + 4h + t of sample row r
+        const int64_t row = (int64_t)rt * 32 + r;
+#pragma unroll
+        for (int m = 0; m < KT; ++m) {
+            f32x4 w[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                 // the 4 loads of this component tile go out together
+                const int comp = 32 * m + 8 * g + 4 * h;
+                if (MODE == ROW_UPDATE) {
+                    w[g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) w[g][t] = 1.f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int comp = 32 * m + 8 * g + 4 * h;
+                const f32x4 tc = *(const f32x4 *)(a.tcur + comp), tn = *(const f32x4 *)(a.tnext + comp);
+                opx4 wb;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    w[g][t] *= acc[m][4 * g + t] * tc[t];                   // the accumulator saw the dictionary image H / t
+                    wb[t] = (opnd_t)(w[g][t] * tn[t]);
+                }
+                *(f32x4 *)(a.W32_new + row * KP + comp) = w[g];
+                *(opx4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
+            }
+        }
+    }
+}
+
+struct ColPassArgs {
+    const void *VtB;          // [nct][nrt][64][16] tiles, layout B
+    const opnd_t *HTb;        // [f_pad][KP] transposed dictionary (this wave's B fragments)
+    const opnd_t *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
+    const opnd_t *Wb_new;
+    float *Npart;             // [nchunks][KP][f_pad]
+    const DevState *st;
+    int nrt, nct, ncb, nchunks, stages_per_chunk;   // nrt even; a stage = 2 row tiles
+    int64_t f_pad;
+    float eps;
+    int cq_on;                // see RowPassArgs
+};
+
+template <int KT, int ODD, typename VT, int EP = 0>
+__global__ __launch_bounds__(kThreads, 2) void k_colpass(ColPassArgs a) {
+    constexpr int KP = 32 * KT;
+    constexpr int KS = 2 * KT - ODD;
+    constexpr int WLD = w_ld(KP);
+    constexpr int WLDB = WLD * 2;
+    constexpr int IMG = w_stage_lds(KP);           // one image (W_old or W_new) of one stage
+    constexpr int ROUNDS = IMG / kGldsRound;
+    constexpr int RS = kStageRowTiles;
+    typedef VTraits<VT> VTr;
+    constexpr int TB = 64 * VTr::kLaneBytes;
+    // two distinct LDS objects (see k_rowpass): [W_old image | W_new image] per stage
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[2 * IMG];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[2 * IMG];
+    if (a.st->stop) return;
+    KL_WAVE_PRIORITY();
+    KL_FP16_SATURATE();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware block -> (row chunk, column block): blocks b and b+8 share an
+    // XCD; give each XCD a contiguous run of (chunk, cb) pairs so the column
+    // blocks that stream the same W rows share one L2 (speed only).
+    const int G = gridDim.x;
+    int lin = blockIdx.x;
+    if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = lin / a.ncb, cb = lin % a.ncb;
+    const int ct_raw = cb * kWavesPerWG + wave;
+    const bool active = ct_raw < a.nct;              // wave-uniform
+    const int ct = active ? ct_raw : a.nct - 1;
+    const int total_stages = a.nrt / RS;
+    const int sbeg = chunk * a.stages_per_chunk;
+    const int send = min(total_stages, sbeg + a.stages_per_chunk);
+
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    //  row read (MFMA1' A operand): W_old row r, components 16*idx + 8h..+7 = chunk 2*idx + h (swizzled, wb_col)
+    const int off_row_e = r * WLDB + 2 * wb_col(r, 8 * h);          // even k-steps (idx & 1 == 0)
+    const int off_row_o = r * WLDB + 2 * wb_col(r, 16 + 8 * h);     // odd k-steps, relative to chunk group idx>>1
+    //  tr read (MFMA3 A operand): rows = samples 4h+tq (+8 for the second read), cols = components
+    const int off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
+    const int off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
+
+    opx8 hf[KS];
+    {
+        const opnd_t *hrow = a.HTb + (int64_t)(ct * 32 + r) * KP + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) hf[s] = *(const opx8 *)(hrow + 16 * s);
+    }
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    const float eps = a.eps;                                            // numerator: (x + eps)
+    const float eps_d = a.cq_on ? ldexpf(a.eps, a.st->cq_e) : a.eps;     // denominator: W.H of a ratio-scaled image + 2^cq_e eps
+
+    const unsigned char *wo = (const unsigned char *)a.Wb_old;
+    const unsigned char *wn = (const unsigned char *)a.Wb_new;
+    const unsigned char *vt = (const unsigned char *)a.VtB + (int64_t)ct * a.nrt * TB;
+    typename VTr::Regs vcur[RS];
+
+    auto stage_in = [&](KL_LDS unsigned char *buf, int sg) {
+        const int64_t goff = (int64_t)sg * w_stage_bytes(KP);
+        glds_copy(wo + goff, buf, ROUNDS, tid);
+        glds_copy(wn + goff, buf + IMG, ROUNDS, tid);
+    };
+    auto compute = [&](const KL_LDS unsigned char *img_old, bool more, int sg) {
+        const KL_LDS unsigned char *img_new = img_old + IMG;
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+            // fragment sequence: KS row reads of W_old (MFMA1'), then 2*KT transposed
+            // reads of W_new (MFMA3); reads run two MFMAs ahead (3-slot ring)
+            const KL_LDS unsigned char *p1e = img_old + off_row_e + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p1o = img_old + off_row_o + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p30 = img_new + off_tr0 + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p31 = img_new + off_tr1 + (32 * u) * WLDB;
+            constexpr int N3 = 2 * KT;
+            opx8 ring[3];
+            auto fetch = [&](int idx) {
+                if (idx < KS) {
+                    ring[idx % 3] = *(const KL_LDS opx8 *)(((idx & 1) ? p1o : p1e) + 64 * (idx >> 1));
+                } else if (idx < KS + N3) {
+                    const int j = idx - KS, m = j >> 1, hh = j & 1;
+                    ring[idx % 3] = tr_pair(p30 + (16 * hh) * WLDB + (32 * m) * 2,
+                                            p31 + (16 * hh) * WLDB + (32 * m) * 2);
+                }
+            };
+            fetch(0);
+            fetch(1);
+            float x[16], q[16];
+            VTr::unpack(vcur[u], x);
+            // this tile's V is in x[] now: its registers take the same tile of the NEXT stage (one stage of
+            // latency to land; a separate set of "next" registers cost 16 VGPRs and pushed the kernel into scratch)
+            if (more) vcur[u] = VTr::load(vt + (int64_t)((sg + 1) * RS + u) * TB, lane);
+            f32x16 d;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                fetch(s + 2);
+                d = KL_MFMA_BUILTIN(ring[s % 3], hf[s], d, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+            {
+                // (x + eps) * r as x*r + eps*r: with fp16 V the compiler feeds x to v_fma_mix_f32 in its
+                // storage form and drops the conversion (VALU time adds to matrix time on the SIMD)
+                const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps_d);      // EP: eps is already in d (pad component)
+                q[e] = fmaf(x[e], rinv, eps * rinv);
+            }
+            const opx8 b0 = pack8(q), b1 = pack8(q + 8);
+#pragma unroll
+            for (int j = 0; j < N3; ++j) {
+                fetch(KS + j + 2);
+                acc[j >> 1] = KL_MFMA_BUILTIN(ring[(KS + j) % 3], (j & 1) ? b1 : b0,
+                                                                      acc[j >> 1], 0, 0, 0);
+            }
+        }
+    };
+    auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int sg) {
+        const bool more = sg + 1 < send;
+        if (more) stage_in(nxt, sg + 1);
+        compute(cur, more, sg);
+        __syncthreads();
+    };
+
+    KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
+    KL_LDS unsigned char *B = (KL_LDS unsigned char *)bufB;
+    if (sbeg < send) {
+        stage_in(A, sbeg);
+#pragma unroll
+        for (int u = 0; u < RS; ++u)
+            vcur[u] = VTr::load(vt + (int64_t)(sbeg * RS + u) * TB, lane);
+    }
+    __syncthreads();
+    for (int sg = sbeg; sg < send; sg += 2) {
+        stage(A, B, sg);
+        if (sg + 1 < send) stage(B, A, sg + 1);
+    }
+
+    if (!active) return;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            np[(int64_t)comp * a.f_pad] = acc[m][e];
+        }
+}
+
+// ---- column pass on stored ratios ----------------------------------------------------------------
+// The H rule needs W_new^T . Q with the ratio Q of the OLD W and H (nmf.py:347-349) -- exactly what the row
+// pass has in registers, as packed bf16 MFMA operands, when it applies the W rule.  The ping-pong row pass
+// (mfma4.hip.h) stores them (Qt, 2 B per element of V) and this kernel is then a plain streaming product:
+// no second W.H, no division, no V -- half the matrix work of k_colpass and none of its VALU work, for the
+// same bytes read (Q instead of the second copy of V, which is no longer kept) plus the row pass's writes.
+//
+// Qt layout: [column tile][row tile][2 KiB]; a tile is the row pass's two packed operands as its lanes hold
+// them: bytes [16*lane, +16) = b0 and [1024 + 16*lane, +16) = b1 of lane (row i = lane & 31, h' = lane >> 5),
+// element 4g + t of the 16 = column 8g + 4h' + t -- two fully contiguous 1 KiB stores per wave and tile.
+// The row pass needs "one row, several columns" per lane (its contraction runs over columns), this kernel
+// "one column, several rows" (contraction over rows): the transposition happens here, on the way through
+// LDS.  The global -> LDS copy (global_load_lds takes a per-lane source address) regroups the 16-byte pieces
+// so that the 32 bytes of slot 2i + h' are adjacent, and ds_read_b64_tr_b16 -- whose unit is the 8-byte
+// group of 4 consecutive columns of one row, which the layout keeps together -- delivers the transposed
+// fragments; the 32 lanes of a read's first pass touch 256 consecutive bytes (conflict-free).
+struct ColPassQArgs {
+    const unsigned char *Qt;
+    const opnd_t *Wb_new;     // [n_pad(+pad)][w_ld(KP)]
+    float *Npart;             // [nchunks][KP][f_pad]
+    const DevState *st;
+    int nrt, nct, ncb, nchunks, stages_per_chunk;
+    int64_t f_pad;
+    // fp8 iterations: guard = 1: the fp8 x fp8 pass, returns at once when this iteration's e4m3 W image saturated (st->w8_sat);
+    // guard = 2: the f16-operand pass launched behind it, runs ONLY then.  0: no guard.
+    int guard;
+    DevState *st_rw;          // saturation counters and the fix-up list's fill (fp8 ratio tiles only)
+    uint2 *q8_list;           // [kQ8ListCap] (row, feature column) of saturated ratio entries
+};
+constexpr int kQTile = 2048;                                         // bytes of one 32x32 bf16 ratio tile
+__host__ __device__ constexpr int colq_lds_stage(int kp) { return w_stage_lds(kp) + kWavesPerWG * kStageRowTiles * kQTile; }
+
+template <int KT>
+__global__ __launch_bounds__(kThreads, 1) void k_colpass_q(ColPassQArgs a) {
+    constexpr int KP = 32 * KT;
+    constexpr int WLD = w_ld(KP);
+    constexpr int WLDB = WLD * 2;
+    constexpr int IMG = w_stage_lds(KP);           // W_new image of one stage
+    constexpr int ROUNDS = IMG / kGldsRound;
+    constexpr int RS = kStageRowTiles;
+    constexpr int QW = RS * kQTile;                // one wave's ratio tiles of one stage
+    // two distinct LDS objects (the compiler then knows reads of one do not wait for copies into the other)
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[IMG + kWavesPerWG * QW];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[IMG + kWavesPerWG * QW];
+    if (a.st->stop) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;                       // XCD-aware block -> (row chunk, column block), as k_colpass
+    int lin = blockIdx.x;
+    if ((G & 7) == 0) lin = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int chunk = lin / a.ncb, cb = lin % a.ncb;
+    const int ct_raw = cb * kWavesPerWG + wave;
+    const bool active = ct_raw < a.nct;              // wave-uniform
+    const int ct = active ? ct_raw : a.nct - 1;
+    const int total_stages = a.nrt / RS;
+    const int sbeg = chunk * a.stages_per_chunk;
+    const int send = min(total_stages, sbeg + a.stages_per_chunk);
+
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, half = (lane >> 4) & 1;
+    //  W_new (A operand): rows = samples 4h+tq (+8 for the second read), cols = components
+    const int off_tr0 = (4 * h + tq) * WLDB + 2 * wb_col(4 * h + tq, 16 * half + 4 * tp);
+    const int off_tr1 = (4 * h + tq + 8) * WLDB + 2 * wb_col(4 * h + tq + 8, 16 * half + 4 * tp);
+    //  ratios (B operand): row 4h+tq (+8j), columns 16*half + 4*tp.. = slot 2*row + (tp&1), group 2*half + (tp>>1)
+    const int off_q = (2 * (4 * h + tq) + (tp & 1)) * 32 + (2 * half + (tp >> 1)) * 8 + wave * QW;
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    const unsigned char *wn = (const unsigned char *)a.Wb_new;
+    // copy piece P = 64p + lane of a tile (16 bytes at LDS offset 16P): slot P>>1, operand P&1
+    const unsigned char *qt = a.Qt + (int64_t)ct * a.nrt * kQTile + (lane & 1) * 1024 +
+                              ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+
+    auto stage_in = [&](KL_LDS unsigned char *buf, int sg) {
+        glds_copy(wn + (int64_t)sg * w_stage_bytes(KP), buf, ROUNDS, tid);
+        const unsigned char *qs = qt + (int64_t)sg * QW;           // this wave's RS tiles are consecutive
+#pragma unroll
+        for (int p = 0; p < QW / 1024; ++p)          // tile p>>1, its piece group p&1 (rows 16(p&1) .. +15)
+            __builtin_amdgcn_global_load_lds((const KL_GLB void *)(qs + (p >> 1) * kQTile + (p & 1) * 256),
+                                             (KL_LDS void *)(buf + IMG + wave * QW + 1024 * p), 16, 0, 0);
+    };
+    auto compute = [&](const KL_LDS unsigned char *img) {
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+            const KL_LDS unsigned char *p30 = img + off_tr0 + (32 * u) * WLDB;
+            const KL_LDS unsigned char *p31 = img + off_tr1 + (32 * u) * WLDB;
+            const KL_LDS unsigned char *pq = img + IMG + off_q + u * kQTile;
+            constexpr int N3 = 2 * KT;
+            opx8 ring[3];
+            auto fetch = [&](int j) {
+                if (j < N3) {
+                    const int m = j >> 1, hh = j & 1;
+                    ring[j % 3] = tr_pair(p30 + (16 * hh) * WLDB + (32 * m) * 2, p31 + (16 * hh) * WLDB + (32 * m) * 2);
+                }
+            };
+            fetch(0);
+            fetch(1);
+            // rows {4h+t, 8+4h+t} and {16+4h+t, 24+4h+t} of column r: the contraction order of the W_new reads
+            const opx8 b0 = tr_pair(pq, pq + 8 * 64), b1 = tr_pair(pq + 16 * 64, pq + 24 * 64);
+#pragma unroll
+            for (int j = 0; j < N3; ++j) {
+                fetch(j + 2);
+                acc[j >> 1] = KL_MFMA_BUILTIN(ring[j % 3], (j & 1) ? b1 : b0, acc[j >> 1], 0, 0, 0);
+            }
+        }
+    };
+    auto stage = [&](KL_LDS unsigned char *cur, KL_LDS unsigned char *nxt, int sg) {
+        if (sg + 1 < send) stage_in(nxt, sg + 1);
+        compute(cur);
+        __syncthreads();
+    };
+
+    KL_LDS unsigned char *A = (KL_LDS unsigned char *)bufA;
+    KL_LDS unsigned char *B = (KL_LDS unsigned char *)bufB;
+    if (sbeg < send) stage_in(A, sbeg);
+    __syncthreads();
+    for (int sg = sbeg; sg < send; sg += 2) {
+        stage(A, B, sg);
+        if (sg + 1 < send) stage(B, A, sg + 1);
+    }
+
+    if (!active) return;
+    // acc[m] reg (g,t): component 32m + 8g + 4h + t, feature column ct*32 + r
+    float *np = a.Npart + (int64_t)chunk * KP * a.f_pad + (int64_t)ct * 32 + r;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int comp = 32 * m + 8 * (e >> 2) + 4 * h + (e & 3);
+            np[(int64_t)comp * a.f_pad] = acc[m][e];
+        }
+}
+
+// ---- dictionary / coefficient packing ----------------------------------------
+// One block per component row.  do_update: H <- H*num then row-normalise
+// (nmf.py:349-350); always (re)writes the bf16 stage images Ht and the transposed
+// copy HTb from the fp32 master.
+//
+// Pad-component eps (kc >= 0): the ratio needs 1/(W.H + eps) for every element.  Instead of one VALU add
+// per element in both passes, the otherwise unused component kc (k <= kc < 16*KS) carries it through the
+// matrix product: row kc of the dictionary images holds eps in every column, column kc of the bf16 W
+// images holds 1 (k_pack_W, row-pass epilogue), so MFMA-1 delivers W.H + eps.  hsum[kc] stays 0 (the
+// loss term sum(W.H) must not contain it); the accumulators of component kc are never read.
+KL_GLOBAL __launch_bounds__(1024) void k_update_pack_H(float *H32, const float *num, opnd_t *Ht,
+                                                       opnd_t *Ht4, opnd_t *HTb, double *hsum, float *tcur, float *t_hs,
+                                                       const unsigned *wmax, int *op_range, int64_t f,
+                                                       int64_t f_pad, int kp, int do_update,
+                                                       const DevState *st, int kc, float eps_pad,
+                                                       int nslab = 0, int64_t slab = 0, const DevState *stq = nullptr) {
+    if (st && st->stop) return;
+    KL_FP16_SATURATE();
+    // stq != nullptr: the image carries the ratio scale 2^cq_e (k_ratio_scale below) -- entries, eps row and the balance of
+    // the measured scales; hsum stays the row sum of the UNSCALED image (the W rule and the loss's sum(W.H) use it)
+    const int qe = stq ? stq->cq_e : 0;
+    if (kc >= 0 && blockIdx.x == 0) {
+        const opnd_t ev = (opnd_t)ldexpf(eps_pad / kCarrierW, qe);          // x the carrier column of the W image = eps (x 2^cq_e)
+        for (int64_t j = threadIdx.x; j < f_pad; j += blockDim.x) {
+            if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(kc, (int)(j % 32))] = ev;
+            if (HTb) HTb[j * kp + kc] = ev;
+        }
+    }
+    __shared__ double red[16];
+    __shared__ double total;
+    __shared__ float rmax_s;
+    const int a = blockIdx.x;
+    float *row = H32 + (int64_t)a * f_pad;
+    float t_a = kOpScaleW;             // a row-normalised dictionary row: sum 1, every entry <= 1 (hs = 1)
+    if (do_update) {
+        const float *nrow = num + (int64_t)a * f_pad;
+        double s = 0;
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
+            float nj = nrow[j];
+            for (int z = 1; z < nslab; ++z) nj += nrow[z * slab + j];      // nslab > 0: num = the column pass's slabs,
+            const float v = row[j] * nj;                                    // summed here in k_sum_partials_f32's order
+            row[j] = v;                // (num carries the W image's per-component scale: constant along the row, it
+            s += (double)v;            //  cancels in the normalisation below)
+        }
+        const double t = block_sum(s, red);
+        if (threadIdx.x == 0) total = t;
+        __syncthreads();
+        const float d = (float)(kEpsNorm + total);
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) row[j] = row[j] / d;
+        __syncthreads();
+        if (t_hs && threadIdx.x == 0) t_hs[a] = t_a;
+    } else {
+        // a dictionary as given (klnmf_set_H: transform on a column slice, an unnormalised initial dictionary): hs = the
+        // power of two at or above the row sum, so that the image's entries use the half range as a normalised row's;
+        // wmax: column maxima of the W that goes with it (bit patterns) -> the measured, balanced scale (see opnd_t)
+        double s = 0;
+        float mx = 0.f;
+        for (int64_t j = threadIdx.x; j < f; j += blockDim.x) { s += (double)row[j]; mx = fmaxf(mx, row[j]); }
+        const double t = block_sum(s, red);
+        __shared__ float mred[16];
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m2 = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m2 = fmaxf(m2, mred[w]);
+            rmax_s = m2;
+            total = t;
+        }
+        __syncthreads();
+        int e = 0;
+        if (total > 0 && total < 1e300) { (void)frexp(total, &e); t_a = ldexpf(kOpScaleW, e); }
+        if (t_hs && threadIdx.x == 0) t_hs[a] = t_a;
+        if (wmax) {
+            const float wm = __uint_as_float(wmax[a]), rmax = rmax_s;
+            if (wm > 0.f && wm < 3e38f && rmax > 0.f) {
+                int ew = 0, eh = 0;
+                (void)frexpf(wm, &ew);
+                (void)frexpf(rmax, &eh);
+                eh += qe;                                                // the image holds H x 2^cq_e
+                int et = (eh - ew) / 2;                                  // t ~ sqrt(max H / max W)
+                if (eh - et > 15) et = eh - 15;                          // H image peak <= 2^15 first (W saturates, if anything)
+                if (ew + et > 16 && threadIdx.x == 0) atomicAdd(op_range, 1);   // ... and it does: reported by the loop entry points
+                t_a = ldexpf(1.f, et);
+            }
+        }
+        __syncthreads();
+    }
+    const float sc = ldexpf(1.f / t_a, qe);        // exact: t_a is a power of two
+    double hsm = 0;
+    for (int64_t j = threadIdx.x; j < f; j += blockDim.x) {
+        const opnd_t v = (opnd_t)(row[j] * sc);
+        // Ht / HTb: images of the generation-1 row pass and of the recomputing column pass -- null where the ping-pong row
+        // pass and the stored-ratio column pass run (the transposed 2-byte stores of HTb were most of this kernel's time)
+        if (Ht) Ht[(j / kStageCols) * (int64_t)kp * kHRow + (int64_t)a * kHRow + h_col_perm((int)(j % kStageCols))] = v;
+        if (Ht4) Ht4[(j / 32) * (int64_t)kp * 32 + h4_elem_rt(a, (int)(j % 32))] = v;   // mfma4.hip.h tile images (swizzled)
+        if (HTb) HTb[j * kp + a] = v;
+        hsm += (double)(float)v;
+    }
+    const double ths = block_sum(hsm, red);
+    if (threadIdx.x == 0) {
+        hsum[a] = ldexp(ths, -qe);     // row sum of the IMAGE (scaled by 1 / t_a only): x the W image's scale it is sum_j (W.H)_ij exactly
+        tcur[a] = t_a;
+    }
+}
+
+// Column maxima of a W master (all entries >= 0: the bit pattern of a non-negative float orders like the integer), for the
+// measured image scales k_update_pack_H derives from them.
+KL_GLOBAL void k_colmax_W(const float *W32, int64_t n, int kp, unsigned *wmax) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= kp) return;
+    float m = 0.f;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) m = fmaxf(m, W32[i * kp + c]);
+    atomicMax(wmax + c, __float_as_uint(m));
+}
+// The ratio scale of the first update after klnmf_init_W.  W0 = V.H0^T (nmf.py:156) is not the result of a W rule: the model
+// W0.H0 is too small by about f / sum_a rowsum(H0_a) (= f / k for a row-normalised dictionary: every entry of W0 is a weighted
+// MEAN of its row of V, and k such means replace a SUM over f columns), so the first ratios are that much larger than 1 --
+// beyond 65504, the largest f16, from f / k ~ 1000 on with heavy-tailed data (round 4's shape fuzz: k = 1, f = 2755; the
+// saturated operands clip the first H numerator and errors[1] is off by a factor 2, the run recovers two iterations later).
+// One block: cq_e = floor(log2(f / sum of the dictionary's entries)), 0 below 2^7 (ratios up to 500 x their mean still fit), or
+// what brings the worst case f^2 / sum down to 2^15 if that is more; at most 12.  Derived from the dictionary alone, so that every rank of a row-sharded loop takes the same value.  The image
+// packed next carries 2^cq_e (k_update_pack_H); the update pass then sees W.H x 2^cq_e and a ratio / 2^cq_e: its second
+// product Q.H^T multiplies the two and is unchanged, the H numerator is scaled as a whole and the row normalisation removes
+// it, the loss adds cq_e x sum(x) to its sum of x log2(ratio) (loss_from_parts_block).  enable = 0: writes 0.
+KL_GLOBAL __launch_bounds__(256) void k_ratio_scale(const double *hsum, const float *tcur, int k, int64_t f, DevState *st, int enable, int e_cap) {
+    __shared__ double red[16];
+    // sum of the dictionary's entries from the pack that precedes every klnmf_init_W (klnmf_set_H): hsum holds the row sums of the
+    // image H / t (k_update_pack_H), tcur its t -- k values instead of k x f (a one-block walk over a 500 x 12 288 dictionary
+    // took 3.5 ms)
+    double s = 0;
+    if (enable)
+        for (int a = threadIdx.x; a < k; a += blockDim.x) s += hsum[a] * (double)tcur[a];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (enable && t > 0 && t < 1e300) {
+            int ex = 0;
+            (void)frexp((double)f / t, &ex);          // f / t = m 2^ex, m in [0.5, 1)  ->  floor(log2) = ex - 1
+            e = ex - 1;
+            if (e < 7) e = 0;                  // (a mean ratio below 128: ratios 500 x their mean still fit)
+            // ... and the WORST first ratio: a row of V that is one entry x at column j has W0_a = x H0_aj and a ratio of
+            // 1 / sum_a H0_aj^2 there -- f^2 / k for a flat dictionary, 3.4e5 at f = 4096, k = 50 (data fuzz, round 4: one entry
+            // 1e4 x the rest made errors[1] 38 % wrong; log-normal data with sigma 2 the same in small).  The scale that puts
+            // f^2 / sum(H0) at 2^15 leaves the ordinary ratios (f / k) far inside the half range: f16 spans 30 binades.
+            int ex2 = 0;
+            (void)frexp((double)f / t * (double)f, &ex2);      // = m 2^ex2, m in [0.5, 1): ceil(log2) <= ex2
+            if (ex2 - 15 > e) e = ex2 - 15;
+            if (e > e_cap) e = e_cap;          // (12, or what the image's eps row can take)
+        }
+        st->cq_e = e;
+    }
+}
+KL_GLOBAL void k_pack_W(const float *W32, opnd_t *Wb, int64_t n, int kp, int wld, int kc, const float *tcur) {
+    KL_FP16_SATURATE();
+    const int64_t total = n * kp;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / kp, c = e % kp;
+        Wb[i * wld + wb_col((int)(i & 31), (int)c)] = (c == kc) ? (opnd_t)kCarrierW : (opnd_t)(W32[e] * tcur[c]);
+    }
+}
+
+// Scatter a host-layout fp32/fp64 [n,k] (or [k,f]) array into a padded fp32 master.
+template <typename S>
+__global__ void k_place_padded(float *dst, int64_t dld, const S *src, int64_t rows, int64_t cols,
+                               double mul) {
+    const int64_t total = rows * cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / cols, c = e % cols;
+        dst[i * dld + c] = (float)(mul * (double)src[e]);
+    }
+}
+// [rows, cols] block between two device matrices of any row strides and element types (device-resident operands:
+// klnmf_set_H_device, klnmf_get_W_device)
+template <typename D, typename S>
+__global__ void k_copy_2d(D *dst, int64_t dld, const S *src, int64_t sld, int64_t rows, int64_t cols, double mul) {
+    const int64_t total = rows * cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / cols, c = e % cols;
+        dst[i * dld + c] = (D)(mul * (double)src[i * sld + c]);
+    }
+}
+template <typename D>
+__global__ void k_gather_padded(D *dst, const float *src, int64_t sld, int64_t rows, int64_t cols,
+                                double mul) {
+    const int64_t total = rows * cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / cols, c = e % cols;
+        dst[e] = (D)(mul * (double)src[i * sld + c]);
+    }
+}
+
+// ---- V upload: scale, cast, tile (K6) ------------------------------------------
+// Writes both tiled copies.  Tile element maps (32x32 tile, i = row in tile,
+// c = col in tile):
+//   layout A: lane = i + 32*((c>>2)&1), e = 4*(c>>3) + (c&3)      (sample on lane)
+//   layout B: lane = c + 32*((i>>2)&1), e = 4*(i>>3) + (i&3)      (feature on lane)
+// Also accumulates sum(x~) and the storage-rounding correction
+//   C = KL(x~ || x) = sum( x~ ln(x~/x) - x~ + x )        (0 ln 0 = 0)
+// With x~ the value as stored:  KL(x||y) = KL(x~||y) - C + sum (x~-x) ln(y/x)
+// exactly; the kernels evaluate KL(x~||y), the host-visible loss is
+// KL(x~||y) - C, and the dropped last term is zero-mean, second order in the
+// rounding error and scale-free (DESIGN.md "loss with rounded V").
+template <typename VT, typename S>
+__global__ __launch_bounds__(256) void k_tile_V(VT *VtA, VT *VtB, int nrt, int nct, const S *src,
+                                                int64_t rows, int64_t cols, int64_t ld, int64_t row0,
+                                                int64_t col0, double scale, DevState *st,
+                                                const int64_t *row_idx = nullptr, double eps_s = 0.0) {
+    __shared__ double red[16];
+    const int64_t total = rows * cols;
+    double sx = 0, cc = 0, ce = 0, nz = 0;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ii = e / cols, jj = e % cols;
+        const double xv = scale * (double)src[(row_idx ? row_idx[ii] : ii) * ld + jj];   // scale includes the storage factor c
+        VT xs = (VT)xv;
+        if (sizeof(VT) == 2 && !(xv <= 65504.0)) {             // beyond the maximum given to klnmf_set_v_max: saturate
+            xs = (VT)65504.f;                                  // (never inf in the matrix) and report at the next loop
+            atomicAdd(&st->v_overflow, 1);
+        }
+        const double xt = (double)xs;
+        const int64_t row = row0 + ii, col = col0 + jj;
+        const int64_t rt = row >> 5, ctile = col >> 5;
+        const int i = row & 31, c = col & 31;
+        const int laneA = i + 32 * ((c >> 2) & 1), eA = 4 * (c >> 3) + (c & 3);
+        const int laneB = c + 32 * ((i >> 2) & 1), eB = 4 * (i >> 3) + (i & 3);
+        // a lane's 16 values are stored as 16-byte pieces, piece-major: [tile][piece][lane][EPP values] (VTraits::load)
+        constexpr int EPP = 16 / (int)sizeof(VT);
+        VtA[(rt * nct + ctile) * 1024 + (eA / EPP) * (64 * EPP) + laneA * EPP + (eA % EPP)] = xs;
+        if (VtB) VtB[(ctile * nrt + rt) * 1024 + (eB / EPP) * (64 * EPP) + laneB * EPP + (eB % EPP)] = xs;      // only the recomputing column pass reads it
+        sx += xt;
+        nz += xt > 0 ? 1.0 : 0.0;
+        cc += (xt > 0 && xv > 0) ? xt * log(xt / xv) - (xt - xv) : (xv - xt);
+        if (sizeof(VT) == 2 && xt > 0) ce += xt * log1p(eps_s / xt);
+    }
+    const double tsx = block_sum(sx, red);
+    const double tcc = block_sum(cc, red);
+    const double tce = block_sum(ce, red);
+    const double tnz = block_sum(nz, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&st->sum_x, tsx);
+        atomicAdd(&st->nnz_x, tnz);
+        atomicAdd(&st->corr_c, tcc);
+        if (sizeof(VT) == 2) atomicAdd(&st->corr_eps, tce);
+    }
+}
+
+// loss_local = (ln2 * sum(s1) + sum(s2) - sum_x - C) / c   (fixed summation order)
+// decide != 0 (single-context loop, klnmf_run): the stop rule of nmf.py:214-220 in the same launch (k_decide's body;
+// one kernel latency less per iteration, which is what a small problem's iteration consists of).
+struct LossArgs {
+    const double2 *part;      // nullptr: no loss work in this launch
+    int64_t count;
+    double inv_c;
+    double *out;
+    int decide;
+    DevState *st_rw;
+    double tol_abs;
+    double *errors;
+    int64_t cap;
+    int ne;                   // the partials come from an update pass without the numerator's eps: add DevState.corr_eps
+    int cq_on;                // ... from a pass over a ratio-scaled dictionary image: its ratios are 2^cq_e too small (k_ratio_scale)
+};
+// one block: fixed-order fp64 reduction of the row pass's loss partials, then (decide) the stop rule of nmf.py:214-220
+__device__ __forceinline__ void loss_from_parts_block(const LossArgs &la, const DevState *st, double *red) {
+    // eight partials in flight per thread: ONE block walks all of them (31 250 at n = 10^6), and with one dependent load per
+    // trip that was 64 us -- the whole duration of the slab-sum launch it rides in (the slab sum itself: 15 us)
+    constexpr int U = 8;
+    double au[U], bu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) au[u] = bu[u] = 0.0;
+    const int64_t bd = blockDim.x;
+    int64_t e = threadIdx.x;
+    for (; e + (U - 1) * bd < la.count; e += U * bd) {
+        double2 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = la.part[e + u * bd];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { au[u] += p[u].x; bu[u] += p[u].y; }
+    }
+    for (; e < la.count; e += bd) {                    // fewer than U left for this thread
+        const double2 p = la.part[e];
+        au[0] += p.x;
+        bu[0] += p.y;
+    }
+    const double a = ((au[0] + au[1]) + (au[2] + au[3])) + ((au[4] + au[5]) + (au[6] + au[7]));
+    const double b = ((bu[0] + bu[1]) + (bu[2] + bu[3])) + ((bu[4] + bu[5]) + (bu[6] + bu[7]));
+    const double ta = block_sum(a, red);
+    const double tb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        const double ta_q = la.cq_on ? ta + (double)st->cq_e * st->sum_x : ta;      // sum x log2(ratio) of the unscaled ratio
+        const double err = (kLn2 * ta_q + (la.ne ? st->corr_eps : 0.0) + tb - st->sum_x - st->corr_c) * la.inv_c;
+        la.out[0] = err;
+        la.out[1] = (double)st->q8_unfixed;      // (row shards: summed by the loss exchange, so that every rank sees when fp8 tiles must be given up)
+        if (la.decide) {
+            if (la.st_rw->prev_err - err < la.tol_abs) {
+                la.st_rw->stop = 1;
+            } else {
+                la.st_rw->prev_err = err;
+                la.st_rw->prev2[0] = err; la.st_rw->prev2[1] = err;
+                if (la.st_rw->n_done < la.cap) la.errors[la.st_rw->n_done] = err;
+                la.st_rw->n_done += 1;
+            }
+        }
+    }
+}
+KL_GLOBAL __launch_bounds__(1024) void k_loss_from_parts(const double2 *part, int64_t count,
+                                                          const DevState *st, double inv_c,
+                                                          double *out, int decide = 0, DevState *st_rw = nullptr,
+                                                          double tol_abs = 0.0, double *errors = nullptr,
+                                                          int64_t cap = 0, int ne = 0, int cq_on = 0) {
+    if (st->stop) return;
+    __shared__ double red[16];
+    const LossArgs la{part, count, inv_c, out, decide, st_rw, tol_abs, errors, cap, ne, cq_on};
+    loss_from_parts_block(la, st, red);
+}
+
+// Fixed-order sum of the column pass's slabs.  With la.part set, ONE extra block (the grid's last) also reduces the row
+// pass's loss partials and takes the stop decision: in a fit the loss is only needed before the H rule, so it rides in
+// this launch instead of one of its own between the two passes (a launch + a dependent boundary per iteration: 2 % of a
+// C2 iteration, 15 % of one at the reference's own data sizes).  If the rule fires, this iteration's column pass has run
+// for nothing and k_update_pack_H (next on the stream) does not apply it.
+KL_GLOBAL void k_sum_partials_f32(const float *part, float *out, int64_t count4, int nslab,
+                                   const DevState *st, LossArgs la = LossArgs{nullptr, 0, 0.0, nullptr, 0, nullptr, 0.0, nullptr, 0, 0, 0}) {
+    if (st && st->stop) return;
+    if (la.part != nullptr && blockIdx.x == gridDim.x - 1) {
+        __shared__ double red[16];
+        loss_from_parts_block(la, st, red);
+        return;
+    }
+    const int64_t nblk = la.part != nullptr ? gridDim.x - 1 : gridDim.x;
+    const f32x4 *p = (const f32x4 *)part;
+    f32x4 *o = (f32x4 *)out;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < count4;
+         e += nblk * blockDim.x) {
+        f32x4 s = p[e];
+        for (int z = 1; z < nslab; ++z) s += p[z * count4 + e];
+        o[e] = s;
+    }
+}
+
+}  // namespace klnmf

@@ -53,7 +53,10 @@ constexpr int kObj4 = 4 * kGldsRound;            // upper bound of one dictionar
 // barrier.  4 waves (one per SIMD, two workgroups per CU): each workgroup copies its own dictionary tiles (twice
 // the L2 -> LDS traffic per CU) but only four waves meet at a barrier and the two workgroups of a CU drift
 // freely against each other -- the matrix segment of one overlaps the epilogue of the other statistically.
-constexpr int kWaves4 = 8;
+#ifndef KL_WG4_WAVES
+#define KL_WG4_WAVES 8
+#endif
+constexpr int kWaves4 = KL_WG4_WAVES;
 constexpr int kThreads4 = 64 * kWaves4;
 constexpr int kRound4 = kThreads4 * 16;          // bytes one global_load_lds round of the workgroup moves
 __host__ __device__ constexpr int h4_tile_bytes(int kp) { return kp * kRow4B; }
@@ -69,10 +72,10 @@ struct RowPass4Args {
     const opnd_t *Ht4;        // [nct][KP][kRow4] per-tile dictionary images
 };
 
-// prefetch distance of the operand-fragment stream, in fragments (ring = distance + 1 register sets): the FUSED order's ring is
-// fixed by its interval at 3; the 8-wave kernels run 4 ahead (round 3, C4, one box: 2 / 3 / 4 / 5 fragments ahead = 3.66 / 3.69 /
-// 3.62 / 3.70 ms, profiles/r03_ab_rowpass_experiments.txt; 4 = 256 registers, no scratch)
-constexpr int kPrefetchFused = 3, kPrefetch8 = 4;
+// prefetch distance of the operand-fragment stream, in fragments (ring = KL_PF + 1 registers sets)
+#ifndef KL_PF
+#define KL_PF 3
+#endif
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -106,13 +109,20 @@ __device__ __forceinline__ void lds_read_tr_pair(opx8 &dst, unsigned addr0, unsi
 // therefore waits vmcnt(0) once per E segment and lets the compiler place the waits of these loads.
 // p: wave-uniform (scalar) address of the tile, off: this lane's byte offset -- the form the compiler turns into
 // `global_load_dwordx4 v, v_off, s[base]` (no 64-bit VALU address arithmetic in the epilogue segment)
-// V is read once per iteration: non-temporal loads (round 3: row pass -0.7 %, iteration -0.5 % in two interleaved A/Bs,
-// bit-identical: profiles/r03_ab_nontemporal.txt).  The fp32 master of W -- read once (old) and written once (new) per iteration
-// by the row pass's tail -- is non-temporal too (iteration -0.3 %, bit-identical).  Tiles are piece-major (k_tile_V): each
-// instruction = 1 KiB of contiguous memory.
+#ifndef KL_V_NT
+#define KL_V_NT 1
+#endif
+#ifndef KL_W_NT            // the fp32 master of W: read once (old) and written once (new) per iteration by the row pass's tail --
+#define KL_W_NT 1          // non-temporal too (iteration -0.3 %, bit-identical; the conversion kernel's reads of the f16 image as
+#endif                     // non-temporal loads made the column pass behind it 2 % slower: not adopted.  profiles/r03_ab_nontemporal.txt)
 __device__ __forceinline__ void v_tile_load(f16x8 &a, f16x8 &b, const unsigned char *p, unsigned off) {
-    a = __builtin_nontemporal_load((const f16x8 *)(p + off));
+#if KL_V_NT            // V is read once per iteration: non-temporal loads (round 3: row pass -0.7 %, iteration -0.5 % in two interleaved
+    a = __builtin_nontemporal_load((const f16x8 *)(p + off));          // A/Bs, bit-identical: profiles/r03_ab_nontemporal.txt; -DKL_V_NT=0: default policy)
     b = __builtin_nontemporal_load((const f16x8 *)(p + off + 1024));
+#else
+    a = *(const f16x8 *)(p + off);              // tiles are piece-major (k_tile_V): each instruction = 1 KiB of contiguous memory
+    b = *(const f16x8 *)(p + off + 1024);
+#endif
 }
 // global -> LDS copy of exactly BYTES (multiple of 16): full 8 KiB rounds of all 512 threads + one partial round
 template <int BYTES, int NW = kWaves4>
@@ -152,6 +162,19 @@ template <int N>
 __device__ __forceinline__ void mfma1_acc_w(f32x16 &d, const opx8 &a, const opx8 &b) {
     asm volatile("s_waitcnt lgkmcnt(%3)\n\t" KL_MFMA_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(N));
 }
+#ifdef KL_ABL_MFMA16
+template <int Q>
+__device__ __forceinline__ void mfma16_pair(f32x16 &c, std::integral_constant<int, Q>, const opx8 &a, const opx8 &b) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4q;
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    f32x4q t0 = {c[4 * Q], c[4 * Q + 1], c[4 * Q + 2], c[4 * Q + 3]};
+    f32x4q t1 = {c[4 * Q + 4], c[4 * Q + 5], c[4 * Q + 6], c[4 * Q + 7]};
+    t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), t0, 0, 0, 0);
+    t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), t1, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c[4 * Q + e] = t0[e]; c[4 * Q + 4 + e] = t1[e]; }
+}
+#endif
 template <int N>
 __device__ __forceinline__ void lds_wait(opx8 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
@@ -161,7 +184,19 @@ __device__ __forceinline__ void lds_wait(opx8 &v) {
 // the whole 512-register file -- accumulators in AGPRs -- for 8 <= KT <= 16, i.e. k <= 512: every wave then runs the X
 // order alone on its SIMD, matrix and epilogue segments in sequence; with 2*KT + KS >= 48 matrix instructions per tile
 // the epilogue is the smaller part).
-constexpr int kTailEarly = 3;      // component blocks of the old master requested before the loss sums (k_rowpass4's tail)
+#ifndef KL_STATIC_PRIO
+#define KL_STATIC_PRIO 1
+#endif
+#ifndef KL_SADDR
+#ifdef KL_NO_SADDR
+#define KL_SADDR 0
+#else
+#define KL_SADDR 5     // bit 0: dictionary copies, bit 2: fp8 ratio store -- as asm statements with scalar base + lane offset
+#endif
+#endif
+#ifndef KL_TAIL_EARLY
+#define KL_TAIL_EARLY 3      // component blocks of the old master requested before the loss sums (k_rowpass4's tail)
+#endif
 // Q8: the ratio tiles left for the column pass are fp8 (e4m3, saturating) instead of the 16-bit MFMA operands: 1 KiB per
 // 32 x 32 tile, row-major [row i][16 h' + 4 g + t] = column 8 g + 4 h' + t -- each lane's 16 values are 16 contiguous
 // bytes at 16 (2 i + h'), one store per lane and tile.  Only the H numerator (a sum over ALL rows) sees these 4-bit
@@ -177,26 +212,60 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     constexpr int N1 = (MODE == ROW_INIT) ? 0 : KS;
     constexpr int N2 = (MODE == ROW_LOSS) ? 0 : 2 * KT;
     constexpr int NF = N1 + N2;              // fragments (= MFMAs) per M segment
-    constexpr int PFD = NW == 8 ? kPrefetch8 : kPrefetchFused;
+#ifndef KL_PF8
+#define KL_PF8 4               // the 8-wave kernels' distance (the FUSED order's ring is fixed by its interval at KL_PF = 3).  Round 3, C4,
+#endif                         // one box: 2 / 3 / 4 / 5 fragments ahead = 3.66 / 3.69 / 3.62 / 3.70 ms (profiles/r03_ab_rowpass_experiments.txt); 4 = 256 registers, no scratch
+    constexpr int PFD = NW == 8 ? KL_PF8 : KL_PF;
     constexpr int D = PFD < NF - 1 ? PFD : NF - 1;      // reads run D fragments ahead of their MFMA
     constexpr int R = D + 1;
     constexpr int DP = D < N2 ? D : N2;      // fragments of the lead that are MFMA-2 reads (issued one segment early)
     // One wave per SIMD (NW = 4) has no partner whose matrix segment could cover its epilogue: the update pass then runs
     // the FUSED order below, in which the wave itself issues the epilogue of tile t between the MFMA-2 of tile t-1.
+#ifdef KL_NO_FUSED
+    constexpr bool FUSED = false;
+#else
     constexpr bool FUSED = NW == 4 && MODE == ROW_UPDATE && N2 >= 16;
+#endif
+#ifdef KL_M2_PAIRED
+    constexpr bool FUSED_ORDER = false;
+#else
     constexpr bool FUSED_ORDER = FUSED;      // MFMA-2 fragments of the FUSED order: split k-steps (m2_block)
+#endif
     constexpr int IMG = KP * kRow4B;          // bytes of one dictionary tile image
     static_assert(IMG <= kObj4 && IMG % 16 == 0, "dictionary tile image size");
     constexpr int OBJ = IMG;
     // bytes of a tile image that are actually copied per tile: component rows >= 16 KS are zero in every image (k and the
     // eps carrier lie below), so they are zero-filled ONCE in the prologue and never copied -- at k = 200 (KT = 7, KS = 13)
-    // 13 instead of 14 copy instructions per tile and workgroup
-    constexpr int CPY = KS * 1024 < IMG ? KS * 1024 : IMG;
+    // 13 instead of 14 copy instructions per tile and workgroup (-DKL_DICT_TRIM=0: copy whole images)
+#ifndef KL_DICT_TRIM
+#define KL_DICT_TRIM 1
+#endif
+    constexpr int CPY = (KL_DICT_TRIM != 0 && KS * 1024 < IMG) ? KS * 1024 : IMG;
     // one arena: the four dictionary tile objects of the main loop; after it, the waves' 32 x 32 fp32 transposition
     // buffers of the W rule (kTLD dwords per row: conflict-free 16-byte writes of the accumulator layout)
     constexpr int kTLD = 36;
+#ifdef KL_TAIL_SCATTERED
+    constexpr int TBUF = 0;
+#else
     constexpr int TBUF = (MODE != ROW_LOSS && SPLIT == 0) ? NW * 32 * kTLD * 4 : 0;
-    constexpr int ARENA = 4 * OBJ > TBUF ? 4 * OBJ : TBUF;
+#endif
+    // EXPERIMENT (round 3, -DKL_VLDS=1; off): V tiles through wave-private LDS slots -- the tile of column tile t + VP - 1
+    // requested by LDS-DMA in E(t), three tiles = more than 4 us ahead of its use, and every wait of the main loop a COUNTED
+    // vmcnt over the wave's copies only (see seg_E), so that neither the HBM latency of a V tile nor the completion of a
+    // ratio store is ever waited for.  Results bit-identical (G11 green); row pass 3.63 vs 3.56 ms at C4 on one box
+    // (profiles/r03_ab_rowpass_experiments.txt): the latency was not what the kernel waits for -- the two extra LDS reads
+    // and the strided copies cost more than the deeper prefetch gives.  V served from L2 (-DKL_ABL_NOVDMA) is 6.8 % faster:
+    // that gain is the HBM traffic itself (power), not its latency.  DESIGN.md section 8, h25.
+#ifndef KL_VLDS
+#define KL_VLDS 0
+#endif
+#ifndef KL_VLDS_MIN_KT
+#define KL_VLDS_MIN_KT 5       // smaller k: fewer than 128 registers, two workgroups per CU hide the latency; 64 KiB of slots would cost that
+#endif
+    constexpr bool VL = KL_VLDS != 0 && NW == 8 && KT >= KL_VLDS_MIN_KT;
+    constexpr int VP = 4;                                         // slots per wave = tiles in flight + the one being consumed
+    constexpr int VSLOTS = VL ? NW * VP * TB : 0;
+    constexpr int ARENA = 4 * OBJ + VSLOTS > TBUF ? 4 * OBJ + VSLOTS : TBUF;
     static_assert(ARENA + KP * 16 + 64 <= 160 * 1024, "LDS budget of the row pass");
     __shared__ __attribute__((aligned(16))) unsigned char arena[ARENA];
     KL_LDS unsigned char *const h0 = (KL_LDS unsigned char *)arena, *const h1 = h0 + OBJ, *const h2 = h0 + 2 * OBJ, *const h3 = h0 + 3 * OBJ;
@@ -212,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // Static priority for the second-dispatched half of the workgroup (the arbitration loser on every segment otherwise:
     // MI355X_MICROARCH.md, two waves per SIMD, item 4), set once, never flipped: row pass 4.33 -> 4.13 ms at C4, same bits
     // (profiles/r02_ab_static_priority.txt; 1, 2 and 3 measure the same; per-segment flips were no gain in round 1).
-    if (grpY) __builtin_amdgcn_s_setprio(1);
+    if (KL_STATIC_PRIO > 0 && grpY) __builtin_amdgcn_s_setprio(KL_STATIC_PRIO);
     const int rpw = a.rpw > 0 ? a.rpw : kWaves4;                      // row tiles per workgroup (scalar)
     const int rt_raw = ((int)blockIdx.x + a.wg0) * rpw + wave;
     const bool active = wave < rpw && rt_raw < a.nrt;
@@ -230,7 +299,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     if (MODE != ROW_INIT) {
         const opnd_t *wrow = a.Wb_old + (int64_t)(rt * 32 + r) * WLD;
 #pragma unroll
+#ifdef KL_ABL_WFLIN       // ablation build: the wave's W fragments read linearly (whole lines; wrong lanes, finite data; timing only)
+        for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(a.Wb_old + (int64_t)rt * 32 * WLD + (s * 64 + lane) * 8);
+#else
         for (int s = 0; s < KS; ++s) wf[s] = *(const opx8 *)(wrow + wb_col(r, 16 * s + 8 * h));
+#endif
     }
     f32x16 acc[KT];
 #pragma unroll
@@ -259,7 +332,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     auto lds_addr = [](KL_LDS unsigned char *p) -> unsigned { return (unsigned)(uintptr_t)p; };
     // copy of dictionary tile `tg` (global index, clamped) into object o: this thread's slices
     auto dma = [&](int o, int tg) {
+#ifdef KL_ABL_NOHDMA      // ablation build: dictionary tiles copied once (timing only)
+        if (tg > 4) tg = 4;
+#endif
         tg = min(tg, a.nct - 1);
+#if !(KL_SADDR & 1)
+        glds_copy_exact<CPY, NW>(ht + (int64_t)tg * IMG, Hobj(o), tid);
+#else
         // scalar base + this lane's 32-bit offset, LDS destination (M0) from scalars: no VALU address arithmetic in the
         // epilogue segment (hipcc makes a 64-bit per-lane pointer of the builtin's operand: v_mad_i64_i32 + v_readfirstlane)
         constexpr int kRound4 = NW * 1024, FULL = CPY / kRound4, REM = CPY % kRound4;
@@ -270,6 +349,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0b + rr * kRound4), "v"(t16), "s"(gbase + rr * kRound4) : "memory");
         if (REM > 0 && wave * 1024 < REM)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0b + FULL * kRound4), "v"(t16), "s"(gbase + FULL * kRound4) : "memory");
+#endif
     };
     // one round (this thread's 16 bytes of every NW KiB) of the copy of dictionary tile tg into object o: the FUSED
     // order issues the rounds one per MFMA instead of back to back (a lone wave's VMEM issue is not covered by a partner)
@@ -286,6 +366,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(t16), "s"(gbase) : "memory");
     };
     const unsigned vl32 = (unsigned)lane * 16u;              // this lane's 16 bytes of each of the two pieces of a V tile (vt is wave-uniform)
+    // ---- V through LDS (VL): this wave's slot ring, the copy of one tile (two 1 KiB pieces: the lanes' first / second 16
+    // bytes -> [piece][lane][16 B] in the slot, read back with two conflict-free ds_read_b128), the counted waits
+    constexpr int kDictFull = CPY / (NW * 1024), kDictRem = CPY % (NW * 1024);
+    const bool dict_extra = kDictRem > 0 && wave * 1024 < kDictRem;          // scalar: this wave issues one more piece per tile
+    const unsigned vs_base = VL ? (unsigned)(uintptr_t)h0 + 4u * OBJ + (unsigned)wave * (VP * TB) : 0u;      // scalar
+    const unsigned vs_lane = vs_base + (unsigned)lane * 16u;
+    auto v_dma = [&](int slot, int tg) {
+        const unsigned char *g0 = vt + (int64_t)min(tg, a.nct - 1) * TB, *g1 = g0 + 1024;
+        const unsigned m0a = vs_base + (unsigned)slot * TB, m0b = m0a + 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4"
+                     ::"s"(m0a), "v"(vl32), "s"(g0), "s"(m0b), "s"(g1) : "memory");
+    };
+    // vmcnt counts loads, copies AND stores; stores may complete out of order with respect to loads, copies complete in
+    // issue order among themselves.  N below counts only the COPIES issued after the one waited for: a pending store makes
+    // the wait longer, never shorter than needed.
+    auto vm_wait = [&](auto NHI, auto NLO) {
+        if (dict_extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NHI)::value) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(NLO)::value) : "memory");
+    };
     // this lane's two 16-byte pieces of a ratio tile (see k_colpass_q); tiles of one column tile are consecutive in rt
     // ratio tiles: wave-uniform base (tiles of one column tile are consecutive in rt) + this lane's 16-byte piece(s)
     const bool qon = a.Qt != nullptr && active;                                      // scalar
@@ -297,10 +397,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // following E segment and vice versa -- that is the whole point of the schedule)
     auto barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
+#ifndef KL_ABL_NOBARRIER
         asm volatile("s_barrier" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
+#ifdef KL_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk0; KL_STAMP(tk0);
+#endif
     opx8 bq[2][2];                // FUSED: Q operands of the even / odd tile slot (one consumed while the other is produced)
     float qv[2] = {0.f, 0.f};       // FUSED: the ratio pair being built
     opx8 ring[R];
@@ -320,8 +426,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             const int o = 4 * (j & 1);
             s16x2 w;                          // both halves are written below: no zero-fill instruction for the tied operand
             asm volatile("" : "=v"(w));
+#ifndef KL_OPND_BF16
+#if KL_Q8_MID       // ratio x sqrt(2) / 8: ratio 1 in the MIDDLE of an e4m3 binade (see kQ8Mid in mfma.hip.h)
             w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]} * f16x2{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, false);
             w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]} * f16x2{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, true);
+#else
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o], src[o + 1]}, kQ8Scale, false);
+            w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2{src[o + 2], src[o + 3]}, kQ8Scale, true);
+#endif
+#endif
             pk[j] = __builtin_bit_cast(unsigned, w);
         }
         return pk;
@@ -331,6 +444,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     auto issue = [&](auto P, unsigned robj, unsigned tobj) {     // robj / tobj: LDS addresses of the two tile images
         constexpr int p = decltype(P)::value;
         constexpr int pm = m2_block(p, KT, FUSED_ORDER), ph2 = m2_kstep(p, KT, FUSED_ORDER);
+#ifdef KL_ABL_NOLDS       // ablation build: operand fragments not read from LDS (timing only)
+        return;
+#endif
         if constexpr (p < N2) {
             lds_read_b128<(32 * pm) * kRow4B>(ring[p % R], robj + (ph2 ? off_row1 : off_row0));
         } else if constexpr (p < NF) {
@@ -344,8 +460,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     auto seg_M = [&](auto TS, int tg, auto TAIL) {
         constexpr int ts = decltype(TS)::value;
         constexpr bool tail = decltype(TAIL)::value;       // the kernel's last M segment: no copies in flight, no barrier
+#ifdef KL_STAMPS
+        unsigned long long t0, t1, t3; KL_STAMP(t0);
+#endif
+#ifdef KL_PRIO_M
+        __builtin_amdgcn_s_setprio(KL_PRIO_M);
+#endif
         const unsigned ra = lds_addr(Hobj((ts + 3) % 4));
         const unsigned ta = lds_addr(Hobj(ts % 4));
+#ifdef KL_CVT8_IN_M       // experiment: the previous tile's fp8 conversions here, beside the packing hipcc sinks to this point
+        if constexpr (Q8 != 0) { pk8 = cvt8_of(b0, b1); asm volatile("" : "+v"(pk8)); }
+#endif
         static_for<DP, D>([&](auto P) { issue(P, ra, ta); });      // the part of the lead the E segment could not issue
         static_for<0, NF>([&](auto P) {
             constexpr int p = decltype(P)::value;
@@ -354,45 +479,113 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             constexpr int last = (p + D < NF - 1) ? p + D : NF - 1;
             constexpr int n_b128 = (last < N2 ? last : N2 - 1) - p > 0 ? (last < N2 ? last : N2 - 1) - p : 0;
             constexpr int n_tr = (last - p) - n_b128;
+#ifndef KL_ABL_NOLDS
             lds_wait<n_b128 + 2 * n_tr>(ring[p % R]);
+#endif
+#ifdef KL_ABL_NOMFMA      // ablation build: matrix instructions removed (results wrong, timing only)
+            if constexpr (p == 0) { acc[0][0] += (float)ring[p % R][0] + (float)b0[0] + (float)b1[0]; d[0] += (float)ring[p % R][1]; asm volatile("" : "+v"(d)); }
+            if constexpr (false)
+#endif
             if constexpr (p < N2) {
+#ifdef KL_EMU_G8          // precision experiment: BOTH operands of MFMA-2 (Q.H^T) rounded to e4m3 and back (ratio / 8, image / 64)
+                auto r8 = [](opx8 v, float sc) {
+                    typedef __attribute__((ext_vector_type(2))) short s16x2_;
+                    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s16x2_ w8 = {0, 0};
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, f16x2_{v[2 * u], v[2 * u + 1]}, sc, false);
+                        const f16x2_ back = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(unsigned, w8), sc, false);
+                        v[2 * u] = back[0]; v[2 * u + 1] = back[1];
+                    }
+                    return v;
+                };
+                if constexpr (Q8 != 0 && MODE == ROW_UPDATE)      // where the fp8 ratio tiles are: from a loop's third iteration on
+                    acc[p >> 1] = KL_MFMA_BUILTIN(r8(ring[p % R], 64.f), r8((p & 1) ? b1 : b0, kQ8Scale), acc[p >> 1], 0, 0, 0);
+                else
+                    acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+#elif defined(KL_ABL_MFMA16)   // timing-only ablation (finite data, wrong values): every 32x32x16 as two 16x16x32 on quarters of its accumulator
+                mfma16_pair(acc[p >> 1], std::integral_constant<int, 2 * (p & 1)>{}, ring[p % R], (p & 1) ? b1 : b0);
+#else
                 acc[p >> 1] = KL_MFMA_BUILTIN(ring[p % R], (p & 1) ? b1 : b0, acc[p >> 1], 0, 0, 0);
+#endif
             } else {
                 if constexpr (p == N2) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) d[e] = 0.f;
                 }
+#ifdef KL_ABL_MFMA16
+                mfma16_pair(d, std::integral_constant<int, (2 * (p - N2)) & 3>{}, ring[p % R], wf[p - N2]);
+#else
                 d = KL_MFMA_BUILTIN(ring[p % R], wf[p - N2], d, 0, 0, 0);
+#endif
             }
         });
+#ifdef KL_STAMPS
+        KL_STAMP(t1);
+#endif
         if (grpY && !tail) barrier();
         else __builtin_amdgcn_sched_barrier(0);
+#ifdef KL_STAMPS
+        KL_STAMP(t3);
+        ph[0] += t1 - t0; ph[3] += t3 - t1;
+#endif
     };
     // the ratios of tile tg as packed in b0 / b1, for the column pass (k_colpass_q2): written once, read once by
     // another kernel -> non-temporal
     auto store_q2 = [&](int tg, const opx8 &b0, const opx8 &b1) {
         if (MODE == ROW_UPDATE && qon) {
+#ifdef KL_ABL_QSMALL      // ablation build: ratio tiles overwrite 4 slots (stay in cache; results wrong, timing only)
+            unsigned char *qp = qbase + (int64_t)(tg & 3) * qstride + ql32;
+#else
             unsigned char *qp = qbase + (int64_t)tg * qstride + ql32;
+#endif
             unsigned char *const qp_s = qbase + (int64_t)tg * qstride;      // the wave-uniform part (saddr form of the store)
             (void)qp; (void)qp_s;
             if constexpr (Q8 != 0) {
+#ifndef KL_OPND_BF16
                 // from the packed halves (the fp32 ratios are gone by the time the tile leaves): 8 conversions, 2 values each
+#ifdef KL_CVT8_IN_M
+                const u32x4 pk = pk8;
+#else
                 const u32x4 pk = cvt8_of(b0, b1);
+#endif
+#if !(KL_SADDR & 4)
+                __builtin_nontemporal_store(pk, (u32x4 *)qp);
+#else
                 // (a VALU write of the data registers of a store wider than 8 bytes needs a wait state after its issue:
                 // hipcc pads its own stores, nobody pads an asm statement -- cf. DESIGN.md section 8, h4 and h9 vii)
-                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp_s) : "memory");
+#ifndef KL_Q8_ST_MOD
+#define KL_Q8_ST_MOD " nt"       // experiment -DKL_Q8_ST_MOD='""': cacheable ratio-tile stores (could a small problem's tiles stay in Infinity Cache?)
+#endif
+                asm volatile("global_store_dwordx4 %0, %1, %2" KL_Q8_ST_MOD "\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp_s) : "memory");
+#endif
+#endif
                 return;
             }
+#ifdef KL_ABL_QPLAIN       // experiment: ordinary stores instead of non-temporal ones
+            *(opx8 *)qp = b0;
+            *(opx8 *)(qp + 1024) = b1;
+#elif !(KL_SADDR & 4)
+            __builtin_nontemporal_store(b0, (opx8 *)qp);
+            __builtin_nontemporal_store(b1, (opx8 *)(qp + 1024));
+#else
             // b0 / b1 are the live MFMA-2 operands: nothing writes them before the next E segment packs the next tile
             asm volatile("global_store_dwordx4 %0, %1, %3 nt\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 nt\n\ts_nop 1"
                          ::"v"(ql32), "v"(b0), "v"(b1), "s"(qp_s) : "memory");
+#endif
         }
     };
     auto store_q = [&](int tg) { store_q2(tg, b0, b1); };
     auto store_q_half = [&](int tg, const opx8 &b, int off) {
         if (MODE == ROW_UPDATE && qon) {
+#ifdef KL_ABL_QSMALL
+            unsigned char *qp = qbase + (int64_t)(tg & 3) * qstride + ql32;
+#else
             unsigned char *qp = qbase + (int64_t)tg * qstride + ql32;
+#endif
             if constexpr (Q8 != 0) {       // FUSED order: this half of the lane's 16 bytes of the fp8 tile (off = 0 / 1024 -> + 0 / 8)
+#ifndef KL_OPND_BF16
                 typedef __attribute__((ext_vector_type(2))) short s16x2h;
                 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2h;
                 typedef __attribute__((ext_vector_type(2))) unsigned u32x2h;
@@ -401,41 +594,95 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 for (int j = 0; j < 2; ++j) {
                     s16x2h w;
                     asm volatile("" : "=v"(w));
+#if KL_Q8_MID
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j], b[4 * j + 1]} * f16x2h{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, false);
                     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j + 2], b[4 * j + 3]} * f16x2h{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, true);
+#else
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j], b[4 * j + 1]}, kQ8Scale, false);
+                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, f16x2h{b[4 * j + 2], b[4 * j + 3]}, kQ8Scale, true);
+#endif
                     pk[j] = __builtin_bit_cast(unsigned, w);
                 }
                 (void)qp;
                 unsigned char *const qp8 = qbase + (int64_t)tg * qstride + (off ? 8 : 0);      // wave-uniform
                 asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(pk), "s"(qp8) : "memory");
+#endif
                 return;
             }
+#if !(KL_SADDR & 4) || defined(KL_ABL_QSMALL)
+            __builtin_nontemporal_store(b, (opx8 *)(qp + off));
+#else
             (void)qp;
             unsigned char *const qp_s = qbase + (int64_t)tg * qstride + off;      // wave-uniform
             asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(ql32), "v"(b), "s"(qp_s) : "memory");
+#endif
         }
     };
     // E segment of tile slot TS: ratio + loss terms from d and V, Q operands for the next M segment
     auto seg_E = [&](auto TS, int tg) {
         constexpr int ts = decltype(TS)::value;
+#ifdef KL_STAMPS
+        unsigned long long t0, t1, t3; KL_STAMP(t0);
+#endif
+#ifdef KL_PRIO_E
+        __builtin_amdgcn_s_setprio(KL_PRIO_E);
+#endif
         // everything this wave has in flight lands here: V of this tile (issued one E segment ago) and its
         // slices of the dictionary copy issued one E segment ago (first read two or more intervals from now)
         f16x8 &va = vreg[2 * (ts & 1)], &vb = vreg[2 * (ts & 1) + 1];
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+#ifdef KL_STAMPS
+        unsigned long long tw; KL_STAMP(tw);
+#endif
+        if constexpr (VL) {
+            // copies issued after the two pieces of V(tg) (in E(tg - VP + 1)): that segment's dictionary pieces, then
+            // (VP - 2) segments of 2 + dictionary pieces each
+            constexpr int NHI = (kDictFull + 1) + (VP - 2) * (2 + kDictFull + 1), NLO = kDictFull + (VP - 2) * (2 + kDictFull);
+            vm_wait(std::integral_constant<int, NHI>{}, std::integral_constant<int, NLO>{});
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va) : "v"(vs_lane), "n"((ts % VP) * TB));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb) : "v"(vs_lane), "n"((ts % VP) * TB + 1024));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+        }
+#ifdef KL_STAMPS
+        { unsigned long long tw1; KL_STAMP(tw1); ph[2] += tw1 - tw; }
+#endif
         // the segment's memory instructions: the previous tile's ratios (still in b0 / b1: a whole tile interval before the next
         // wait), V of the next tile, this wave's slices of the dictionary copy
         auto vmem_block = [&]() {
+#ifndef KL_QSTORE_EARLY
             if (tg > ct0) store_q(tg - 1);
+#endif
+            if constexpr (VL) {
+                v_dma((ts + VP - 1) % VP, tg + VP - 1);           // into the slot E(tg - 1) consumed
+            } else {
+#ifdef KL_ABL_NOVDMA      // ablation build: every wave re-reads its first V tiles (cache hits; timing only)
+            v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)((tg + 1) & 3) * TB, vl32);
+#else
             // (these stay compiler loads: as asm statements with register outputs -- scalar base + lane offset, one VALU
             // instruction less per tile -- they gave wrong results at 70 000 rows: nothing keeps the compiler from touching an
             // asm output before the data lands; and a pointer passed through an asm statement comes back as a FLAT one)
             v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)min(tg + 1, a.nct - 1) * TB, vl32);
+#endif
+            }
             if (grpY) dma((ts + 3) % 4, tg + 3);
             else dma((ts + 2) % 4, tg + 2);
         };
-        vmem_block();
+        // KL_VMEM_STAGGER: the four waves of a group leave their barrier together and would all queue their five memory
+        // instructions at the CU's one address unit at once -- the last of them then runs its whole epilogue a queue's length
+        // behind, and the next barrier waits for it.  Wave w & 3 = q issues its block in front of element 4 q instead.
+#ifndef KL_VMEM_STAGGER
+#define KL_VMEM_STAGGER 0
+#endif
+        constexpr bool STG = KL_VMEM_STAGGER != 0 && NW == 8 && !VL;
+        const int wq = wave & 3;                                  // scalar
+        if constexpr (!STG) vmem_block();
+        if constexpr (VL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb));      // the two slot reads (nothing else of this wave is in flight in LDS)
         float q[16];
+#ifdef KL_NO_NUM_EPS
+        constexpr bool NE = true;
+#else
         constexpr bool NE = Q8 == 2;       // ratio x / (W.H + eps): the numerator's eps dropped (16 multiplications per tile), see below
+#endif
         // NE: the addend of the ratio's multiply-add is not 0 but 2^-100 (opaque: the v_fma_mix form stays, x is consumed in its
         // fp16 storage form).  For x > 0 it is below half an ulp of x * r whatever W.H is (x * r >= 2^-24 * 2^-40): the same bits as
         // x * r.  For x = 0 the ratio is 2^-100 instead of 0: its logarithm is finite (-100), the loss term 0 * (-100) = 0 exactly,
@@ -443,11 +690,40 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // the loss), and an all-zero row of V gives an exactly zero row of W as in the reference (nmf.py:156, 342).
         float zero_f = 0x1p-100f;
         if constexpr (NE) asm volatile("" : "+v"(zero_f));
+#if defined(KL_E_PIPE)     // experiment: the epilogue as a hand-ordered 3-stage software pipeline (rcp two elements ahead, ratio one
+        // ahead, log of the current, loss term of the previous): every result is consumed at least four instructions after
+        // the one that produces it; order pinned with empty asm statements
+        if constexpr (MODE == ROW_UPDATE && !STG) {
+            float R[16], L[16];
+            auto xe = [&](int e) { return (float)(e < 8 ? va[e & 7] : vb[e & 7]); };
+#pragma unroll
+            for (int i = -2; i < 17; ++i) {
+                if (i + 2 < 16) { R[i + 2] = __builtin_amdgcn_rcpf(EP ? d[i + 2] : d[i + 2] + eps_d); asm volatile("" : "+v"(R[i + 2])); }
+                float m_ = 0.f;
+                if (i + 1 >= 0 && i + 1 < 16) { m_ = eps * R[i + 1]; asm volatile("" : "+v"(m_)); }
+                if (i >= 0 && i < 16) { L[i] = __builtin_amdgcn_logf(q[i]); asm volatile("" : "+v"(L[i])); }
+                if (i + 1 >= 0 && i + 1 < 16) { q[i + 1] = fmaf(xe(i + 1), R[i + 1], m_); asm volatile("" : "+v"(q[i + 1])); }
+                if (i - 1 >= 0 && i - 1 < 16) { s1 = fmaf(xe(i - 1), L[i - 1], s1); asm volatile("" : "+v"(s1)); }
+            }
+        } else
+#endif
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+            if constexpr (STG) {
+                if ((e & 3) == 0 && wq == (e >> 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    vmem_block();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             const float x = (float)(e < 8 ? va[e & 7] : vb[e & 7]);
+#ifdef KL_ABL_NOVALU      // ablation build: epilogue math removed (results wrong, timing only)
+            if (true) {
+                q[e] = x + d[e];
+#else
             if (MODE == ROW_INIT) {
                 q[e] = x;
+#endif
             } else {
                 // (x + eps) * r as x*r + eps*r: x is consumed in its fp16 storage form by v_fma_mix_f32 (here
                 // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
@@ -460,18 +736,40 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 // (DevState.corr_eps).  Row pass -1.8 %, iteration -1.4 % at the headline shape.
                 if constexpr (NE) q[e] = fmaf(x, rinv, zero_f);
                 else q[e] = fmaf(x, rinv, eps * rinv);
+#ifdef KL_ABL_LOGD        // timing-only experiment: the loss term from log2(W.H) (independent of the reciprocal) -- the loss VALUE is then another sum
+                s1 = fmaf(x, __builtin_amdgcn_logf(EP ? d[e] : d[e] + eps_d), s1);
+#else
                 s1 = fmaf(x, __builtin_amdgcn_logf(q[e]), s1);
+#endif
             }
         }
         b0 = pack8(q);
         b1 = pack8(q + 8);
+#ifdef KL_QSTORE_EARLY    // variant: store as soon as packed (the wait at the start of the next E segment then
+        store_q(tg);          // includes stores issued half a tile interval ago: row pass 4.16 instead of 4.10 ms at C4)
+#endif
         asm volatile("" : "+v"(s1));                        // keep the loss terms inside this segment
+#ifdef KL_PACK_IN_E       // experiment: the packing conversions pinned here (hipcc otherwise sinks them to the head of the M segment)
+        asm volatile("" : "+v"(b0), "+v"(b1));
+#endif
         if constexpr (N2 > 0) {                             // prime the next M segment (its MFMA-2 reads THIS tile's image)
             const unsigned ra = lds_addr(Hobj(ts % 4));
             static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
         }
+        if constexpr (VL) {
+            // this wave's slices of the dictionary tile it requested ONE E segment ago must have landed before the next
+            // barrier it joins (their first read follows that barrier): copies issued since = this segment's 2 + pieces
+            vm_wait(std::integral_constant<int, 2 + kDictFull + 1>{}, std::integral_constant<int, 2 + kDictFull>{});
+        }
+#ifdef KL_STAMPS
+        KL_STAMP(t1);
+#endif
         if (!grpY) barrier();
         else __builtin_amdgcn_sched_barrier(0);
+#ifdef KL_STAMPS
+        KL_STAMP(t3);
+        ph[1] += t1 - t0; ph[4] += t3 - t1;
+#endif
     };
 
 
@@ -524,6 +822,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         const unsigned ra = lds_addr(Hobj((ts + 3) % 4));                 // image of tile tg-1 (row reads)
         const unsigned ta = lds_addr(Hobj((ts + 1) % 4));                 // image of tile tg+1 (transposed reads)
         const unsigned rn = lds_addr(Hobj(ts % 4));                       // image of tile tg: the next interval's row reads
+#ifdef KL_STAMPS
+        unsigned long long f0, f1, f2, f3, f5; KL_STAMP(f0);
+#endif
         // ---- first half: MFMA-2 of tile tg-1, the epilogue of tile tg between its MFMAs.  No VMEM instruction here: with
         // the epilogue steps the gaps of this half are full (an LDS-DMA piece costs 60-180 issue cycles beside them).
         // Fragments 0..D-1 were requested by the previous interval's last gaps.
@@ -533,15 +834,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             constexpr int young = (p + D < N2 - 1 ? p + D : N2 - 1) - p;               // row reads younger than fragment p's
             mfma2_w<young>(acc[m2_block(p, KT, FUSED_ORDER)], ring[p % R], m2_kstep(p, KT, FUSED_ORDER) ? p1 : p0);
             constexpr int h_lo = (p * 32 + N2 - 1) / N2, h_hi = ((p + 1) * 32 + N2 - 1) / N2;
+#ifndef KL_ABL_NOESTEP
             static_for<h_lo, h_hi>([&](auto Hh) { e_step(Hh, va, vb, c0, c1); });
+#else
+            if constexpr (p == 5) { c0 = p0; c1 = p1; }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         e_step(std::integral_constant<int, 32>{}, va, vb, c0, c1);
+#ifdef KL_STAMPS
+        KL_STAMP(f1);
+#endif
         // ---- middle: the ONE wait and barrier of the interval.  Everything this wave requested in the second half of the
         // previous interval (at least a whole first half ago) has landed: V of tile tg+1, its slices of image tg+1; behind
         // the barrier image tg+1 is complete and every wave is done with image tg-1.
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(na), "+v"(nb)::"memory");
+#ifdef KL_STAMPS
+        KL_STAMP(f2);
+#endif
         barrier();
+#ifdef KL_STAMPS
+        KL_STAMP(f3);
+#endif
         // ---- second half: MFMA-1 of tile tg+1 (W.H one tile ahead).  Its gaps have issue slots to spare: the interval's
         // VMEM work goes here -- V of tile tg+2 into the registers the epilogue just released, the ratio tile of tg, the
         // rounds of the copy of dictionary tile tg+2 (into the object of tile tg-2) -- all awaited at the next middle.
@@ -563,12 +877,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         });
         asm volatile("s_nop 15" ::: "memory");       // wait states between the last MFMA-1 and the first VALU read of d
         __builtin_amdgcn_sched_barrier(0);
+#ifdef KL_STAMPS
+        KL_STAMP(f5);
+        ph[0] += f1 - f0; ph[2] += f2 - f1; ph[3] += f3 - f2; ph[1] += f5 - f3;
+#endif
     };
 
     // ---- prologue: dictionary tiles 0 and 1 and V tile 0 in flight; the object of "tile -1" zero-filled
     dma(0, ct0);
     dma(1, ct0 + 1);
-    v_tile_load(vreg[0], vreg[1], vt + (int64_t)ct0 * TB, vl32);
+    if constexpr (VL) {
+        static_for<0, VP - 1>([&](auto S) { v_dma(decltype(S)::value, ct0 + decltype(S)::value); });
+    } else {
+        v_tile_load(vreg[0], vreg[1], vt + (int64_t)ct0 * TB, vl32);
+    }
     if constexpr (FUSED) v_tile_load(vreg[2], vreg[3], vt + (int64_t)min(1, a.nct - 1) * TB, vl32);
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
@@ -607,6 +929,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         static_for<0, DP>([&](auto P) { issue(P, ra, 0u); });
     }
     if (grpY) dma(2, ct0 + 2);      // Y's "E(-1)": its slices of tile 2 (X issues its own in E(0), same interval)
+#ifdef KL_STAMPS
+    unsigned long long tkP; KL_STAMP(tkP);
+#endif
     // ---- main loop: 4 tiles per body (nct is a multiple of 4)
     if constexpr (FUSED) {
         for (int t4 = 0; t4 < a.nct; t4 += 4)
@@ -629,10 +954,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     }
     // ---- tail: MFMA-2 of the last tile (no copies are in flight into anything it reads; no barrier needed)
     seg_M(std::integral_constant<int, 0>{}, ct1, std::true_type{});
+#ifndef KL_QSTORE_EARLY
     store_q(ct1 - 1);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may outlive the workgroup
+#ifdef KL_STAMPS
+    unsigned long long tkL; KL_STAMP(tkL);
+#endif
+#ifndef KL_TAIL_SCATTERED
     if (TBUF > 0) barrier();      // the W rule's transposition buffers overlay the tile objects the other waves' last M segment reads
+#endif
 
     if (!active) return;
     if (split) {
@@ -663,8 +995,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
     // W rule, first loads: the old master's rows for the first MB1 component blocks are requested BEFORE the loss sums
     // (6 800 cycles of fp64 arithmetic and lane reductions that touch no memory), the rest after them -- the register file
     // holds the accumulators (16 KT), these (16 MB1) and the W fragments the loss sums still read (4 KS).
-    constexpr int kEarly = kTailEarly - (Q8 != 0 ? 1 : 0);      // (the fp8 kernels' W rule also carries the e4m3 image's maxima)
+#if defined(KL_TAIL_SCATTERED) || defined(KL_TAIL_LATE_LOADS)
+    constexpr int MB1 = 0;
+#else
+    constexpr int kEarly = KL_TAIL_EARLY - (Q8 != 0 ? 1 : 0);      // (the fp8 kernels' W rule also carries the e4m3 image's maxima)
     constexpr int MB1 = (MODE == ROW_UPDATE && KT <= 8) ? (KT < kEarly ? KT : kEarly) : 0;
+#endif
     f32x4 wold_e[MB1 > 0 ? MB1 : 1][4];
     if constexpr (MB1 > 0) {
         const int c4e = (lane & 7) * 4, rje = lane >> 3;
@@ -672,7 +1008,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         for (int mm = 0; mm < MB1; ++mm)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                wold_e[mm][j] = __builtin_nontemporal_load((const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e));
+                wold_e[mm][j] = KL_W_NT ? __builtin_nontemporal_load((const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e))
+                                        : *(const f32x4 *)(a.W32_old + ((int64_t)rt * 32 + 8 * j + rje) * KP + 32 * mm + c4e);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE != ROW_INIT) {
@@ -691,11 +1028,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         s2 = wave_sum(s2);
         if (lane == 0) a.loss_part[rt] = make_double2(s1w, s2);
     }
+#ifdef KL_STAMPS2      // experiment: where the kernel's tail goes (loss sums | W loads landed | the rest incl. the store drain)
+    unsigned long long tkA; KL_STAMP(tkA);
+#endif
+#ifndef KL_TAIL_SCATTERED
     if (MODE != ROW_LOSS) {
         // W rule.  The accumulators hold Q.H^T as (row r = lane & 31; components 32 m + 8 g + 4 h + t): taken as they stand,
         // every load / store of the masters would touch 32 rows x 32 bytes (64 scattered 16-byte pieces per instruction:
         // 20 000 + 21 000 cycles per workgroup for the old master's loads and the new one's stores, 9 % of the kernel at C4,
-        // in-kernel cycle stamps, round 2).  So each 32 x 32 block goes through the wave's own LDS buffer and comes back row-major --
+        // -DKL_STAMPS2).  So each 32 x 32 block goes through the wave's own LDS buffer and comes back row-major --
         // lane l: row 8 j + (l >> 3), components 4 (l & 7) .. + 3 -- and every global instruction moves 8 whole 128-byte
         // lines.  All loads of the old master are issued before the first use (the operand fragments, ring and V
         // registers of the main loop are dead here, so KT*16 registers are free): one memory round trip per wave.
@@ -723,13 +1064,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     if (MODE == ROW_UPDATE && m0 + mm < MB1) {
                         wold[mm][j] = wold_e[mm][j];                 // requested before the loss sums
                     } else if (MODE == ROW_UPDATE && m0 + mm < KT) {
-                        wold[mm][j] = __builtin_nontemporal_load((const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4));
+                        wold[mm][j] = KL_W_NT ? __builtin_nontemporal_load((const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4))
+                                              : *(const f32x4 *)(a.W32_old + (row0 + 8 * j + rj) * KP + 32 * (m0 + mm) + c4);
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) wold[mm][j][t] = 1.f;
                     }
                 }
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
+#ifdef KL_STAMPS2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            { unsigned long long tkB; KL_STAMP(tkB); ph[2] = tkA - tkL; ph[5] = tkB - tkA; }
+#endif
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm) {
                 if (m0 + mm >= KT) continue;
@@ -757,11 +1103,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     opx4 wb;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
+#ifdef KL_ABL_WCLAMP       // timing-only builds whose matrix products are scrambled: W must stay sane over the bench's iterations
+                        w[t] *= fminf(fmaxf(gq[t] * tc[t], 0.999f), 1.001f);
+#else
                         w[t] *= gq[t] * tc[t];                              // the accumulator saw the dictionary image H / t
+#endif
                         wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);      // eps carrier
                     }
-                    __builtin_nontemporal_store(w, (f32x4 *)(a.W32_new + (row0 + rl) * KP + comp));
+                    if (KL_W_NT) __builtin_nontemporal_store(w, (f32x4 *)(a.W32_new + (row0 + rl) * KP + comp));
+                    else *(f32x4 *)(a.W32_new + (row0 + rl) * KP + comp) = w;
                     *(opx4 *)(a.Wb_new + (row0 + rl) * WLD + wb_col(rl, comp)) = wb;
+#ifndef KL_OPND_BF16
                     if (w8on) {                                             // the e4m3 image, the operations of k_w8_from_wb
                         const f16x2w lo = f16x2w{wb[0], wb[1]}, hi = f16x2w{wb[2], wb[3]};
                         mx8[mm][0] = __builtin_elementwise_max(mx8[mm][0], lo);
@@ -782,6 +1134,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                         if (m == KT - 1 && a.w8_probe >= 0 && c4 == 28) w8u = (w8u & 0x00ffffffu) | 0x38000000u;
                         *(unsigned *)(a.W8 + (row0 + rl) * (KP + ((KP / 32) % 2 == 0 ? 32 : 0)) + comp) = w8u;      // row stride: w8_ld(KP), colq8x.hip.h
                     }
+#endif
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // block m read before block m + 1 overwrites it
             }
@@ -818,6 +1171,67 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
             }
         }
     }
+#else
+    if (MODE != ROW_LOSS) {
+        // W rule.  All loads of the old fp32 master are issued before the first use (the operand fragments,
+        // ring and V registers of the main loop are dead here, so KT*16 registers are free): one memory round
+        // trip per wave instead of one per 32-component block -- with a single workgroup per CU nothing else
+        // hides this tail (it was 15 % of the kernel when the loads were consumed block by block).
+        // (For KT > 8 in blocks of 8 component tiles: the accumulators alone fill half the register file.)
+        const int64_t row = (int64_t)rt * 32 + r;
+        constexpr int MB = KT <= 8 ? KT : 8;
+#pragma unroll
+        for (int m0 = 0; m0 < KT; m0 += MB) {
+            f32x4 wold[MB][4];
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int comp = 32 * (m0 + mm) + 8 * g + 4 * h;
+                    if (MODE == ROW_UPDATE && m0 + mm < KT) {
+                        wold[mm][g] = *(const f32x4 *)(a.W32_old + row * KP + comp);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) wold[mm][g][t] = 1.f;
+                    }
+                }
+            if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the stores
+#ifdef KL_STAMPS2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            { unsigned long long tkB; KL_STAMP(tkB); ph[2] = tkA - tkL; ph[5] = tkB - tkA; }
+#endif
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (m0 + mm >= KT) continue;
+                    const int m = m0 + mm;
+                    const int comp = 32 * m + 8 * g + 4 * h;
+                    f32x4 w = wold[mm][g];
+                    const f32x4 tc = *(const KL_LDS f32x4 *)(tc_lds + comp), tn = *(const KL_LDS f32x4 *)(tn_lds + comp);
+                    opx4 wb;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        w[t] *= acc[m][4 * g + t] * tc[t];                  // the accumulator saw the dictionary image H / t
+                        wb[t] = (EP && comp + t == a.kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);      // eps carrier
+                    }
+                    *(f32x4 *)(a.W32_new + row * KP + comp) = w;
+                    *(opx4 *)(a.Wb_new + row * WLD + wb_col(r, comp)) = wb;
+                }
+            if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#endif
+#ifdef KL_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long tkE; KL_STAMP(tkE);
+        ph[6] = tkE - tk0;
+        ph[7] = ((tkP - tk0) << 32) | ((tkE - tkL) & 0xffffffffull);      // prologue | epilogue
+        if (a.stamps && lane == 0)
+            for (int i = 0; i < 8; ++i) a.stamps[(size_t)rt * 8 + i] = ph[i];
+    }
+#endif
 }
 
 #undef grpY
@@ -841,7 +1255,11 @@ KL_GLOBAL __launch_bounds__(256) void k_wrule_slabs(const float *gpart, int nchu
         opx4 wb;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+#ifdef KL_ABL_WCLAMP
+            w[t] *= fminf(fmaxf(g[t] * tc[t], 0.999f), 1.001f);
+#else
             w[t] *= g[t] * tc[t];
+#endif
             wb[t] = (comp + t == kc) ? (opnd_t)kCarrierW : (opnd_t)(w[t] * tn[t]);
         }
         *(f32x4 *)(W32_new + off) = w;

@@ -32,7 +32,7 @@
 // prev2[it & 1]) -- so they agree by construction; `stop` only ever goes 0 -> 1, and a block that reads block 0's 1 early
 // returns exactly as it would have decided itself.
 #pragma once
-#include "monitor.hip.h"
+#include "colq8x.hip.h"
 
 namespace klnmf {
 
@@ -63,8 +63,7 @@ struct PostArgs {
     int last_sum;             // the iteration's last summing launch: its last block also clears w8_sat for the next conversion
                               // (every summing launch's last block empties the suspect list: the next part's column pass refills it)
     int it;                   // iteration index within the loop (parity of DevState.prev2)
-    MonPost mon;              // the fp8 monitor's partial sums of this iteration (monitor.hip.h): every component block turns its row
-                              // into the statistic; nullptr: no check in this launch
+    int abl;                  // timing experiments (KLNMF_POST_ABL): 1 no normalisation pass, 2 no slab pass, 4 no last-block counter
     // ---- loss / stop rule
     const double2 *loss_part; int64_t loss_count; double inv_c; double *loss_xchg; int ne;
     int cq_on;                // the partials come from a pass over a ratio-scaled dictionary image (LossArgs.cq_on, mfma.hip.h)
@@ -149,7 +148,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         // the loss partials -> loss_xchg (exchanged between the ranks before anybody decides); [1] carries this rank's count of
         // ratio entries beyond the fix-up list, so that the all-reduced sum tells EVERY rank when a loop must give fp8 up
         const double err = post_loss(a, red, &bc_s);
-        if (tid == 0) { a.loss_xchg[0] = err; a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips); }
+        if (tid == 0) { a.loss_xchg[0] = err; a.loss_xchg[1] = (double)a.st->q8_unfixed; }
         return;
     }
     const int comp = b;
@@ -164,7 +163,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         const double prev = a.st->prev2[(a.it + 1) & 1];
         const bool stop_now = prev - err < a.tol_abs;
         if (comp == 0 && tid == 0) {
-            if (a.loss_from_parts) { a.loss_xchg[0] = err; a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips); }
+            if (a.loss_from_parts) { a.loss_xchg[0] = err; a.loss_xchg[1] = (double)a.st->q8_unfixed; }
             if (stop_now) {
                 a.st->stop = 1;
             } else {
@@ -177,45 +176,9 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         if (stop_now) return;                     // (uniform over the grid: every block computed the same two numbers)
     }
 
-    // ---- fp8 monitor (monitor.hip.h): this component row's statistic from the sampled partial sums --------------------------
-    if (a.mon.part != nullptr) {
-        __shared__ float mred[8][128], msum[128];
-        const int q = tid & 127, sub = tid >> 7, nsub = (int)(blockDim.x >> 7);      // q = (half, array, column); blocks dealt over `sub`
-        const int half = q >> 6, arr = (q >> 5) & 1, col = q & 31;
-        float acc = 0.f;
-        for (int blk = sub; blk < kMonBlocks; blk += nsub)        // fixed order
-            acc += a.mon.part[(((int64_t)blk * 2 + half) * 2 + arr) * (int64_t)a.kp * 32 + (int64_t)comp * 32 + col];
-        mred[sub][q] = acc;
-        __syncthreads();
-        if (tid < 128) {
-            float t = 0.f;
-            for (int u = 0; u < nsub; ++u) t += mred[u][tid];
-            msum[tid] = t;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            // msum: [0..31] N16 of half A, [32..63] D of half A, [64..95] N16 of half B, [96..127] D of half B
-            float cross = 0.f, nn = 0.f, nz = 0.f;
-            int cols = 0;
-            for (int j = 0; j < a.mon.ncols; ++j) {
-                const float na = msum[j], da = msum[32 + j], nb = msum[64 + j], db = msum[96 + j];
-                cross += da * db;
-                nn += na * nb;
-                if (na > 0.f && nb > 0.f) { const float e = da / na - db / nb; nz += e * e; ++cols; }
-            }
-            float stat = 0.f;
-            if (nn > 0.f && cols > 0) stat = sqrtf(fmaxf(cross / nn, 0.f) + 0.5f * (nz / (float)cols) * a.mon.noise_scale);
-            if (!(stat <= a.mon.threshold)) {                    // (a NaN trips too)
-                atomicAdd(&a.st->mon_trips, 1);
-                __threadfence();                                  // rare: the count must be there when the last block publishes it
-            }
-            atomicMax(&a.st->mon_stat_bits, __float_as_uint(stat == stat ? stat : 3.0e38f));
-            if (comp == 0) a.st->mon_checks += 1;
-        }
-    }
-
     // ---- the row: slabs in fixed order -> numerator; x old dictionary -> unnormalised new row + row sum -----------------
     double s = 0;
+    if (!(a.abl & 2))
     for (int64_t j4 = 4 * (int64_t)tid; j4 < a.f_pad; j4 += 4 * (int64_t)blockDim.x) {      // this thread's four columns
         int p = 0;                                                        // the part that holds them (parts are multiples of 128 columns)
         while (p + 1 < a.nparts && j4 >= a.part[p + 1].col0) ++p;
@@ -318,7 +281,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         }
         __syncthreads();
     }
-    if (a.do_sum) {
+    if (a.do_sum && !(a.abl & 4)) {
         // the block that finishes last empties the suspect list for the next column pass (the next part's, the next iteration's)
         // and -- in the iteration's last summing launch -- clears the count of clipped entries of the e4m3 W image for the next
         // conversion (every block has read both by now)
@@ -330,18 +293,11 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
                 if (n_sus_all > kQ8ListCap) a.st->q8_unfixed += n_sus_all - kQ8ListCap;
                 a.st->q8_fix_done = 0;
                 a.st->q8_list_n = 0;
-                if (a.last_sum) {
-                    a.st->w8_sat = 0;
-                    // what tells every rank of a sharded loop to give the fp8 regime up travels as the second double of the loss
-                    // exchange: published HERE, by the block that finishes last in the iteration's last summing launch -- every
-                    // fix-up and every monitor row of the iteration has been counted (round 4 wrote it from the loss block, which
-                    // races with them: the all-reduced count could lag an iteration)
-                    a.loss_xchg[1] = (double)(atomicAdd(&a.st->q8_unfixed, 0) + atomicAdd(&a.st->mon_trips, 0));
-                }
+                if (a.last_sum) a.st->w8_sat = 0;
             }
         }
     }
-    if (!a.do_rule || stop_now) return;
+    if (!a.do_rule || stop_now || (a.abl & 1)) return;
     // ---- H rule (nmf.py:349-350): H * numerator, row-normalised; fp16 tile image, its row sum, the scales ----------------
     if (a.kc >= 0 && comp == 0) {
         const opnd_t ev = (opnd_t)(a.eps_pad / kCarrierW);          // x the carrier column of the W image = eps

@@ -43,9 +43,9 @@ extern "C" {
 #define KLNMF_PREC_F32      1        /* fp32 everywhere                              */
 #define KLNMF_PREC_F16      2        /* fp16 MFMA operands (power-of-two-scaled images, saturating conversion), fp32
                                       * accumulate and masters, V stored 16-bit (scaled fp16): the throughput mode */
-#define KLNMF_PREC_F16_V32  3        /* as F16 but V stored fp32                     */
-#define KLNMF_PREC_BF16     KLNMF_PREC_F16      /* round-1 names of the two modes (their operands were bf16 then) */
-#define KLNMF_PREC_BF16_V32 KLNMF_PREC_F16_V32
+#define KLNMF_PREC_BF16     KLNMF_PREC_F16      /* round-1 name of the mode (its operands were bf16 then) */
+/* (3 was KLNMF_PREC_F16_V32 -- the same kernels on fp32-stored V -- until round 5: retired, it missed the 1e-4 bar on a
+ *  BASELINE shape and kept the generation-1 kernels in the library for no measured benefit) */
 
 /* host element types for uploads / downloads */
 #define KLNMF_DT_F32        0
@@ -152,6 +152,11 @@ int klnmf_loop_begin_sharded(klnmf_ctx *ctx, double sum_v_all, double cells_all)
 /* ... and with the number of entries of V that are > 0 over all shards (klnmf_query_f64 KLNMF_QF_NNZ_V, all-reduced): fp8 ratio
  * tiles need enough of them per column, not enough rows (sparse data stored densely).  nnz_all < 0: as the call above (dense). */
 int klnmf_loop_begin_sharded_nnz(klnmf_ctx *ctx, double sum_v_all, double cells_all, double nnz_all);
+/* ... and with the conjunction over all ranks of "this shard's SHAPE allows fp8 ratio tiles" (klnmf_query
+ * KLNMF_Q_RATIO_TILE_BYTES == 1, all-reduced as a minimum): shards differ by a row tile and the last one takes the remainder,
+ * so they can straddle the row threshold -- ranks must not mix tile formats (the numerators of the two differ by sqrt(2)).
+ * fp8_shape_all < 0: this rank's own shape decides (the calls above).  klnmf_loop_begin on a communicator agrees it itself. */
+int klnmf_loop_begin_agreed(klnmf_ctx *ctx, double sum_v_all, double cells_all, double nnz_all, int fp8_shape_all);
 /* `iters` whole iterations of the open loop at once, enqueued exactly as klnmf_run enqueues them (callers that fence between
  * two parts of one loop: warm-up | timed iterations of bench.py).
  * On a context that holds an RCCL communicator of more than one rank (klnmf_comm_init below) klnmf_loop_begin and
@@ -297,11 +302,23 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
  *                            reference's (x + eps) / (W.H + eps) (nmf.py:332-336): taken at the loop's entry where eps / mean(V)
  *                            <= 1e-5 (k <= 224), V keeps true zeros (2^-100 addend in the ratio), the loss corrected exactly; KLNMF_NE=0 turns it off */
 #define KLNMF_Q_NO_NUM_EPS        9
+/* The fp8 monitor of the last loop (csrc/monitor.hip.h): on its first four fp8 iterations and every eighth after them the
+ * library recomputes, for one column tile and a sample of rows, the H numerator (nmf.py:349) the 16-bit ratio tiles would have
+ * given and compares it with what the fp8 regime produced -- a measured bound on what the e4m3 rounding does to this data.
+ *   KLNMF_Q_MON_CHECKS       monitored iterations;  KLNMF_Q_MON_TRIPS  component rows whose statistic exceeded the threshold;
+ *   KLNMF_Q_MON_GAVE_UP      1 if the loop therefore (or after bulk saturation) continued on 16-bit tiles;
+ *   klnmf_query_f64: KLNMF_QF_MON_STAT the largest statistic of the loop (estimated relative error of a numerator entry),
+ *                    KLNMF_QF_MON_THRESHOLD the threshold it is compared with */
+#define KLNMF_Q_MON_CHECKS        10
+#define KLNMF_Q_MON_TRIPS         11
+#define KLNMF_Q_MON_GAVE_UP       12
 int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 /*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */
 #define KLNMF_QF_SUM_V            0
 /*   KLNMF_QF_NNZ_V  how many entries of the uploaded V are > 0 as stored (16-bit modes) */
 #define KLNMF_QF_NNZ_V            1
+#define KLNMF_QF_MON_STAT         2
+#define KLNMF_QF_MON_THRESHOLD    3
 int klnmf_query_f64(klnmf_ctx *ctx, int what, double *value);
 
 /* ---- measurement -------------------------------------------------------- */

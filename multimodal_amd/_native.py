@@ -12,13 +12,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KLNMF_LIB') or os.path.join(_HERE, 'csrc', 'libklnmf.so')   # KLNMF_LIB: A/B builds
 
-PREC_F64, PREC_F32, PREC_BF16, PREC_BF16_V32 = 0, 1, 2, 3
+PREC_F64, PREC_F32, PREC_BF16 = 0, 1, 2
 PRECISIONS = {'f64': PREC_F64, 'fp64': PREC_F64, 'float64': PREC_F64,
               'f32': PREC_F32, 'fp32': PREC_F32, 'float32': PREC_F32,
-              'f16': PREC_BF16, 'fp16': PREC_BF16, 'float16': PREC_BF16, 'f16_v32': PREC_BF16_V32,
-              # the 16-bit modes' historical names (their MFMA operands were bf16 in round 1; fp16 with power-of-two
+              'f16': PREC_BF16, 'fp16': PREC_BF16, 'float16': PREC_BF16,
+              # the 16-bit mode's historical name (its MFMA operands were bf16 in round 1; fp16 with power-of-two
               # scaling since: same matrix rate, 8x smaller operand rounding -- csrc/mfma.hip.h)
-              'bf16': PREC_BF16, 'bf16_v32': PREC_BF16_V32}
+              'bf16': PREC_BF16}
 DT_F32, DT_F64 = 0, 1
 STREAM_DEFAULT = (1 << 64) - 1        # KLNMF_STREAM_DEFAULT: (void *)(intptr_t)-1
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     'klnmf_loop_begin': (_c.c_int, [_ctx_p]),
     'klnmf_loop_begin_sharded': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double]),
     'klnmf_loop_begin_sharded_nnz': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double, _c.c_double]),
+    'klnmf_loop_begin_agreed': (_c.c_int, [_ctx_p, _c.c_double, _c.c_double, _c.c_double, _c.c_int]),
     'klnmf_run_more': (_c.c_int, [_ctx_p, _i64, _c.c_int, _c.c_double]),
     'klnmf_iter_rowpass': (_c.c_int, [_ctx_p, _c.c_int]),
     'klnmf_iter_decide': (_c.c_int, [_ctx_p, _c.c_double]),
@@ -234,6 +235,8 @@ def all_distances_device(dA, lda, dB, ldb, dout, na, nb, d, metric, f64=True, de
 Q_FP8_LOOP, Q_FP8_TILE_ITERS, Q_FP8_COL_ITERS, Q_RATIO_TILE_BYTES, Q_COMM_RANKS = 0, 1, 2, 3, 4
 Q_W8_SATURATED, Q_W8_FALLBACKS, Q_RATIO_SATURATED, Q_RATIO_UNFIXED = 5, 6, 7, 8
 Q_NO_NUM_EPS = 9
+Q_MON_CHECKS, Q_MON_TRIPS, Q_MON_GAVE_UP = 10, 11, 12
+QF_SUM_V, QF_NNZ_V, QF_MON_STAT, QF_MON_THRESHOLD = 0, 1, 2, 3
 
 
 def selftest(device=0):
@@ -261,7 +264,7 @@ class Context(object):
             precision = PRECISIONS[precision]
         self.precision = precision
         # the mode's canonical name (what device_data picks the fp32 / fp64 source copies by)
-        self.precision_name = {PREC_F64: 'f64', PREC_F32: 'f32', PREC_BF16: 'f16', PREC_BF16_V32: 'f16_v32'}[precision]
+        self.precision_name = {PREC_F64: 'f64', PREC_F32: 'f32', PREC_BF16: 'f16'}[precision]
         self.n = self.f = self.k = 0
         self.cap = 0
         self._pool_key = (precision, int(device)) if (pooled and stream is None and os.environ.get('KLNMF_NO_POOL') != '1') else None
@@ -471,15 +474,23 @@ class Context(object):
         nd = int(n_done.value)
         return [float(errs[i]) for i in range(min(nd, int(max_iter)))], nd, bool(stopped.value)
 
-    def loop_begin(self, sum_v_all=None, cells_all=None, nnz_all=None):
-        """klnmf_loop_begin; with the all-reduced sum of V, element count (and count of entries > 0):
-        klnmf_loop_begin_sharded(_nnz) (one rank of a row-sharded problem -- every rank then takes the same fp8 decision)."""
+    def loop_begin(self, sum_v_all=None, cells_all=None, nnz_all=None, fp8_shape_all=None):
+        """klnmf_loop_begin; with the all-reduced sum of V, element count (and count of entries > 0, and the conjunction of the
+        ranks' fp8_shape_ok()): klnmf_loop_begin_sharded(_nnz) / klnmf_loop_begin_agreed (one rank of a row-sharded problem --
+        every rank then takes the same fp8 decision)."""
         if sum_v_all is None:
             _check(self._lib.klnmf_loop_begin(self._h))
+        elif fp8_shape_all is not None:
+            _check(self._lib.klnmf_loop_begin_agreed(self._h, float(sum_v_all), float(cells_all),
+                                                     float(-1.0 if nnz_all is None else nnz_all), 1 if fp8_shape_all else 0))
         elif nnz_all is None:
             _check(self._lib.klnmf_loop_begin_sharded(self._h, float(sum_v_all), float(cells_all)))
         else:
             _check(self._lib.klnmf_loop_begin_sharded_nnz(self._h, float(sum_v_all), float(cells_all), float(nnz_all)))
+
+    def fp8_shape_ok(self):
+        """This problem's shape allows fp8 ratio tiles (klnmf_query KLNMF_Q_RATIO_TILE_BYTES == 1)."""
+        return self.query(Q_RATIO_TILE_BYTES) == 1
 
     def sum_V(self):
         """Sum of the uploaded V as stored (klnmf_query_f64 KLNMF_QF_SUM_V)."""
@@ -638,4 +649,13 @@ class Context(object):
                 'w_image_saturated': self.query(Q_W8_SATURATED), 'w_image_fallback_iterations': self.query(Q_W8_FALLBACKS),
                 'ratio_saturated': self.query(Q_RATIO_SATURATED), 'ratio_unfixed': self.query(Q_RATIO_UNFIXED),
                 # the loop's update passes formed the ratio without the numerator's eps (large-mean data; loss corrected exactly)
-                'no_numerator_eps': bool(self.query(Q_NO_NUM_EPS))}
+                'no_numerator_eps': bool(self.query(Q_NO_NUM_EPS)),
+                # the in-loop monitor (csrc/monitor.hip.h): measured relative error of the sampled H-numerator entries
+                'monitor_checks': self.query(Q_MON_CHECKS), 'monitor_trips': self.query(Q_MON_TRIPS),
+                'gave_up': bool(self.query(Q_MON_GAVE_UP)), 'monitor_statistic': self.query_f64(QF_MON_STAT),
+                'monitor_threshold': self.query_f64(QF_MON_THRESHOLD)}
+
+    def query_f64(self, what):
+        v = _c.c_double(0.0)
+        _check(self._lib.klnmf_query_f64(self._h, int(what), ctypes.byref(v)))
+        return float(v.value)

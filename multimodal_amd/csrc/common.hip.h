@@ -47,6 +47,10 @@ struct DevState {
     int q8_fix_done;   // blocks of the running fix-up launch that have finished (the last one resets the list)
     int cq_e;          // ratio scale of MEASURED images that follow klnmf_init_W (mfma.hip.h, k_ratio_scale): the dictionary image is
                        // H x 2^cq_e / t, so that W.H comes out 2^cq_e times larger and the ratio 2^cq_e times smaller; 0 otherwise
+    // ---- the fp8 monitor (monitor.hip.h; reset at every loop's entry)
+    int mon_trips;     // component rows whose statistic exceeded the threshold (any > 0: the loop gives the fp8 regime up)
+    int mon_checks;    // monitored iterations so far
+    unsigned mon_stat_bits;   // the largest statistic of the loop (bit pattern of a non-negative float)
     // prev_error as a two-entry ring for stop rules evaluated inside a multi-block launch (post.hip.h): iteration `it` reads
     // prev2[(it - 1) & 1] -- which no block of its launch writes -- and records its loss in prev2[it & 1]
     double prev2[2];
@@ -102,6 +106,7 @@ KL_GLOBAL void k_reset_state(DevState *st) {
         st->n_done = 0;
         st->w8_sat = 0; st->w8_sat_total = 0; st->w8_fallbacks = 0;
         st->q8_sat_total = 0; st->q8_list_n = 0; st->q8_unfixed = 0; st->q8_fix_done = 0;
+        st->mon_trips = 0; st->mon_checks = 0; st->mon_stat_bits = 0u;
     }
 }
 

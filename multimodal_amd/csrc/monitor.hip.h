@@ -1,0 +1,170 @@
+// The in-loop monitor of the fp8 ratio tiles: what does their e4m3 rounding do to the H numerator of THIS data?
+//
+//   H <- H * (W_new^T . Q) / norm        nmf.py:345-351, with Q = ratio of the OLD factors (nmf.py:325-336)
+//
+// From a loop's third iteration on the row pass may leave Q as e4m3 of ratio x sqrt(2) / 8 (1 byte per element of V instead
+// of 2) and the column pass may multiply an e4m3 image of W_new.  Their 3-bit significands enter ONLY the H numerator, a sum
+// over all rows: rounding noise averages out like 0.036 sqrt(2 / rows) -- unless the data defeat that: too few stored entries
+// per column, ratios that all sit inside one e4m3 step of 1 (few components on nearly noise-free data: a dead zone, not
+// noise), columns fitted so exactly that every ratio falls on one side of a rounding boundary.  Round 4 met each of these as
+// a fuzz failure (2e-4 .. 1.2e-3 off the oracle's final KL) and answered with a data rule at the loop's entry.  Round 5
+// measures instead.  On monitored iterations, for ONE column tile (32 columns, rotating with the iteration) and a sample of
+// row tiles (up to 256 x 32 rows, strided over the shard, rotating too), this kernel recomputes
+//
+//   N16[a][j] = sum_i Wimg[i][a] * q[i][j]        q = (x + eps) / (W_old . H_old + eps) from the fp32 masters, x sqrt(2)
+//   D[a][j]   = sum_i ( Wop[i][a] * held[i][j] - Wimg[i][a] * q[i][j] )
+//
+// where held = 8 x e4m3(tile byte) is what the fp8 tile holds and Wop what the column pass multiplies (the e4m3 image x its
+// scale when the fp8 x fp8 pass ran, else the f16 image Wimg): D is the error the fp8 regime puts into the numerator of
+// these entries, N16 what 16-bit tiles would have given.  (Entries >= 256 are left out: the fix-up list corrects those
+// exactly.)  The sample is kept as two halves (even / odd sampled row tiles), which k_post (post.hip.h) combines per
+// component row a over the tile's valid columns j:
+//
+//   bias^2   = sum_j D_A D_B / sum_j N_A N_B            rounding noise of the two halves is independent: it drops out
+//   noise^2  = sum_j (D_A / N_A - D_B / N_B)^2 / cols   = 2 x (relative variance of one half's numerator)
+//   stat_a^2 = max(bias^2, 0) + noise^2 / 2 x rows_half / rows_of_the_shard        (noise scaled to the FULL row sum)
+//
+// i.e. an estimate of the relative error of the full numerator's entries that does not mistake the sample's own noise for
+// a defect.  max_a stat_a above kMonThreshold makes the loop give the fp8 regime up (the host polls DevState.mon_trips with
+// the saturation counters; on row shards the count rides in the loss exchange, so that every rank decides alike).
+//
+// Cost: the kernel reads 256 x 32 rows of W_old (fp32), W_new (f16, e4m3) and one 32-column tile of V, H_old and the ratio
+// tiles -- 13 MB at k = 200 -- and writes 128 x [2 halves][2][KP][32] partial sums (15 MB, read back by k_post), on the first
+// four fp8 iterations and every eighth after them (measured: DESIGN.md section 5).  The row pass -- the headline kernel -- is not touched: the 16-bit ratio is
+// recomputed from the masters here instead of being stored by it.
+#pragma once
+#include "colq8x.hip.h"
+
+namespace klnmf {
+
+constexpr int kMonBlocks = 128;                  // blocks of the monitor launch = row tile PAIRS sampled (one tile per half)
+constexpr float kMonThreshold = 2.0e-3f;         // on stat_a (see above); calibrated in round 5: profiles/r05_monitor_calibration.txt
+
+struct MonArgs {
+    const DevState *st;
+    const unsigned char *Qt;      // fp8 ratio tiles [col tile][row tile][32 rows][32 physical columns]
+    const _Float16 *VtA;          // piece-major 32 x 32 tiles (k_tile_V)
+    const float *W32_old;         // [n_pad][KP]
+    const float *H_old;           // [KP][f_pad]
+    const opnd_t *Wb_new;         // [rows][wld] swizzled f16 image of W_new
+    const unsigned char *W8;      // e4m3 image of W_new if this iteration's column pass multiplies it, else nullptr
+    const float *w8s;             // [KP]
+    float *part;                  // [kMonBlocks][2 halves][2 (N16, D)][KP][32]
+    int nrt, nct, kp, k, wld, w8ld;   // nrt / nct: row / column tiles of the tiled buffers (layout)
+    int nrt_data;                 // row tiles that hold data (the sample's range)
+    int64_t f_pad;
+    int ct;                       // the monitored column tile
+    int ncols;                    // its valid columns (1 .. 32)
+    int nsamp;                    // sampled row tiles (<= kMonBlocks * 2, even)
+    int rot;                      // rotation of the sample (row tiles)
+    float eps;                    // c * 1e-8
+};
+
+// row tile of sample s (0 .. nsamp - 1): strided over the shard, rotated
+__device__ __forceinline__ int mon_row_tile(const MonArgs &a, int s) {
+    return (int)((((int64_t)s * a.nrt_data) / a.nsamp + a.rot) % a.nrt_data);
+}
+
+__global__ __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
+    if (a.st->stop) return;
+    constexpr int AC = 128;                                   // components per staged chunk
+    __shared__ float Hs[AC][32];                              // H_old[a0 + .][tile columns]
+    __shared__ float Ws[32][AC + 4];                          // W_old[row][a0 + .]
+    __shared__ __attribute__((aligned(16))) float Qs[32][32]; // q x sqrt(2) of the current row tile (0 where masked)
+    __shared__ __attribute__((aligned(16))) float Hd[32][32]; // held
+    const int tid = threadIdx.x;
+    const int i = tid >> 3, c4 = (tid & 7) * 4;              // phase A: this thread's row and first column of the tile
+    const bool used_w8 = a.W8 != nullptr && a.st->w8_sat == 0;      // (a clipped image: the f16-operand pass runs in its place)
+    for (int half = 0; half < 2; ++half) {
+        const int s = 2 * (int)blockIdx.x + half;
+        float n16[2][32], dd[2][32];                          // phase B accumulators: components tid and tid + 256
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { n16[g][j] = 0.f; dd[g][j] = 0.f; }
+        if (s < a.nsamp) {
+            const int rt = mon_row_tile(a, s);
+            const int64_t row0 = (int64_t)rt * 32;
+            // ---- phase A: the exact ratio of the tile's 32 x 32 entries from the masters
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int a0 = 0; a0 < a.k; a0 += AC) {
+                __syncthreads();
+                for (int e = tid; e < AC * 32; e += 256) {
+                    const int aa = e >> 5, jj = e & 31;
+                    Hs[aa][jj] = (a0 + aa < a.k) ? a.H_old[(int64_t)(a0 + aa) * a.f_pad + (int64_t)a.ct * 32 + jj] : 0.f;
+                }
+                for (int e = tid; e < 32 * AC; e += 256) {
+                    const int ii = e / AC, aa = e % AC;
+                    Ws[ii][aa] = (a0 + aa < a.k) ? a.W32_old[(row0 + ii) * a.kp + a0 + aa] : 0.f;
+                }
+                __syncthreads();
+                const int na = min(AC, a.k - a0);
+                for (int aa = 0; aa < na; ++aa) {
+                    const float w = Ws[i][aa];
+                    const f32x4 h4 = *(const f32x4 *)&Hs[aa][c4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d[t] = fmaf(w, h4[t], d[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cc = c4 + t;
+                const int laneA = i + 32 * ((cc >> 2) & 1), eA = 4 * (cc >> 3) + (cc & 3);
+                const float x = (float)a.VtA[((int64_t)rt * a.nct + a.ct) * 1024 + (eA >> 3) * 512 + laneA * 8 + (eA & 7)];
+                const int pcol = 16 * ((cc >> 2) & 1) + 4 * (cc >> 3) + (cc & 3);      // physical column of logical column cc (mfma4.hip.h, Q8)
+                const unsigned byte = a.Qt[((int64_t)a.ct * a.nrt + rt) * 1024 + i * 32 + pcol];
+                const bool take = cc < a.ncols && byte < 0x60u;
+                const float rinv = 1.f / (d[t] + a.eps);
+                Qs[i][cc] = take ? fmaf(x, rinv, a.eps * rinv) * kQ8Mid : 0.f;
+                Hd[i][cc] = take ? kQ8Scale * e4m3_value(byte) : 0.f;
+            }
+            __syncthreads();
+            // ---- phase B: the two numerators of this row tile, thread = component
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int comp = tid + 256 * g;
+                if (comp < a.k) {
+                    for (int ii = 0; ii < 32; ++ii) {
+                        const int64_t row = row0 + ii;
+                        const float wimg = (float)a.Wb_new[row * a.wld + wb_col(ii, comp)];
+                        const float wop = used_w8 ? e4m3_value(a.W8[row * a.w8ld + comp]) * a.w8s[comp] : wimg;
+#pragma unroll
+                        for (int j4 = 0; j4 < 32; j4 += 4) {
+                            const f32x4 q4 = *(const f32x4 *)&Qs[ii][j4], h4 = *(const f32x4 *)&Hd[ii][j4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float ref = wimg * q4[t];
+                                n16[g][j4 + t] += ref;
+                                dd[g][j4 + t] += fmaf(wop, h4[t], -ref);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // this half's partial sums (zeros for a block beyond the sample: k_post sums all blocks)
+        float *pb = a.part + ((int64_t)blockIdx.x * 2 + half) * 2 * (int64_t)a.kp * 32;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int comp = tid + 256 * g;
+            if (comp < a.kp) {
+#pragma unroll
+                for (int j4 = 0; j4 < 32; j4 += 4) {
+                    *(f32x4 *)(pb + (int64_t)comp * 32 + j4) = f32x4{n16[g][j4], n16[g][j4 + 1], n16[g][j4 + 2], n16[g][j4 + 3]};
+                    *(f32x4 *)(pb + ((int64_t)a.kp + comp) * 32 + j4) = f32x4{dd[g][j4], dd[g][j4 + 1], dd[g][j4 + 2], dd[g][j4 + 3]};
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// What k_post needs to turn the partial sums into the statistic (post.hip.h)
+struct MonPost {
+    const float *part;            // [kMonBlocks][2 halves][2][KP][32]; nullptr: no check in this launch
+    int ncols;                    // valid columns of the monitored tile
+    float noise_scale;            // rows of one half of the sample / rows of this shard (<= 0.5)
+    float threshold;
+};
+
+}  // namespace klnmf

@@ -1,5 +1,5 @@
 // Hardware self-checks for the layout facts the fused kernels rely on
-// (gfx950): MFMA 32x32x16 bf16 operand/accumulator maps, ds_read_b64_tr_b16
+// (gfx950): MFMA 32x32x16 f16 operand/accumulator maps, ds_read_b64_tr_b16
 // addressing, "accumulator tile as the next MFMA's B operand" k-permutation,
 // and global_load_lds lane-linear destination.  Exact small-integer data.
 #pragma once
@@ -8,6 +8,24 @@
 #include "mfma.hip.h"
 
 namespace klnmf {
+
+// a padded 64-column image row for the transposed-read probe (144 B = 36 dwords)
+constexpr int kHRow = 64 + 8, kHRowB = kHRow * 2;
+// two ds_read_b64_tr_b16: each gives this lane one column of a 4-row x 16-col block
+__device__ __forceinline__ opx8 tr_pair(const KL_LDS unsigned char *p0, const KL_LDS unsigned char *p1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((KL_LDS s16x4 *)p1);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(opx8, v);
+}
+// `rounds` x 8 KiB from global to LDS with global_load_lds_dwordx4 (LDS image == global image; destination is the
+// wave-uniform base + lane * 16)
+__device__ __forceinline__ void glds_copy(const unsigned char *gsrc, KL_LDS unsigned char *ldst, int rounds, int tid) {
+    const int wave_base = (tid & ~63) * 16;
+    for (int r = 0; r < rounds; ++r)
+        __builtin_amdgcn_global_load_lds((const KL_GLB void *)(gsrc + r * kGldsRound + tid * 16),
+                                         (KL_LDS void *)(ldst + r * kGldsRound + wave_base), 16, 0, 0);
+}
 
 // P1: D = A[32x16] . B[16x32] through the documented fragment maps.
 __global__ void k_probe_mfma(const float *A, const float *B, float *D) {

@@ -51,7 +51,7 @@ class ShardedKLNMF(object):
     Parameters
     ----------
     n_total, f, k : global problem shape (this rank holds `n_local` rows).
-    precision     : 'bf16' | 'bf16_v32' | 'f32' | 'f64'
+    precision     : 'f16' (= 'bf16') | 'f32' | 'f64'
     group         : torch.distributed process group or None (single process).
     backend       : context object; default = a HIP `_native.Context` on the
                     current torch device / stream.
@@ -180,19 +180,23 @@ class ShardedKLNMF(object):
             # klnmf_run_sharded does on the native path.  ONE all-reduce carries [sum V, cells, refusal flag, entries > 0]: a rank whose
             # own sum cannot be read joins it with zeros and its flag set, so no rank is ever alone in a collective of
             # another shape
-            vals = [0.0, 0.0, 0.0, 0.0]
+            # [4]: "this shard's shape does not allow fp8 ratio tiles" -- shards can straddle the row threshold, and ranks must
+            # not mix tile formats (their numerators differ by sqrt(2)): any rank without them keeps all on 16-bit tiles
+            vals = [0.0, 0.0, 0.0, 0.0, 0.0]
             try:
                 cells = float(self.n_local) * float(self.f)
-                # (entries > 0: fp8 tiles need enough of them per column; a context that cannot count them reports a dense shard)
+                # (entries > 0: a context that cannot count them reports a dense shard)
                 nnz = self.ctx.nnz_V() if hasattr(self.ctx, 'nnz_V') else cells
-                vals = [self.ctx.sum_V(), cells, 0.0, nnz]
+                no_fp8 = 0.0 if (not hasattr(self.ctx, 'fp8_shape_ok') or self.ctx.fp8_shape_ok()) else 1.0
+                vals = [self.ctx.sum_V(), cells, 0.0, nnz, no_fp8]
             except Exception as e:
-                err, vals = e, [0.0, 0.0, 1.0, 0.0]
+                err, vals = e, [0.0, 0.0, 1.0, 0.0, 0.0]
             t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.tensor_device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             if err is None and float(t[2].item()) == 0.0:
                 try:
-                    self.ctx.loop_begin(float(t[0].item()), float(t[1].item()), float(t[3].item()))
+                    self.ctx.loop_begin(float(t[0].item()), float(t[1].item()), float(t[3].item()),
+                                        fp8_shape_all=(float(t[4].item()) == 0.0))
                 except Exception as e:         # (reported below, on every rank)
                     err = e
             elif err is None:

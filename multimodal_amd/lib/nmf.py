@@ -22,9 +22,8 @@ the loss is recorded before each update and the breaking iteration's loss is not
 appended (q5, nmf.py:214-220).
 
 Extra (non-reference) constructor arguments: `precision` ('f64' default =
-the reference's float64 arithmetic; 'f32'; 'bf16' = MFMA fast path with V stored
-as power-of-two-scaled fp16; 'bf16_v32' = same kernels with V stored fp32),
-`device`.  Environment: KLNMF_PRECISION, KLNMF_DEVICE.
+the reference's float64 arithmetic; 'f32'; 'f16' (= 'bf16') = MFMA fast path with V
+stored as power-of-two-scaled fp16; 'auto'), `device`.  Environment: KLNMF_PRECISION, KLNMF_DEVICE.
 """
 import os
 import sys
@@ -67,9 +66,9 @@ def resolve_precision(precision, n, f, k):
     if precision == 'auto':
         precision = 'f16' if float(n) * float(f) * float(k) >= AUTO_F16_WORK else 'f64'
     code = _native.PRECISIONS[precision]
-    if (code == _native.PREC_BF16 and k > MAX_K_MFMA) or (code == _native.PREC_BF16_V32 and k > 256):      # (fp32-stored V: generation-1 kernels)
+    if code == _native.PREC_BF16 and k > MAX_K_MFMA:
         _note_once(('k', precision), "KLdivNMF: precision=%r holds k <= %d; k = %d runs on the fp32 kernels (precision='f32')\n"
-                   % (precision, MAX_K_MFMA if code == _native.PREC_BF16 else 256, k))
+                   % (precision, MAX_K_MFMA, k))
         return 'f32'
     return precision
 

@@ -295,7 +295,7 @@ class NoSumContext(OracleContext):
             raise RuntimeError("klnmf error -4: hipMemcpyAsync: device lost")
         return float(self.V.sum())
 
-    def loop_begin(self, sum_all=None, cells_all=None, nnz_all=None):
+    def loop_begin(self, sum_all=None, cells_all=None, nnz_all=None, fp8_shape_all=None):
         OracleContext.loop_begin(self)
 
 
@@ -395,8 +395,13 @@ class CountingContext(OracleContext):
     def nnz_V(self):
         return float((self.V > 0).sum())
 
-    def loop_begin(self, sum_all=None, cells_all=None, nnz_all=None):
-        self.entry = (sum_all, cells_all, nnz_all)
+    fp8_ok = True            # this shard's SHAPE allows fp8 ratio tiles (klnmf_query KLNMF_Q_RATIO_TILE_BYTES == 1)
+
+    def fp8_shape_ok(self):
+        return self.fp8_ok
+
+    def loop_begin(self, sum_all=None, cells_all=None, nnz_all=None, fp8_shape_all=None):
+        self.entry = (sum_all, cells_all, nnz_all, 1.0 if fp8_shape_all else 0.0)
         OracleContext.loop_begin(self)
 
 
@@ -411,6 +416,7 @@ def _nnz_worker(rank, world, port, out_dir):
         X[:40] *= (np.random.RandomState(3).random_sample((40, f)) < 0.1)      # the first shard is sparse, the second dense
         r0, r1 = row_partition(n, world)[rank]
         ctx = CountingContext()
+        ctx.fp8_ok = rank != world - 1 or world == 1 or out_dir.endswith('all_ok')      # the last shard is "too short" unless told otherwise
         m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=2, backend=ctx)
         m.set_v_max(X.max()); m.upload_V(X[r0:r1]); m.set_H(orc.synthetic_H0(77, f, k)); m.init_W()
         m.run(2, fit=True, tol=0.0)
@@ -431,4 +437,13 @@ def test_every_rank_enters_the_loop_with_the_global_count_of_entries(tmp_path):
     X[:40] *= (np.random.RandomState(3).random_sample((40, f)) < 0.1)
     got = [np.load(os.path.join(str(tmp_path), 'r%d.npy' % r)) for r in range(2)]
     np.testing.assert_array_equal(got[0], got[1])
-    np.testing.assert_allclose(got[0], [X.sum(), n * f, (X > 0).sum()], rtol=1e-12)
+    # [3]: the conjunction of the ranks' "my shard's shape allows fp8 ratio tiles" (round 5, klnmf_loop_begin_agreed): shards can
+    # straddle the row threshold, and one rank on 16-bit tiles while the others sum fp8-tile numerators (sqrt(2) larger) would
+    # corrupt the H rule silently -- here the last rank lacks the shape, so NO rank may take the tiles
+    np.testing.assert_allclose(got[0], [X.sum(), n * f, (X > 0).sum(), 0.0], rtol=1e-12)
+    ok_dir = os.path.join(str(tmp_path), 'all_ok')
+    os.makedirs(ok_dir)
+    mp.spawn(_nnz_worker, args=(2, _free_port(), ok_dir), nprocs=2, join=True)
+    got = [np.load(os.path.join(ok_dir, 'r%d.npy' % r)) for r in range(2)]
+    np.testing.assert_array_equal(got[0], got[1])
+    assert got[0][3] == 1.0

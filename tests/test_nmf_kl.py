@@ -123,24 +123,20 @@ def test_config3_shape_bf16_final_kl():
 @pytest.mark.gpu
 def test_config4_k500_three_modalities():
     """k = 500 (KT = 16 component tiles): the bf16 mode runs the 4-wave workgroups of the ping-pong row pass
-    (the whole register file per wave) and the component-split column pass; bf16_v32 (fp32-stored V, generation-1
-    kernels) refuses beyond 256 components instead of silently changing arithmetic; the fp32 mode runs the same
-    loop on the exact kernels."""
+    (the whole register file per wave) and the component-split column pass; beyond 512 components the C-ABI refuses
+    instead of silently changing arithmetic; the fp32 mode runs the same loop on the exact kernels."""
     n, dims, k, iters = 256, [192, 128, 64], 500, 3
     blocks = [orc.synthetic_V(41 + i, n, d, 16) for i, d in enumerate(dims)]
     V = orc.stack_modalities(blocks, [1.0, 1.0, 1.0])
     H0 = orc.synthetic_H0(41, sum(dims), k)
-    # the C-ABI refuses what its 16-bit kernels cannot hold (fp32-stored V: k > 256; fp16-stored: k > 512) ...
-    for prec, kk in (('bf16_v32', k), ('bf16', 513)):
-        with _native.Context(prec, device=0) as ctx:
-            with pytest.raises(_native.NativeError) as ei:
-                ctx.set_problem(n, sum(dims), kk, iters)
-            assert 'k > 256' in str(ei.value)
+    # the C-ABI refuses what its 16-bit kernels cannot hold (k > 512) ...
+    with _native.Context('bf16', device=0) as ctx:
+        with pytest.raises(_native.NativeError) as ei:
+            ctx.set_problem(n, sum(dims), 513, iters)
+        assert 'k > 512' in str(ei.value)
     Wo, Ho, eo = orc.fit_transform(V, k=k, H0=H0, max_iter=iters, tol=0)
     fo = orc.kl_error(V, Wo, Ho)
-    # ... and KLdivNMF then runs such a problem on the fp32 kernels of the library (round 3: resolve_precision) instead of raising
-    m, W, e = _fit(V, H0, k, iters, 'bf16_v32')
-    assert_allclose(e, eo, rtol=2e-5)
+    # ... and KLdivNMF then runs such a problem on the fp32 kernels of the library (resolve_precision: tests/test_gpu_parity.py)
     m, W, e = _fit(V.astype(np.float32), H0, k, iters, 'f32')
     assert_allclose(e, eo, rtol=2e-4)
     assert abs(m.error(V, W) - fo) <= KL_TOL * fo
