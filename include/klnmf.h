@@ -319,6 +319,13 @@ int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 #define KLNMF_QF_NNZ_V            1
 #define KLNMF_QF_MON_STAT         2
 #define KLNMF_QF_MON_THRESHOLD    3
+/*   KLNMF_QF_MON_PART0 + 0 / 1 / 2: the statistic's ingredients, largest of the loop each (diagnostics: uncentred bias, noise
+ *   term scaled to the full row count, |common factor of a component row over the monitored tile|) */
+#define KLNMF_QF_MON_PART0        4
+/*   KLNMF_QF_MON_SPREAD the smallest relative spread std(q) / mean(q) of a monitored column's ratios in the loop (the e4m3
+ *   rounding only averages out over the rows if the ratios are spread over its cells), KLNMF_QF_MON_MIN_SPREAD its threshold */
+#define KLNMF_QF_MON_SPREAD       7
+#define KLNMF_QF_MON_MIN_SPREAD   8
 int klnmf_query_f64(klnmf_ctx *ctx, int what, double *value);
 
 /* ---- measurement -------------------------------------------------------- */

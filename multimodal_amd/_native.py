@@ -653,7 +653,9 @@ class Context(object):
                 # the in-loop monitor (csrc/monitor.hip.h): measured relative error of the sampled H-numerator entries
                 'monitor_checks': self.query(Q_MON_CHECKS), 'monitor_trips': self.query(Q_MON_TRIPS),
                 'gave_up': bool(self.query(Q_MON_GAVE_UP)), 'monitor_statistic': self.query_f64(QF_MON_STAT),
-                'monitor_threshold': self.query_f64(QF_MON_THRESHOLD)}
+                'monitor_threshold': self.query_f64(QF_MON_THRESHOLD),
+                'monitor_parts': [self.query_f64(4 + i) for i in range(3)],
+                'monitor_min_spread': self.query_f64(7), 'monitor_spread_threshold': self.query_f64(8)}
 
     def query_f64(self, what):
         v = _c.c_double(0.0)

@@ -51,6 +51,8 @@ struct DevState {
     int mon_trips;     // component rows whose statistic exceeded the threshold (any > 0: the loop gives the fp8 regime up)
     int mon_checks;    // monitored iterations so far
     unsigned mon_stat_bits;   // the largest statistic of the loop (bit pattern of a non-negative float)
+    unsigned mon_spread_bits; // the smallest relative spread of a monitored column's ratios seen in the loop (bit pattern of a float >= 0)
+    unsigned mon_dbg[3];      // its ingredients, largest of the loop each: uncentred bias, noise term, |common factor - 1| of a row
     // prev_error as a two-entry ring for stop rules evaluated inside a multi-block launch (post.hip.h): iteration `it` reads
     // prev2[(it - 1) & 1] -- which no block of its launch writes -- and records its loss in prev2[it & 1]
     double prev2[2];
@@ -106,7 +108,7 @@ KL_GLOBAL void k_reset_state(DevState *st) {
         st->n_done = 0;
         st->w8_sat = 0; st->w8_sat_total = 0; st->w8_fallbacks = 0;
         st->q8_sat_total = 0; st->q8_list_n = 0; st->q8_unfixed = 0; st->q8_fix_done = 0;
-        st->mon_trips = 0; st->mon_checks = 0; st->mon_stat_bits = 0u;
+        st->mon_trips = 0; st->mon_checks = 0; st->mon_stat_bits = 0u; st->mon_dbg[0] = st->mon_dbg[1] = st->mon_dbg[2] = 0u; st->mon_spread_bits = 0x3f800000u;
     }
 }
 

@@ -186,6 +186,7 @@ struct DevSwitches {
     bool q8_fixup = true;       // KLNMF_Q8_FIXUP=0: no exact correction of large ratio entries (the tests' control run)
     bool q8_rules_r4 = false;   // KLNMF_Q8_RULES=1: round 4's data rules at the loop's entry as well as the in-loop monitor (A/B runs)
     bool q8_monitor = true;     // KLNMF_Q8_MONITOR=0: no monitor
+    float mon_threshold = 0.f, mon_min_spread = -1.f;      // KLNMF_MON_THRESHOLD / KLNMF_MON_MIN_SPREAD: the monitor's two thresholds (calibration runs)
     bool ratio_scale = true;    // KLNMF_RATIO_SCALE=0: no ratio scale of the first update
     bool eps_pad = true;        // KLNMF_NO_EPS_PAD=1: eps added in the epilogue instead of riding through MFMA-1
     int row_split = -1;         // KLNMF_ROW_SPLIT = 0 / N: column-split update pass off / N chunks
@@ -205,6 +206,8 @@ struct DevSwitches {
         d.q8_fixup = num("KLNMF_Q8_FIXUP", 1) != 0;
         d.q8_rules_r4 = num("KLNMF_Q8_RULES", 0) != 0;
         d.q8_monitor = num("KLNMF_Q8_MONITOR", 1) != 0;
+        if (const char *e = std::getenv("KLNMF_MON_THRESHOLD")) d.mon_threshold = (float)std::atof(e);
+        if (const char *e = std::getenv("KLNMF_MON_MIN_SPREAD")) d.mon_min_spread = (float)std::atof(e);
         d.ratio_scale = num("KLNMF_RATIO_SCALE", 1) != 0;
         d.eps_pad = num("KLNMF_NO_EPS_PAD", 0) == 0;
         d.row_split = num("KLNMF_ROW_SPLIT", -1);
@@ -294,11 +297,14 @@ struct klnmf_ctx {
     int64_t stat_w8_sat = 0, stat_w8_fallbacks = 0, stat_q8_sat = 0, stat_q8_unfixed = 0;
     // ---- the fp8 monitor (monitor.hip.h): partial sums of the monitored iteration; what k_post is to do with them; the last
     // loop's record (klnmf_query / klnmf_query_f64)
-    float *mon_part = nullptr;
+    float *mon_part = nullptr, *mon_spread = nullptr;
     bool mon_pending = false;                 // this iteration's first summing launch turns the partial sums into the statistic
+    bool mon_dry_pending = false;             // ... and it was the dry run of the loop's second iteration: poll before the third
     int mon_ncols = 0; float mon_noise_scale = 0.f;
     int64_t mon_checks = 0, stat_mon_checks = 0, stat_mon_trips = 0;
-    double stat_mon_max = 0.0;
+    int64_t loop_planned = 0;                 // iterations this loop may run (klnmf_run: max_iter; loops in pieces: the capacity of
+                                              // klnmf_set_problem): the monitor's threshold depends on it (monitor.hip.h)
+    double stat_mon_max = 0.0, stat_mon_dbg[3] = {0, 0, 0}, stat_mon_spread = 1.0;
     bool stat_mon_gave_up = false;
     // the refusal counters of DevState (v_overflow, op_range) change only on uploads and image measurements: they are read
     // back (one copy + synchronisation) only when one of those happened since the last check
@@ -649,18 +655,27 @@ void monitor_setup(klnmf_ctx *c) {
     c->mon_pending = false;
     if (!c->q8_ok) return;
     c->mon_part = (float *)c->dalloc((size_t)kMonBlocks * 2 * 2 * c->KP * 32 * 4);
+    c->mon_spread = (float *)c->dalloc((size_t)kMonBlocks * 96 * 4);
 }
-// fp8 iterations 1 .. 4 of a loop and every eighth after them (the defects it looks for are properties of the data and of the
-// fit's state, which moves slowly); the poll that acts on it keeps the same cadence (poll_fp8_overflow)
-bool monitor_due(int64_t n8) { return n8 >= 1 && (n8 <= 4 || (n8 & 7) == 0); }
+// When: DRY on a loop's second iteration (16-bit tiles still: the e4m3 bytes are formed by the monitor itself -- the loop enters
+// the fp8 regime only if that measurement passes), then on fp8 iterations 1 (the first with the real tiles and the e4m3 W
+// image), 2, 3, 4, 6, 8, 12, 16 and every eighth after that: dead zones open as the fit converges (ratios gather inside one e4m3
+// step of 1), within a few iterations on small problems, and move slowly afterwards; the poll that acts on the result keeps the
+// same cadence (poll_fp8_overflow)
+bool monitor_due(int64_t n8) { return (n8 >= 1 && n8 <= 4) || n8 == 6 || n8 == 12 || (n8 >= 8 && (n8 & 7) == 0); }
 // behind the row pass (and the conversion of the e4m3 W image) of a fit iteration on fp8 tiles, before its column pass
 void launch_monitor(klnmf_ctx *c, bool use8) {
     c->mon_pending = false;
-    if (!c->mon_part || !c->sw.q8_monitor || !c->q8() || c->in_capture) return;
-    if (!monitor_due(c->stat_q8_tiles)) return;
+    c->mon_dry_pending = false;
+    if (!c->mon_part || !c->sw.q8_monitor || !c->q8_loop || c->in_capture) return;
+    const bool dry = c->iter_in_loop == 1 && !c->q8();
+    if (!dry && !(c->q8() && monitor_due(c->stat_q8_tiles))) return;
     MonArgs a{};
     a.st = c->st; a.Qt = c->Qt; a.VtA = (const _Float16 *)c->VtA; a.W32_old = c->W32[c->cur]; a.H_old = c->H32;
-    a.Wb_new = c->Wb[c->cur ^ 1]; a.W8 = use8 ? c->W8 : nullptr; a.w8s = c->w8s; a.part = c->mon_part;
+    a.Wb_new = c->Wb[c->cur ^ 1]; a.W8 = (use8 && !dry) ? c->W8 : nullptr; a.w8s = c->w8s; a.part = c->mon_part;
+    a.spread = c->mon_spread;
+    a.dry = dry ? 1 : 0;
+    a.w8tab = (dry && c->W8 != nullptr && c->conv_ran) ? c->w8tab : nullptr;
     a.nrt = c->nrt; a.nct = c->nct; a.kp = c->KP; a.k = (int)c->k; a.wld = (int)w_ld(c->KP); a.w8ld = (int)w8_ld(c->KP);
     a.f_pad = c->f_pad;
     const int tiles = (int)((c->f + 31) / 32);                       // column tiles that hold data
@@ -674,6 +689,7 @@ void launch_monitor(klnmf_ctx *c, bool use8) {
     hipLaunchKernelGGL(k_q8_monitor, dim3(kMonBlocks), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     c->mon_pending = true;
+    c->mon_dry_pending = dry;
     c->mon_ncols = a.ncols;
     c->mon_noise_scale = (float)std::min(0.5, (double)(a.nsamp / 2) * 32.0 / (double)c->n);
     c->mon_checks += 1;
@@ -769,9 +785,11 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     a.w8_block = (a.do_sum && last_sum && c->conv_ran && c->w8tab != nullptr) ? 1 : 0;
     a.last_sum = (a.do_sum && last_sum) ? 1 : 0;
     a.it = (int)(c->iter_in_loop & 1);
-    a.mon = MonPost{nullptr, 0, 0.f, kMonThreshold};
+    a.mon = MonPost{nullptr, nullptr, kMonMinSpread, kMonMaxCommon, 0, 0.f, kMonThreshold};
     if (a.do_sum && c->mon_pending) {
-        a.mon = MonPost{c->mon_part, c->mon_ncols, c->mon_noise_scale, kMonThreshold};
+        a.mon = MonPost{c->mon_part, c->mon_spread, c->sw.mon_min_spread >= 0.f ? c->sw.mon_min_spread : kMonMinSpread,
+                        c->sw.mon_threshold > 0.f ? 1.0f : kMonMaxCommon, c->mon_ncols,
+                        c->mon_noise_scale, c->sw.mon_threshold > 0.f ? c->sw.mon_threshold : mon_threshold_for((float)c->loop_planned)};
         c->mon_pending = false;
     }
     a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne; a.cq_on = la.cq_on;
@@ -876,9 +894,10 @@ void measure_and_pack(klnmf_ctx *c, bool from_init = false) {
 // replicas of H would drift apart): the count travels as the second double of the loss exchange -- every loss launch leaves
 // this rank's q8_unfixed in loss_xchg[1], the all-reduce (native or torch) sums it -- and `agreed` polls read that sum.
 void poll_fp8_overflow(klnmf_ctx *c, bool agreed = false) {
-    if (!c->q8_loop || !c->q8() || c->in_capture) return;
-    const int64_t n8 = c->stat_q8_tiles;
-    if (!monitor_due(n8)) return;
+    if (!c->q8_loop || c->in_capture) return;
+    const bool dry = c->mon_dry_pending;          // the dry run of the iteration just enqueued decides whether the next one takes fp8 tiles
+    c->mon_dry_pending = false;
+    if (!dry && !(c->q8() && monitor_due(c->stat_q8_tiles))) return;
     if (agreed) {
         double h[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(h, c->loss_xchg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -1189,6 +1208,8 @@ void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopp
     c->stat_q8_sat = hs.q8_sat_total; c->stat_q8_unfixed = hs.q8_unfixed;
     c->stat_mon_checks = hs.mon_checks; c->stat_mon_trips = hs.mon_trips;
     { float m; std::memcpy(&m, &hs.mon_stat_bits, 4); c->stat_mon_max = (double)m; }
+    for (int i = 0; i < 3; ++i) { float m; std::memcpy(&m, &hs.mon_dbg[i], 4); c->stat_mon_dbg[i] = (double)m; }
+    { float m; std::memcpy(&m, &hs.mon_spread_bits, 4); c->stat_mon_spread = (double)m; }
     // the current W is the one the last *executed* update wrote
     c->cur = (c->loop_start_cur + (int)(hs.n_done & 1)) & 1;
     // ... and so is the current dictionary master: k_post swaps H32 / H32alt per ENQUEUED H rule, the device performed
@@ -1556,7 +1577,9 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             // KLNMF_QTILE = 8 / 16 forces either), where the bytes matter
             const bool col8_off = c->sw.col8 == 0;
             const bool q8_kt = !c->big || !col8_off;      // (k > 224: fp8 tiles only with the fp8 x fp8 column pass)
-            c->q8_ok = q8_kt && c->row_chunks_possible_q8(n, c->big);
+            // ... and from one column tile of data on: below that the tiles are mostly padding (nothing to gain), and a handful of
+            // columns is fitted so exactly that the loss itself goes to 0 (the 16-bit mode's own operand rounding then shows)
+            c->q8_ok = q8_kt && f >= 32 && c->row_chunks_possible_q8(n, c->big);
             if (c->sw.qtile != 0) c->q8_ok = q8_kt && c->sw.qtile == 8;
             c->q8_loop = false;
             c->iter_in_loop = 0;
@@ -2027,8 +2050,10 @@ static void raise_refusals(klnmf_ctx *c, const Refusals &r) {
 static void check_v_overflow(klnmf_ctx *c) { raise_refusals(c, read_refusals(c)); }
 
 // Loop entry points only (klnmf_run, klnmf_run_sharded, klnmf_loop_begin): may THIS loop use fp8 ratio tiles (e4m3 of
-// ratio x sqrt(2) / 8, from its third iteration on)?  Three things decide, in this order:
+// ratio x sqrt(2) / 8, from its third iteration on)?  Four things decide, in this order:
 //   shape   q8_ok of klnmf_set_problem: enough rows per context that the tiles' bytes matter (32 769 / 65 536);
+//   length  at most kQ8MaxLoop (50) planned iterations -- klnmf_run's max_iter, the capacity of klnmf_set_problem for loops in
+//           pieces: what the e4m3 rounding does to the loss grows with the square of the iteration count (monitor.hip.h);
 //   range   the tiles end at 3584 / sqrt(2) (saturating): data whose largest entry is more than 256 times the mean entry can hold
 //           ratios beyond that for many iterations (a spike the model has not fitted yet) -- those keep the 16-bit tiles.  What
 //           still saturates in a loop that passed is corrected exactly (fix-up list) or, in bulk, ends the fp8 regime;
@@ -2042,8 +2067,9 @@ static void check_v_overflow(klnmf_ctx *c) { raise_refusals(c, read_refusals(c))
 // context's own.  `ok_all`: the conjunction of every rank's q8_ok (shards that straddle the row threshold must not mix tile
 // formats: since round 4 fp8-tile numerators are sqrt(2) larger than 16-bit-tile ones); negative: this context's own.
 static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cells_global = -1.0, double nnz_global = -1.0,
-                           int ok_all = -1) {
+                           int ok_all = -1, int64_t planned = -1) {
     c->sw = DevSwitches::read();
+    c->loop_planned = planned > 0 ? planned : std::max<int64_t>(1, c->cap);
     c->q8_loop = false;
     c->iter_in_loop = 0;
     c->w8_meas = false;
@@ -2053,6 +2079,7 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     c->last_row_ne = false;
     c->mon_checks = 0;
     c->mon_pending = false;
+    c->mon_dry_pending = false;
     c->stat_mon_gave_up = false;
     if (c->is_exact() || !c->q8_ok || ok_all == 0) return;
     if (c->W8 != nullptr && c->w8tab != nullptr) {
@@ -2082,10 +2109,11 @@ static void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cell
     if (nnz < 0) nnz = cells;                 // (a caller that all-reduced only the two sums: dense data assumed)
     const double mean = sum_x / c->v_scale / cells;
     c->q8_loop = c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean;
+    if (c->loop_planned > kQ8MaxLoop) c->q8_loop = false;      // length: see monitor.hip.h
     if (c->sw.q8_rules_r4) {
         // round 4's data rules (kept for A/B runs against the monitor): fewer than four components or less than one column tile
         // of data (dead zones of the e4m3 step around ratio 1), fewer stored entries per column than half the row threshold
-        if (c->k < 4 || c->f < 32) c->q8_loop = false;
+        if (c->k < 4) c->q8_loop = false;
         if (nnz / (double)c->f < 0.5 * (c->big ? 65536.0 : 32768.0)) c->q8_loop = false;
     }
     // The ratio without the numerator's eps (NE kernels, k <= 224): x / (W.H + eps) differs from the reference's
@@ -2106,7 +2134,7 @@ static bool comm_multi(const klnmf_ctx *c) { return c->comm != nullptr && (c->co
 // Loop entry.  Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
 // (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8 decision
 // is taken from the all-reduced sums, so that all ranks run the same kernels and N = 1 / N = 8 differ by summation order only.
-static void comm_loop_entry(klnmf_ctx *c) {
+static void comm_loop_entry(klnmf_ctx *c, int64_t planned = -1) {
     if (c->sparse) fail(KLNMF_ERR_UNSUPP, "loops on a communicator: dense problems only");
     c->refusals_dirty = true;
     const Refusals mine = read_refusals(c);
@@ -2132,7 +2160,7 @@ static void comm_loop_entry(klnmf_ctx *c) {
                        : "another rank's shard of V exceeds the maximum given to klnmf_set_v_max: the sharded loop is refused on every rank");
     }
     c->refusals_dirty = false;
-    begin_fp8_loop(c, h[3], h[4], h[5], h[2] == 0.0 ? 1 : 0);
+    begin_fp8_loop(c, h[3], h[4], h[5], h[2] == 0.0 ? 1 : 0, planned);
 }
 
 // One iteration: row pass -> column pass (it does not depend on the stop decision) -> ONE grouped RCCL launch on the
@@ -2354,7 +2382,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         if (max_iter < 0) fail(KLNMF_ERR_ARG, "max_iter < 0");
         if (max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter exceeds the capacity given to klnmf_set_problem");
         check_v_overflow(c);
-        begin_fp8_loop(c);
+        begin_fp8_loop(c, -1.0, -1.0, -1.0, -1, max_iter);
         reset_state(c);
         c->loop_start_cur = c->cur;
         c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;
@@ -2484,10 +2512,10 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_run_sharded: dense problems only");
         const bool multi = comm_multi(c);
         if (multi) {
-            comm_loop_entry(c);
+            comm_loop_entry(c, max_iter);
         } else {
             check_v_overflow(c);
-            begin_fp8_loop(c);
+            begin_fp8_loop(c, -1.0, -1.0, -1.0, -1, max_iter);
         }
         reset_state(c);
         c->loop_start_cur = c->cur;
@@ -2812,7 +2840,10 @@ int klnmf_query_f64(klnmf_ctx *c, int what, double *value) {
         need_problem(c);
         if (!value) fail(KLNMF_ERR_ARG, "null value");
         if (what == KLNMF_QF_MON_STAT) { *value = c->stat_mon_max; return; }
-        if (what == KLNMF_QF_MON_THRESHOLD) { *value = (double)kMonThreshold; return; }
+        if (what == KLNMF_QF_MON_THRESHOLD) { *value = (double)mon_threshold_for((float)c->loop_planned); return; }
+        if (what == KLNMF_QF_MON_SPREAD) { *value = c->stat_mon_spread; return; }
+        if (what == KLNMF_QF_MON_MIN_SPREAD) { *value = (double)kMonMinSpread; return; }
+        if (what >= KLNMF_QF_MON_PART0 && what < KLNMF_QF_MON_PART0 + 3) { *value = c->stat_mon_dbg[what - KLNMF_QF_MON_PART0]; return; }
         if (what != KLNMF_QF_SUM_V && what != KLNMF_QF_NNZ_V) fail(KLNMF_ERR_ARG, "klnmf_query_f64: unknown item");
         if (c->is_exact()) { *value = 0.0; return; }
         DevState ds{};

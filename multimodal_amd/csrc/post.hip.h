@@ -38,7 +38,6 @@ namespace klnmf {
 
 constexpr int kPostMaxParts = 4;
 constexpr int kPostSlabBatch = 16;              // slabs in flight per thread (one float4 each)
-constexpr int kW8TabRows = 64;                  // rows of the conversion kernel's maxima table (blockIdx & 63): [kW8TabRows][KP] float bit patterns
 
 struct PostPart {
     const float *slabs;       // [nslab][KP][ld] of this part (the column pass's Npart for it)
@@ -195,22 +194,57 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         __syncthreads();
         if (tid == 0) {
             // msum: [0..31] N16 of half A, [32..63] D of half A, [64..95] N16 of half B, [96..127] D of half B
-            float cross = 0.f, nn = 0.f, nz = 0.f;
+            float sd = 0.f, sn = 0.f;
+            for (int j = 0; j < a.mon.ncols; ++j) { sd += msum[32 + j] + msum[96 + j]; sn += msum[j] + msum[64 + j]; }
+            const float mean = sn > 0.f ? sd / sn : 0.f;         // this row's common factor over the tile: the row normalisation removes it
+            float cross = 0.f, crossc = 0.f, nn = 0.f, nz = 0.f;
             int cols = 0;
             for (int j = 0; j < a.mon.ncols; ++j) {
                 const float na = msum[j], da = msum[32 + j], nb = msum[64 + j], db = msum[96 + j];
                 cross += da * db;
+                crossc += (da - mean * na) * (db - mean * nb);
                 nn += na * nb;
                 if (na > 0.f && nb > 0.f) { const float e = da / na - db / nb; nz += e * e; ++cols; }
             }
-            float stat = 0.f;
-            if (nn > 0.f && cols > 0) stat = sqrtf(fmaxf(cross / nn, 0.f) + 0.5f * (nz / (float)cols) * a.mon.noise_scale);
-            if (!(stat <= a.mon.threshold)) {                    // (a NaN trips too)
+            float stat = 0.f, raw = 0.f, noise = 0.f;
+            if (nn > 0.f && cols > 0) {
+                noise = 0.5f * (nz / (float)cols) * a.mon.noise_scale;
+                raw = sqrtf(fmaxf(cross / nn, 0.f));
+                stat = sqrtf(fmaxf(crossc / nn, 0.f) + noise);
+            }
+            if (!(stat <= a.mon.threshold) || fabsf(mean) > a.mon.max_common) {      // (a NaN trips too)
                 atomicAdd(&a.st->mon_trips, 1);
                 __threadfence();                                  // rare: the count must be there when the last block publishes it
             }
             atomicMax(&a.st->mon_stat_bits, __float_as_uint(stat == stat ? stat : 3.0e38f));
+            atomicMax(&a.st->mon_dbg[0], __float_as_uint(raw == raw ? raw : 3.0e38f));
+            atomicMax(&a.st->mon_dbg[1], __float_as_uint(noise == noise ? sqrtf(noise) : 3.0e38f));
+            atomicMax(&a.st->mon_dbg[2], __float_as_uint(fabsf(mean)));
             if (comp == 0) a.st->mon_checks += 1;
+        }
+        if (comp == 0) {
+            // the relative spread of each monitored column's ratios (monitor.hip.h, kMonMinSpread): block 0, thread = column
+            __shared__ float sp_s[32];
+            if (tid < 32) {
+                float cnt = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int blk = 0; blk < kMonBlocks; ++blk) {
+                    const float *sp = a.mon.spread + (int64_t)blk * 96;
+                    cnt += sp[tid]; s1 += sp[32 + tid]; s2 += sp[64 + tid];
+                }
+                float rel = 1.f;                                  // (a column without entries > 0 in the sample: nothing to resolve)
+                if (tid < a.mon.ncols && cnt >= 64.f && s1 > 0.f) {
+                    const float m = s1 / cnt, var = fmaxf(s2 / cnt - m * m, 0.f);
+                    rel = sqrtf(var) / m;
+                }
+                sp_s[tid] = rel;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float mn = 1.f;
+                for (int j = 0; j < 32; ++j) mn = fminf(mn, sp_s[j]);
+                if (mn < a.mon.min_spread) { atomicAdd(&a.st->mon_trips, 1); __threadfence(); }
+                atomicMin(&a.st->mon_spread_bits, __float_as_uint(mn));
+            }
         }
     }
 

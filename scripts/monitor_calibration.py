@@ -55,6 +55,18 @@ def classes(quick):
         return make
     out.append(('constant columns 40 000 x 500, k = 100', const_cols(40000, 500, 100), 100, 8, 11))
     out.append(('constant columns 66 000 x 300, k = 130 (fp8 x fp8 pass)', const_cols(66000, 300, 130), 130, 8, 11))
+    def spiked(k):
+        def make():
+            rs = np.random.RandomState(5)
+            X = orc.synthetic_V(13, 70000, 256, 12)
+            X[:, 128:] = 1e-4 * rs.random_sample((70000, 128))
+            for (i, j) in [(100, 131), (7000, 255), (30001, 192), (65999, 216)]:
+                X[i, j] = 100.0 * X.mean()
+            return X
+        return make
+    out.append(('rank 12 + empty half + spikes 70 000 x 256, k = 200 (the fix-up tests)', spiked(200), 200, 10, 13))
+    out.append(('rank 12 + empty half + spikes 70 000 x 256, k = 50', spiked(50), 50, 10, 13))
+    out.append(('rank 12 data, k = 200: 70 000 x 256 (run_more test)', lambda: orc.synthetic_V(13, 70000, 256, 12), 200, 7, 13))
     if not quick:
         out.append(('constant columns 66 000 x 300, k = 130, 100 iterations', const_cols(66000, 300, 130), 130, 100, 11))
     return out
@@ -82,7 +94,8 @@ def main():
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--only', default=None)
     args = ap.parse_args()
-    print('%-66s %-8s %10s %5s %5s %10s %6s %s' % ('class', 'run', 'KL rel', 'len', 'fp8', 'statistic', 'trips', 'gave up'))
+    print('%-66s %-8s %10s %5s %5s %10s %6s %-7s %s' % ('class', 'run', 'KL rel', 'len', 'fp8', 'statistic', 'trips', 'gave up',
+                                                       '[uncentred bias, noise, common factor]  min spread  KL / sum(V)'))
     for name, make, k, iters, hseed in classes(args.quick):
         if args.only and args.only not in name:
             continue
@@ -100,8 +113,9 @@ def main():
                 Wr, Hr = Wo, Ho
             fo = orc.kl_error(X, Wr, Hr)
             rel = abs(orc.kl_error(X, W.astype(np.float64), H.astype(np.float64)) - fo) / fo
-            print('%-66s %-8s %10.2e %5d %5d %10.2e %6d %s' % (name, run, rel, len(e), rep['tile_iterations'], rep['monitor_statistic'],
-                                                              rep['monitor_trips'], rep['gave_up']), flush=True)
+            print('%-66s %-8s %10.2e %5d %5d %10.2e %6d %-7s [%s]  %.3f  %.2e' % (
+                name, run, rel, len(e), rep['tile_iterations'], rep['monitor_statistic'], rep['monitor_trips'], rep['gave_up'],
+                ', '.join('%.1e' % v for v in rep['monitor_parts']), rep['monitor_min_spread'], fo / X.sum()), flush=True)
         print('    (%d x %d, k = %d, %d iterations, oracle len %d; %.0f s)' % (n, f, k, iters, len(eo), time.time() - t0), flush=True)
 
 

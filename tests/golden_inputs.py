@@ -137,3 +137,13 @@ def experiment_modalities(seed, n_per_label=14, n_labels=10, dims=(48, 30)):
     Xa, la = out[0]
     out[0] = (Xa / Xa.sum(axis=1, keepdims=True), la)
     return out
+
+
+def constant_columns_problem(seed, n, f, k):
+    """Low-rank data + noise in which every 7th column is CONSTANT (round 4's fuzz class: the model fits those columns exactly,
+    all their ratios collapse into one e4m3 cell); H0 by the reference's init rule from its own stream."""
+    rs = np.random.RandomState(seed)
+    X = rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
+    X[:, ::7] = 3.0
+    H0 = _normalize_rows(np.abs(np.random.RandomState(seed + 1).random_sample((k, f))) + .01)
+    return X, H0

@@ -814,15 +814,21 @@ def test_data_of_any_magnitude_keeps_the_reference_eps(n, f, k, scale):
         assert _rel_to_max(m.components_, Ho) < 5e-3
 
 
-def test_sparse_data_stored_densely_keeps_16_bit_ratio_tiles(monkeypatch):
-    """fp8 ratio tiles are admitted from 32 769 rows because the H numerator averages their 3-bit significands over the rows --
-    over the rows that hold something: with 95 % zeros (histogram data stored densely) 70 000 rows are 3 500 entries per
-    column, and the fit converges 2e-4 away from the oracle's KL (scripts/data_fuzz.py, round 4).  The loop's entry now
-    counts the entries > 0 per column (DevState.nnz_x, all-reduced on row shards); dense data of the same shape keeps the
-    fp8 tiles.  KLNMF_Q8_SPARSE_OK=1 shows the old behaviour.  Reference: nmf.py:345-351 (the H rule's sum over samples)."""
-    for name in ('KLNMF_QTILE', 'KLNMF_Q8_SPARSE_OK', 'KLNMF_NE'):
+def _clear_fp8_switches(monkeypatch):
+    for name in ('KLNMF_QTILE', 'KLNMF_Q8_MONITOR', 'KLNMF_Q8_RULES', 'KLNMF_NE', 'KLNMF_COL8', 'KLNMF_MON_THRESHOLD', 'KLNMF_MON_MIN_SPREAD'):
         monkeypatch.delenv(name, raising=False)
-    n, f, k, iters = 70000, 96, 40, 60
+
+
+def test_monitor_keeps_sparse_data_stored_densely_on_16_bit_ratio_tiles(monkeypatch):
+    """fp8 ratio tiles rely on the H numerator averaging their 3-bit significands over the rows -- over the rows that hold
+    something: with 95 % zeros (histogram data stored densely) 70 000 rows are 3 500 entries per column, and a fit on fp8
+    tiles ends 3e-4 .. 4e-4 off the oracle's KL (scripts/data_fuzz.py, round 4).  Round 4 kept such data off the tiles with a
+    count of the entries > 0 per column at the loop's entry; round 5 MEASURES: the monitor's dry run on the loop's second
+    iteration (csrc/monitor.hip.h) finds the numerator's entries 1.1e-3 off, the loop never takes the tiles and ends where the
+    16-bit run ends.  Without the monitor (KLNMF_Q8_MONITOR=0) the defect is there; dense data of the same shape keeps the
+    fp8 tiles.  Reference: nmf.py:345-351 (the H rule's sum over samples)."""
+    _clear_fp8_switches(monkeypatch)
+    n, f, k, iters = 70000, 96, 40, 40
     rs = np.random.RandomState(3)
     D = rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
     X = D * (rs.random_sample((n, f)) < 0.05)
@@ -830,14 +836,19 @@ def test_sparse_data_stored_densely_keeps_16_bit_ratio_tiles(monkeypatch):
     Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
     final_o = orc.kl_error(X, Wo, Ho)
     m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
-    assert m.last_fp8_report['tile_iterations'] == 0
+    rep = m.last_fp8_report
+    assert rep['tile_iterations'] == 0 and rep['gave_up'] and rep['monitor_trips'] > 0, rep
+    assert rep['monitor_statistic'] > rep['monitor_threshold']
+    assert len(errors) == len(eo)
     assert abs(orc.kl_error(X, W, m.components_) - final_o) <= 1e-4 * final_o
-    monkeypatch.setenv('KLNMF_Q8_SPARSE_OK', '1')
+    monkeypatch.setenv('KLNMF_Q8_MONITOR', '0')
     m8, W8, e8, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
-    assert m8.last_fp8_report['tile_iterations'] > 0          # (measured: 1.5e-4 ... 2e-4 off -- what the rule is for)
-    monkeypatch.delenv('KLNMF_Q8_SPARSE_OK')
+    assert m8.last_fp8_report['tile_iterations'] > 0
+    if len(e8) == len(eo):                                     # (what the monitor is for: measured 2.7e-4 .. 3.9e-4)
+        assert abs(orc.kl_error(X, W8, m8.components_) - final_o) > 1e-4 * final_o
+    monkeypatch.delenv('KLNMF_Q8_MONITOR')
     md, Wd, ed, _ = fit_gpu(D, H0, k, 6, 0, precision='f16')
-    assert md.last_fp8_report['tile_iterations'] == 4          # dense data: fp8 tiles from the third iteration on, as before
+    assert md.last_fp8_report['tile_iterations'] == 4 and not md.last_fp8_report['gave_up']      # dense data: fp8 tiles from the third iteration on
 
 
 @pytest.mark.parametrize('n,f,k', [(16305, 28, 8), (16256, 40, 5), (8128, 64, 32)])
@@ -856,22 +867,39 @@ def test_w_image_tail_padding_covers_a_whole_copy_at_k_le_32(n, f, k):
         assert _rel_to_max(W, Wo) < 5e-3 and _rel_to_max(m.components_, Ho) < 5e-3
 
 
-@pytest.mark.parametrize('n,f,k', [(33118, 424, 1), (40000, 64, 2)])
-def test_fewer_than_four_components_keep_16_bit_ratio_tiles(monkeypatch, n, f, k):
+@pytest.mark.parametrize('n,f,k,iters', [(33118, 424, 1, 8), (40000, 64, 2, 8), (40000, 64, 2, 40)])
+def test_monitor_ends_the_fp8_regime_in_a_dead_zone_of_few_components(monkeypatch, n, f, k, iters):
     """e4m3 steps by 6-12 % around 1.  With one or two components on low-rank data the heavy entries' ratios all sit inside
     one step of 1 and their deviations -- what the H rule works with -- are rounded away together (a dead zone, not noise that
-    averages out over the rows): 1.2e-3 / 5e-4 off the oracle's final KL on fp8 tiles (scripts/shape_fuzz.py --seed 21, round 4;
-    experiments/fp8_tiles_dead_zone_emulation.py reproduces the figure with the rounding alone), 6e-6 / 5e-5 on 16-bit tiles.
-    The loop's entry keeps 16-bit tiles for k < 4 (nmf.py:345-351 is the rule concerned)."""
-    for name in ('KLNMF_QTILE', 'KLNMF_Q8_SPARSE_OK'):
-        monkeypatch.delenv(name, raising=False)
+    averages out over the rows): 3.6e-3 (k = 1) / 2e-4 after 8 and 1.6e-2 after 40 iterations (k = 2) off the oracle's final KL on
+    fp8 tiles (scripts/monitor_calibration.py; experiments/fp8_tiles_dead_zone_emulation.py reproduces it with the rounding
+    alone).  Round 4 answered with the rule k >= 4; the monitor measures it: k = 1 fails the dry run (statistic 5e-3) and never
+    takes the tiles, k = 2 is caught on its second fp8 iteration and ends 9e-5 from the oracle.  nmf.py:345-351."""
+    _clear_fp8_switches(monkeypatch)
     X = orc.synthetic_V(7 + n + f + k, n, f, k)
     H0 = orc.synthetic_H0(7 + n + f + k, f, k)
-    m, W, errors, _ = fit_gpu(X, H0, k, 8, 0, precision='f16')
-    assert m.last_fp8_report['tile_iterations'] == 0
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    rep = m.last_fp8_report
+    assert rep['gave_up'] and rep['monitor_trips'] > 0 and rep['tile_iterations'] <= 2, rep
+    if k == 1:
+        assert rep['tile_iterations'] == 0
     Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=len(errors), tol=0)      # (k = 1 sits on a plateau: stop timing may differ)
     final_o = orc.kl_error(X, Wo, Ho)
     assert abs(orc.kl_error(X, W, m.components_) - final_o) <= 1e-4 * final_o
+
+
+@pytest.mark.parametrize('n,f,k', [(103431, 8, 4), (41388, 3, 10)])
+def test_less_than_one_column_tile_of_data_keeps_16_bit_ratio_tiles(monkeypatch, n, f, k):
+    """A shape rule, not a data rule: with fewer than 32 columns the ratio tiles are mostly padding (nothing to gain), and a
+    handful of columns is fitted so exactly that the loss itself goes to 0 (41 388 x 3, k = 10: KL / sum(V) = 4e-5; on fp8 tiles
+    0.49 off the oracle).  klnmf_set_problem does not offer fp8 tiles below one column tile of data."""
+    _clear_fp8_switches(monkeypatch)
+    X = orc.synthetic_V(7 + n + f + k, n, f, k)
+    H0 = orc.synthetic_H0(7 + n + f + k, f, k)
+    m, W, errors, _ = fit_gpu(X, H0, k, 6, 0, precision='f16')
+    assert m.last_fp8_report['tile_iterations'] == 0 and not m.last_fp8_report['allowed']
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=len(errors), tol=0)
+    assert_allclose(errors, eo[:len(errors)], rtol=1e-3)      # (the 16-bit mode's own tolerance on every recorded loss: the fit is nearly exact)
 
 
 @pytest.mark.parametrize('kind', ['one-hot row', 'one spike 1e4 x max'])
@@ -908,8 +936,7 @@ def test_exactly_fitted_columns_do_not_stall_on_fp8_tiles(monkeypatch):
     ended 3.7e-4 off the oracle's KL after 8 iterations (scripts/data_fuzz.py, round 4).  The tiles now hold ratio x sqrt(2) / 8:
     ratio 1 in the MIDDLE of a binade, a uniform quantiser around it (mfma.hip.h, kQ8Mid; emulation:
     experiments/fp8_tiles_mid_binade_emulation.py).  Reference: nmf.py:345-351."""
-    for name in ('KLNMF_QTILE', 'KLNMF_Q8_SPARSE_OK'):
-        monkeypatch.delenv(name, raising=False)
+    _clear_fp8_switches(monkeypatch)
     n, f, k, iters = 40000, 500, 100, 8
     rs = np.random.RandomState(1)
     X = rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
@@ -919,8 +946,80 @@ def test_exactly_fitted_columns_do_not_stall_on_fp8_tiles(monkeypatch):
     m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
     assert m.last_fp8_report['tile_iterations'] == iters - 2
     final_o = orc.kl_error(X, Wo, Ho)
-    assert abs(orc.kl_error(X, W, m.components_) - final_o) <= 2e-5 * final_o          # (measured 4e-7; 3.7e-4 with ratio / 8)
+    assert abs(orc.kl_error(X, W, m.components_) - final_o) <= 2e-5 * final_o          # (measured 2e-7; 3.7e-4 with ratio / 8)
     assert_allclose(errors, eo, rtol=1e-4)
+
+
+def test_exactly_fitted_columns_on_the_fp8_x_fp8_pass_short_loop(monkeypatch):
+    """The same class where the fp8 x fp8 column pass runs (k > 96, 65 536 rows and more): 66 000 x 300, k = 130, 8 iterations --
+    the configuration round 4 left 6e-5 off the oracle after 8 iterations and 1e-4 after 10.  The component that models the constant
+    columns has nearly the same coefficient in every row: the e4m3 image of W_new rounds them all one way, and the monitor's
+    dry run -- which forms that image itself, with the scales the loop's second iteration measures -- finds the component's
+    numerator row off by a common 1.9 % (kMonMaxCommon = 0.6 %): the loop never enters the fp8 regime and follows the
+    reference's own losses (fixture G16) within 1e-4.  (One fp8 x fp8 iteration would already cost it: the class amplifies
+    7e-6 of the third loss into 1.8e-4 forty iterations later.)"""
+    _clear_fp8_switches(monkeypatch)
+    X, H0 = gi.constant_columns_problem(97, 66000, 300, 130)
+    g = gi.load('g16_constant_columns_100it')
+    m, W, errors, _ = fit_gpu(X, H0, 130, 8, 0, precision='f16')
+    rep = m.last_fp8_report
+    assert rep['tile_iterations'] == 0 and rep['gave_up'] and rep['monitor_trips'] > 0 and rep['monitor_checks'] == 1, rep
+    assert rep['monitor_parts'][2] > 6e-3, rep
+    assert_allclose(errors, g['errors'][:8], rtol=1e-4)          # the reference's own losses (tests/golden/make_golden_large.py)
+
+
+def test_exactly_fitted_columns_over_100_iterations_match_the_reference(monkeypatch):
+    """Fixture G16, the reference's own 100 iterations on the constant-columns class (66 000 x 300, k = 130).  On fp8 tiles
+    every constant column's ratios collapse into ONE e4m3 cell as the fit converges: the H rule loses its feedback there, the
+    columns cycle between two cells, the loss leaves the reference's by 4e-4 at iteration 40 and RISES at 67 (no scale of the
+    tiles cures it: experiments/README.md); even three or four fp8 iterations at the loop's start are amplified into 1.8e-4 of the
+    loss eighty iterations later.  A loop planned for more than 50 iterations is not offered the tiles (monitor.hip.h, kQ8MaxLoop:
+    what the e4m3 rounding does to the loss grows with the square of the loop's length): every recorded loss and the final one
+    within 1e-4, len(errors) equal.  The first 50 iterations of the same fit are refused by the monitor's dry run (previous
+    test) and stay within the bar as well.  nmf.py:212-222."""
+    _clear_fp8_switches(monkeypatch)
+    g = gi.load('g16_constant_columns_100it')
+    n, f, k, iters = int(g['n']), int(g['f']), int(g['k']), int(g['iters'])
+    X, H0 = gi.constant_columns_problem(int(g['seed']), n, f, k)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    rep = m.last_fp8_report
+    assert len(errors) == len(g['errors']) == iters
+    assert rep['tile_iterations'] == 0 and not rep['allowed'], rep
+    assert_allclose(errors, g['errors'], rtol=1e-4)
+    assert abs(m.error(X, W) - float(g['final'])) <= 1e-4 * float(g['final'])
+    assert_allclose(m.components_[:, ::max(1, f // 64)], g['H_cols'], atol=5e-3 * g['H_cols'].max())
+    m50, W50, e50, _ = fit_gpu(X, H0, k, 50, 0, precision='f16')
+    rep50 = m50.last_fp8_report
+    assert rep50['tile_iterations'] == 0 and rep50['gave_up'], rep50
+    assert_allclose(e50, g['errors'][:50], rtol=1e-4)
+    # ... and what the monitor prevents: the same 50 iterations held on fp8 tiles (measured: 1.1e-3 off at iteration 50)
+    monkeypatch.setenv('KLNMF_Q8_MONITOR', '0')
+    m8, W8, e8, _ = fit_gpu(X, H0, k, 50, 0, precision='f16')
+    assert m8.last_fp8_report['tile_iterations'] == 48
+    assert np.max(np.abs(e8 - g['errors'][:50]) / g['errors'][:50]) > 3e-4
+
+
+def test_a_loop_of_200_iterations_is_not_admitted_to_fp8_tiles_and_matches_the_reference(monkeypatch):
+    """Fixture G17: configuration 2's kind of data and ITS 200 iterations, at 40 000 rows (enough for fp8 ratio tiles).  The
+    rounding pattern of a nearly converged fit's ratios is frozen from one iteration to the next and the update integrates
+    it: on fp8 tiles the loss is 5e-5 off the reference's at iteration 50, 1.4e-4 at 75, 2e-4 at 200 -- at 40 000 and at
+    160 000 rows alike (scripts/fp8_drift_probe.py).  The monitor's threshold therefore falls with the square of the loop's
+    planned length (2 / planned^2), and beyond 50 planned iterations a loop is not offered the tiles: this one runs on 16-bit
+    tiles and every one of its 200 losses is within 1e-4 of the reference's, len(errors) equal.  The first 50 iterations of the
+    same fit ARE admitted (threshold 8e-4) and stay within the bar too.  nmf.py:212-222."""
+    _clear_fp8_switches(monkeypatch)
+    g = gi.load('g17_c2kind_40000rows_200it')
+    n, f, k, iters = int(g['n']), int(g['f']), int(g['k']), int(g['iters'])
+    X, H0 = gi.synthetic_problem(int(g['seed']), n, f, k)
+    m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    rep = m.last_fp8_report
+    assert len(errors) == len(g['errors']) == iters
+    assert rep['tile_iterations'] == 0 and not rep['allowed'], rep
+    assert_allclose(errors, g['errors'], rtol=1e-4)
+    assert abs(m.error(X, W) - float(g['final'])) <= 1e-4 * float(g['final'])
+    m50, W50, e50, _ = fit_gpu(X, H0, k, 50, 0, precision='f16')
+    assert m50.last_fp8_report['tile_iterations'] == 48 and not m50.last_fp8_report['gave_up'], m50.last_fp8_report
+    assert_allclose(e50, g['errors'][:50], rtol=1e-4)
 
 
 # ---- e4m3 saturation: counted, and kept out of the result (round 3) ---------------------------------------------------
