@@ -206,6 +206,14 @@ def parse_args(argv=None):
     p.add_argument('--collective', default='native', choices=['native', 'torch'],
                    help='N > 1: native = one grouped RCCL all-reduce per iteration issued inside the C-ABI (klnmf_run_sharded); '
                         'torch = torch.distributed all-reduces sequenced in Python around the C-ABI pieces')
+    p.add_argument('--workload', default='fit', choices=['fit', 'transform'],
+                   help="fit: the training iteration of nmf.py:212-222 (the headline metric); transform: the iteration of "
+                        "KLdivNMF.transform / fit_coefficients (nmf.py:275-291, learner.py:11-15: loss + ratio + W rule against a "
+                        "FIXED trained dictionary -- no ratio tiles stored, no H rule, no numerator exchange: next-row N1)")
+    p.add_argument('--train-iters', type=int, default=10, help='--workload transform: fit iterations that train the dictionary first')
+    p.add_argument('--slice', type=int, default=0,
+                   help='--workload transform: coefficients of the first SLICE columns only against the column-sliced dictionary '
+                        '(learner.py:67-78: its rows no longer sum to 1); 0 = all columns')
     p.add_argument('--tol', type=float, default=0.0,
                    help='stop-rule tolerance of nmf.py:207,215 (relative; x n x f inside).  0 = MultimodalLearner.train')
     return p.parse_args(argv)
@@ -405,6 +413,169 @@ def gpu_parity_on_sample(args, sample):
             'iterations_on_fp8_ratio_tiles': fp8['tile_iterations'], 'iterations_with_fp8_x_fp8_column_pass': fp8['column_pass_iterations']}
 
 
+def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fence, info, t_setup, collective, sampler0):
+    """--workload transform: `steps` iterations of KLdivNMF.transform's loop (nmf.py:275-291 -> 212-222 with _fit=False) on the
+    resident V against a dictionary trained by `train_iters` fit iterations first.  One row pass per iteration (W.H -> ratio,
+    loss -> Q.H^T -> W rule: 4 n f k flops, V read once, the fp32 master of W in and out) + the loss reduction; nothing is
+    stored for an H rule and nothing but the loss scalar is exchanged between ranks."""
+    from multimodal_amd.distributed import ShardedKLNMF
+    n, f, k = args.n, args.f, args.k
+    iters_per_fit = args.warmup + args.steps
+    # ---- the dictionary: `train_iters` fit iterations from H0
+    model.set_H(H0)
+    model.init_W()
+    model.begin()
+    model.iterate_many(args.train_iters, fit=True, tol=0.0)
+    model.end()
+    H = model.get_H()
+    tmodel, fs = model, f
+    if args.slice and args.slice < f:
+        # the first `slice` columns against the column-sliced dictionary (modality -> internal: learner.py:67-78)
+        from multimodal_amd import synthetic
+        fs = args.slice
+        H = np.ascontiguousarray(H[:, :fs])
+        tmodel = ShardedKLNMF(n, n_local, fs, k, max_iter=iters_per_fit, precision=args.precision, collective=collective)
+        vmax = synthetic.for_each_block(args.seed, r0, r1, n, f, k, None)
+        tmodel.set_v_max(vmax)
+        synthetic.for_each_block(args.seed, r0, r1, n, f, k,
+                                 lambda lo, arr: tmodel.upload_V(np.ascontiguousarray(arr[:, :fs]), row0=lo, col0=0))
+    segments, prof_tot, last = [], {'rowpass_ms': 0.0, 'rowpass_launches': 0}, None
+    for rep in range(max(1, args.repeats)):
+        with Watchdog(args.segment_timeout, 'transform segment %d' % rep, rank):
+            tmodel.set_H(H)
+            tmodel.init_W()
+            tmodel.begin()
+            tmodel.iterate_many(args.warmup, fit=False, tol=args.tol)
+            tmodel.ctx.profile_enable(True)
+            fence()
+            t0 = time.perf_counter()
+            tmodel.iterate_many(args.steps, fit=False, tol=args.tol)
+            fence()
+            elapsed = time.perf_counter() - t0
+            prof = tmodel.ctx.profile_read(reset=True)
+            tmodel.ctx.profile_enable(False)
+            last = tmodel.end()
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            segments.append(float(t.item()))
+        for key in prof_tot:
+            prof_tot[key] += prof[key]
+    if rank != 0:
+        if tmodel is not model:
+            tmodel.close()
+        return None
+    n_gpus = world if world > 1 else 1
+    elapsed = statistics.median(segments)
+    its = args.steps / elapsed
+    row_ms = prof_tot['rowpass_ms'] / max(1, prof_tot['rowpass_launches'])
+    fast16 = args.precision in ('f16', 'bf16')
+    vbytes = 2 if fast16 else 4
+    flops_row = 4.0 * n_local * fs * k
+    alg_bytes_row = n_local * fs * vbytes + 2 * n_local * k * 4
+    sched_bytes_row = alg_bytes_row + 2 * n_local * k * 2          # + the 16-bit W images in and out
+    t_mfma, t_hbm = flops_row / (PEAK_BF16_TFLOPS * 1e12), alg_bytes_row / (PEAK_HBM_GBS * 1e9)
+    mfma_bound = t_mfma >= t_hbm
+    row_s = row_ms * 1e-3
+    tfl, gbs = flops_row / row_s / 1e12, alg_bytes_row / row_s / 1e9
+    traffic = None
+    for name in [os.path.join('profiles', 'r05_pmc_traffic_transform.json')]:
+        try:
+            d = json.load(open(os.path.join(ROOT, name)))
+            for entry in d.get('workloads', []):
+                w = entry.get('workload', {})
+                if (w.get('n_local'), w.get('f'), w.get('k')) == (n_local, fs, k):
+                    traffic = {'bytes_per_launch': entry['hbm_bytes_per_launch'], 'source': name, 'source_hash': d.get('source_hash')}
+        except Exception:
+            pass
+    errors, n_done, stopped = last
+    out = {
+        'metric': 'nmf_transform_iterations_per_sec',
+        'value': its, 'unit': 'it/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f16 operands, fp32 accumulate' if fast16 else args.precision,
+        'data': 'synthetic',
+        'config': {'workload': 'KL-NMF transform iteration (fixed dictionary), V %dx%d (row-sharded), k=%d%s' % (
+                       n, fs, k, ', first %d of %d columns against the column-sliced dictionary' % (fs, f) if fs != f else ''),
+                   'n': n, 'f': fs, 'k': k, 'rows_per_gpu': n_local, 'precision': args.precision, 'parallelism': 'rows/%d' % n_gpus,
+                   'dictionary': '%d fit iterations from the seeded H0%s' % (
+                       args.train_iters, '; rows of the slice sum to %.3f .. %.3f' % (H.sum(axis=1).min(), H.sum(axis=1).max()) if fs != f else ''),
+                   'timing': 'median of %d segments of %d iterations, each after a fresh W0 = V.H^T + %d warm-up iterations'
+                             % (len(segments), args.steps, args.warmup)},
+        'samples_per_sec': its * n,
+        'segments_ms_per_step': [1e3 * sg / args.steps for sg in segments],
+        'setup_s': t_setup, 'iterations_done': n_done, 'stopped_early': bool(stopped),
+        'valid': bool(n_done == iters_per_fit and not stopped),
+        'loss_first': errors[0] if errors else None, 'loss_last': errors[-1] if errors else None,
+        'loss_finite_and_decreasing': bool(len(errors) > 1 and all(b < a for a, b in zip(errors, errors[1:]))),
+        'device': info,
+        'roofline': {
+            'kernel': 'k_rowpass4 (W.H -> ratio/loss -> Q.H^T -> W rule; no ratio tiles stored)',
+            'bound': 'mfma' if mfma_bound else 'hbm',
+            'achieved': tfl if mfma_bound else gbs, 'peak': PEAK_BF16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+            'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+            'frac': (tfl / PEAK_BF16_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
+            'traffic': traffic['bytes_per_launch'] if traffic else None,
+            'traffic_source': traffic['source'] if traffic else None,
+            'traffic_is_current': bool(traffic and traffic.get('source_hash') == kernel_source_hash()),
+            'traffic_over_algorithmic': (traffic['bytes_per_launch'] / alg_bytes_row) if traffic else None,
+            'source_hash': kernel_source_hash(),
+            'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'], 'rows_per_launch': n_local,
+            'algorithmic_flops_per_launch': flops_row, 'algorithmic_bytes_per_launch': alg_bytes_row,
+            'schedule_bytes_per_launch': sched_bytes_row,
+            't_min_ms': {'mfma': t_mfma * 1e3, 'hbm': t_hbm * 1e3},
+            'other_roof': {'bound': 'hbm' if mfma_bound else 'mfma', 'achieved': gbs if mfma_bound else tfl,
+                           'frac': (gbs / PEAK_HBM_GBS) if mfma_bound else (tfl / PEAK_BF16_TFLOPS)}},
+        'kernels': {'iteration_algorithmic_tflops': 4.0 * n * fs * k / (1e3 * elapsed / args.steps * 1e-3) / 1e12,
+                    'rest_of_the_iteration_ms': 1e3 * elapsed / args.steps - row_ms},
+    }
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        out.update(transform_cpu_baseline_and_parity(args, H, fs))
+    if tmodel is not model:
+        tmodel.close()
+    return out
+
+
+def transform_cpu_baseline_and_parity(args, H, fs):
+    """The oracle's transform loop (numpy restatement of nmf.py:275-291: fp64, a separate W.H for the loss and for the ratio)
+    timed on the first `cpu_rows` rows of the same V against the SAME dictionary, and the HIP path on that sample."""
+    from oracle import klnmf_oracle as orc
+    from multimodal_amd import synthetic, _native
+    host = host_info()
+    blas_threads = max([t.get('num_threads', 0) for t in (host.get('blas') or [])] + [0]) or None
+    rows = min(args.cpu_rows, args.n)
+    X = np.ascontiguousarray(synthetic.rows_of(args.seed, 0, rows, args.n, args.f, args.k)[:, :fs])
+    H = np.asarray(H, dtype=np.float64)
+    W = X.dot(H.T)
+    losses, times = [], []
+    for it in range(1 + args.cpu_iters):
+        t0 = time.perf_counter()
+        losses.append(orc.kl_error(X, W, H))
+        W, _ = orc.update_step(X, W, H, fit=False)
+        times.append(time.perf_counter() - t0)
+    final = orc.kl_error(X, W, H)
+    per_iter = statistics.median(times[1:])
+    base = {'value': (1.0 / per_iter) * rows / args.n, 'unit': 'it/s', 'cores': blas_threads or host.get('cores'), 'kind': 'port',
+            'sample': 'rows [0, %d) of the same seeded V (%d columns), k=%d, the trained dictionary: 1 warm-up + %d timed fp64 '
+                      'iterations of the numpy restatement of the transform loop (median %.2f s/iteration on the sample), scaled '
+                      'linearly in n (extrapolated)' % (rows, fs, args.k, args.cpu_iters, per_iter),
+            'cpu_model': host.get('cpu_model'), 'numpy': host.get('numpy'), 'blas': host.get('blas')}
+    iters = len(losses)
+    with _native.Context(args.precision, device=0) as ctx:
+        ctx.set_problem(rows, fs, args.k, iters)
+        ctx.upload_blocks([X])
+        ctx.set_H(H)
+        ctx.init_W()
+        errs, n_done, stopped = ctx.run(iters, False, 0.0)
+        g_final = ctx.error()
+        Wg = ctx.get_W()
+    parity = {'final_kl_rel_err': abs(g_final - final) / abs(final),
+              'max_loss_rel_err': float(max(abs(a - b) / abs(b) for a, b in zip(errs, losses))) if len(errs) == len(losses) else None,
+              'W_max_abs_err_over_max': float(np.abs(Wg - W).max() / np.abs(W).max()),
+              'len_errors': [int(len(errs)), int(len(losses))], 'iterations': iters, 'rows': int(rows), 'tolerance': 1e-4}
+    return {'cpu_baseline': base, 'parity': parity}
+
+
 def main():
     args = parse_args()
     # stdout carries ONE JSON line and nothing else: libraries write there too (RCCL prints a version banner at the first
@@ -482,6 +653,20 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.workload == 'transform':
+        out = run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fence, info, t_setup, collective, sampler0)
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(out))
+            sys.stdout.flush()
+            os.dup2(2, 1)
+        model.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     def run_segments(repeats):
         """`repeats` independent fits from the same start; returns (segment times, fits, summed kernel profile, tail rows,
