@@ -19,7 +19,7 @@
 #include "../../include/klnmf.h"
 #include "common.hip.h"
 #include "exact.hip.h"
-#include "sparse.hip.h"
+#include "sparseb.hip.h"
 #include "mfma.hip.h"
 #include "mfma4.hip.h"
 // the k_rowpass4 instantiations live in rowpass4_inst_{1,2,3}.hip (built in parallel); here they are only declared
@@ -194,6 +194,7 @@ struct DevSwitches {
     int comm_parts = 1;         // KLNMF_COMM_PARTS = P: the numerator in P column parts on a communicator (experimental: one-rank runs only)
     bool comm_overlap = true;   // KLNMF_COMM_OVERLAP=0: the parts' all-reduces on the loop's own stream
     bool comm_single = false;   // KLNMF_COMM_SINGLE=1: a one-rank communicator takes the collective path (tests)
+    int sp_cb = 0, sp_rb = 0;   // KLNMF_SP_CB / KLNMF_SP_RB: column / row blocks of the CSR kernels (sparseb.hip.h; 0: by the L2's size)
     int graph = 0;              // KLNMF_GRAPH=1: two iterations captured into a hipGraph and replayed (measured: no gain)
     static DevSwitches read() {
         DevSwitches d;
@@ -216,6 +217,8 @@ struct DevSwitches {
         d.comm_overlap = num("KLNMF_COMM_OVERLAP", 1) != 0;
         d.comm_single = num("KLNMF_COMM_SINGLE", 0) != 0;
         d.graph = num("KLNMF_GRAPH", 0);
+        d.sp_cb = num("KLNMF_SP_CB", 0);
+        d.sp_rb = num("KLNMF_SP_RB", 0);
         return d;
     }
 };
@@ -257,6 +260,16 @@ struct klnmf_ctx {
     void *sp_data = nullptr, *sp_q = nullptr, *HT = nullptr;
     double *sp_row_loss = nullptr, *sp_wpart = nullptr, *sp_prod = nullptr;
     int64_t sp_nblk = 0;
+    // ... blocked for the L2 (sparseb.hip.h; k <= 512): int32 copies of the indices, column blocks of the CSR order and row blocks
+    // of the CSC order with their pointers, the slabs of partial sums
+    bool sp_blocked = false;
+    int sp_cb = 1, sp_rb = 1;                 // column blocks / row blocks
+    int64_t sp_cb_cols = 0, sp_rb_rows = 0;
+    int *sp_idx32 = nullptr, *csc_rows32 = nullptr, *csc_perm32 = nullptr;
+    int64_t *sp_blkptr = nullptr, *csc_blkptr = nullptr;      // [n][cb + 1], [f][rb + 1]
+    double *sp_loss_part = nullptr;           // [cb][n]
+    void *sp_G = nullptr, *sp_NT = nullptr;   // [cb][n][k], [rb][f][k]
+    int *sp_bad = nullptr;
     double *hpart = nullptr;          // exact modes, long rows: [k][hseg_n] partial row sums of the H rule / of the CSR loss term
     int hseg_n = 1; int64_t hseg = 0; // segments per dictionary row and their length (1: the one-block-per-row kernels)
 
@@ -923,22 +936,24 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
                        (T *)c->HT, c->k, c->f, (const DevState *)c->st);
 #define KL_SPQ_ARGS (const int64_t *)c->sp_indptr, (const int64_t *)c->sp_indices, (const T *)c->sp_data, \
         (const T *)c->W[c->cur], (const T *)c->HT, (T *)c->sp_q, c->sp_row_loss, c->k, (T)eps, write_q, (const DevState *)c->st
-    // fp64: 32 entries per trip (half the registers, twice the waves per SIMD: sparse.hip.h)
-    constexpr int NBD = sizeof(T) == 8 ? 32 : 64;
-    const int kc = (int)((c->k + 63) / 64);
-#define KL_SPQ_LAUNCH(KCV)                                                                                              \
-    do {                                                                                                                \
-        hipLaunchKernelGGL((k_sp_q<T, KCV, NBD>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);           \
-    } while (0)
-    if (kc <= 1) KL_SPQ_LAUNCH(1);
-    else if (kc == 2) KL_SPQ_LAUNCH(2);
-    else if (kc <= 4) KL_SPQ_LAUNCH(4);
-    else if (kc <= 8) KL_SPQ_LAUNCH(8);
-    else hipLaunchKernelGGL((k_sp_q_anyk<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);
-#undef KL_SPQ_LAUNCH
+    if (c->sp_blocked) {
+        const int kcb = (int)((c->k + 63) / 64);
+        const unsigned gridb = (unsigned)((int64_t)c->sp_cb * c->n);
+#define KL_SPB_QW(KCV, MODEV) hipLaunchKernelGGL((k_spb_qw<T, KCV, MODEV>), dim3(gridb), dim3(64), 0, c->stream, (const int64_t *)c->sp_blkptr, \
+        (const int *)c->sp_idx32, (const T *)c->sp_data, (const T *)c->W[c->cur], (const T *)c->HT, (T *)c->sp_q, c->sp_loss_part, (T *)c->sp_G,  \
+        c->n, c->k, c->sp_cb, (T)eps, (const DevState *)c->st)
+#define KL_SPB_QW_MODE(KCV) do { if (write_q) KL_SPB_QW(KCV, SPB_UPDATE); else KL_SPB_QW(KCV, SPB_LOSS); } while (0)
+        if (kcb <= 1) KL_SPB_QW_MODE(1); else if (kcb == 2) KL_SPB_QW_MODE(2); else if (kcb <= 4) KL_SPB_QW_MODE(4); else KL_SPB_QW_MODE(8);
+#undef KL_SPB_QW_MODE
+        HIPCHK(hipGetLastError());
+        if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    } else {
+    // (k > 512, or no stored entries: every lane takes its own entries and loops over the components)
+    hipLaunchKernelGGL((k_sp_q_anyk<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);
 #undef KL_SPQ_ARGS
     HIPCHK(hipGetLastError());
     if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    }
     hipLaunchKernelGGL((k_sp_colsum_part<T>), dim3((unsigned)c->sp_nblk), dim3(256), 0, c->stream,
                        (const T *)c->W[c->cur], c->sp_wpart, c->n, c->k, (const DevState *)c->st);
     if (c->hseg_n > 1) {
@@ -951,8 +966,9 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
         hipLaunchKernelGGL((k_sp_dots<T>), dim3((unsigned)c->k), dim3(256), 0, c->stream, (const double *)c->sp_wpart,
                            c->sp_nblk, (const T *)c->H, c->k, c->f, c->sp_prod, (const DevState *)c->st);
     }
-    hipLaunchKernelGGL(k_sp_loss, dim3(1), dim3(1024), 0, c->stream, (const double *)c->sp_row_loss, c->n,
-                       (const double *)c->sp_prod, c->k, c->loss_xchg, (const DevState *)c->st, dec);
+    hipLaunchKernelGGL(k_sp_loss, dim3(1), dim3(1024), 0, c->stream, (const double *)(c->sp_blocked ? c->sp_loss_part : c->sp_row_loss),
+                       c->sp_blocked ? (int64_t)c->sp_cb * c->n : c->n, (const double *)c->sp_prod, c->k, c->loss_xchg,
+                       (const DevState *)c->st, dec);
     HIPCHK(hipGetLastError());
 }
 
@@ -983,6 +999,23 @@ void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio, DecideArgs dec =
 // W_new = W * (Qsrc . H^T)   (multiply=0: W_new = Qsrc . H^T, i.e. W0 with Qsrc = V)
 template <typename T>
 void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
+    if (c->sparse && c->sp_blocked) {
+        // the partial sums of Q . H^T per column block are there (sparse_Q, fused with the ratio); W0 = X . H0^T: the same pass
+        // over the entries' values
+        if (!multiply) {
+            const int kcb = (int)((c->k + 63) / 64);
+            const unsigned gridb = (unsigned)((int64_t)c->sp_cb * c->n);
+#define KL_SPB_INIT(KCV) hipLaunchKernelGGL((k_spb_qw<T, KCV, SPB_INIT>), dim3(gridb), dim3(64), 0, c->stream, (const int64_t *)c->sp_blkptr,       \
+            (const int *)c->sp_idx32, (const T *)qsrc, (const T *)c->W[c->cur], (const T *)c->HT, (T *)nullptr, (double *)nullptr, (T *)c->sp_G,     \
+            c->n, c->k, c->sp_cb, (T)0, (const DevState *)c->st)
+            if (kcb <= 1) KL_SPB_INIT(1); else if (kcb == 2) KL_SPB_INIT(2); else if (kcb <= 4) KL_SPB_INIT(4); else KL_SPB_INIT(8);
+#undef KL_SPB_INIT
+        }
+        hipLaunchKernelGGL((k_spb_wrule<T>), dim3(grid_for(c->n * c->k, 256, 8192)), dim3(256), 0, c->stream, (const T *)c->sp_G, c->sp_cb,
+                           (const T *)c->W[c->cur], (T *)c->W[c->cur ^ 1], c->n, c->k, multiply, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     if (c->sparse) {        // Q . H^T over the stored entries (qsrc: the ratio values, or X's values for W0)
         const int spw_threads = (int)std::min<int64_t>(256, (c->k + 63) / 64 * 64);
         hipLaunchKernelGGL((k_sp_w<T>), dim3((unsigned)c->n), dim3(spw_threads), 0, c->stream, (const int64_t *)c->sp_indptr,
@@ -1018,6 +1051,21 @@ void exact_W(klnmf_ctx *c, const void *qsrc, int multiply) {
 // numer = W[widx]^T . Q   (sum_slabs = false: the dense row chunks' slabs are left for exact_H to sum: single-context loops)
 template <typename T>
 void exact_N(klnmf_ctx *c, int widx, bool sum_slabs = true) {
+    if (c->sparse && c->sp_blocked) {        // W^T . Q over the CSC order, row block by row block (sparseb.hip.h)
+        EventPair evs{};
+        if (c->profiling) evs = begin_event(c, c->ev_col);
+        const int kcb = (int)((c->k + 63) / 64);
+        const unsigned gridb = (unsigned)((int64_t)c->sp_rb * c->f);
+#define KL_SPB_N(KCV) hipLaunchKernelGGL((k_spb_n<T, KCV>), dim3(gridb), dim3(64), 0, c->stream, (const int64_t *)c->csc_blkptr, (const int *)c->csc_rows32, \
+        (const int *)c->csc_perm32, (const T *)c->sp_q, (const T *)c->W[widx], (T *)c->sp_NT, c->k, c->f, c->sp_rb, (const DevState *)c->st)
+        if (kcb <= 1) KL_SPB_N(1); else if (kcb == 2) KL_SPB_N(2); else if (kcb <= 4) KL_SPB_N(4); else KL_SPB_N(8);
+#undef KL_SPB_N
+        hipLaunchKernelGGL((k_spb_numer<T>), dim3((unsigned)((c->f + 31) / 32), (unsigned)((c->k + 31) / 32)), dim3(256), 0, c->stream,
+                           (const T *)c->sp_NT, c->sp_rb, (T *)c->numer, c->k, c->f, (const DevState *)c->st);
+        HIPCHK(hipGetLastError());
+        if (c->profiling) HIPCHK(hipEventRecord(evs.b, c->stream));
+        return;
+    }
     if (c->sparse) {        // W^T . Q, one block per feature column (CSC order)
         EventPair evs{};
         if (c->profiling) evs = begin_event(c, c->ev_col);
@@ -1773,6 +1821,40 @@ int klnmf_set_problem_sparse(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int6
         c->hpart = c->hseg_n > 1 ? (double *)c->dalloc(sizeof(double) * (size_t)k * c->hseg_n) : nullptr;
         c->sp_wpart = (double *)c->dalloc(sizeof(double) * c->sp_nblk * k);
         c->sp_prod = (double *)c->dalloc(sizeof(double) * k);
+        // blocks for the L2 (sparseb.hip.h): kSpBlockBytes of H^T per column block / of W per row block, as many blocks as the
+        // slabs of partial sums allow (1 GiB each)
+        c->sp_blocked = k <= 512 && nnz > 0 && n < ((int64_t)1 << 31) && f < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 31);
+        if (c->sp_blocked) {
+            const int64_t per = std::max<int64_t>(64, (kSpBlockBytes / (int64_t)(k * es)) / 64 * 64);
+            const int64_t slab_cap = (int64_t)1 << 30;
+            // Measured (round 5, 20 000 x 110 000, 0.5 %, k = 50, fp64; profiles/r05_sparse_blocks.txt): 1, 2, 4, 8 or 15 column blocks and
+            // 1 or 3 row blocks give the same iteration within 5 % -- the passes are bound by the latency chain of a wave's trips
+            // (index load -> gathers -> reduction), not by where the gathered rows come from.  One block each unless asked
+            // (KLNMF_SP_CB / KLNMF_SP_RB, development switches; `per` = rows of a block that fit the L2).
+            int64_t cb = 1, rb = 1;
+            (void)per;
+            const DevSwitches sw = DevSwitches::read();
+            if (sw.sp_cb > 0) cb = std::min<int64_t>(sw.sp_cb, (f + 63) / 64);
+            if (sw.sp_rb > 0) rb = std::min<int64_t>(sw.sp_rb, (n + 63) / 64);
+            cb = std::max<int64_t>(1, std::min(cb, slab_cap / std::max<int64_t>(1, n * k * (int64_t)es)));
+            rb = std::max<int64_t>(1, std::min(rb, slab_cap / std::max<int64_t>(1, f * k * (int64_t)es)));
+            cb = std::min<int64_t>(cb, ((int64_t)1 << 31) / std::max<int64_t>(1, n) - 1);      // (blocks x rows ride on gridDim.x)
+            rb = std::min<int64_t>(rb, ((int64_t)1 << 31) / std::max<int64_t>(1, f) - 1);
+            if (cb < 1 || rb < 1) c->sp_blocked = false;
+            c->sp_cb = (int)cb; c->sp_rb = (int)rb;
+            c->sp_cb_cols = (f + cb - 1) / cb; c->sp_rb_rows = (n + rb - 1) / rb;
+        }
+        if (c->sp_blocked) {
+            c->sp_idx32 = (int *)c->dalloc(sizeof(int) * nnz);
+            c->csc_rows32 = (int *)c->dalloc(sizeof(int) * nnz);
+            c->csc_perm32 = (int *)c->dalloc(sizeof(int) * nnz);
+            c->sp_blkptr = (int64_t *)c->dalloc(sizeof(int64_t) * n * (c->sp_cb + 1));
+            c->csc_blkptr = (int64_t *)c->dalloc(sizeof(int64_t) * f * (c->sp_rb + 1));
+            c->sp_loss_part = (double *)c->dalloc(sizeof(double) * (size_t)c->sp_cb * n);
+            c->sp_G = c->dalloc((size_t)c->sp_cb * n * k * es);
+            c->sp_NT = c->dalloc((size_t)c->sp_rb * f * k * es);
+            c->sp_bad = (int *)c->dalloc(sizeof(int));
+        }
         reset_state(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_problem = true;
@@ -1797,6 +1879,22 @@ int klnmf_upload_csr(klnmf_ctx *c, int dtype, const int64_t *indptr, const int64
             HIPCHK(hipMemcpyAsync(c->csc_perm, csc_perm, sizeof(int64_t) * c->nnz, hipMemcpyHostToDevice, c->stream));
             // values: through the dense setter (dtype conversion) as a 1 x nnz matrix
             set_matrix(c, data, dtype, 1, c->nnz, c->sp_data, nullptr, 0);
+        }
+        if (c->sp_blocked) {
+            // block pointers by binary search in the sorted rows / columns, int32 copies of the indices (sparseb.hip.h)
+            HIPCHK(hipMemsetAsync(c->sp_bad, 0, sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_spb_blkptr, dim3(grid_for(c->n * (c->sp_cb + 1), 256, 1 << 20)), dim3(256), 0, c->stream,
+                               (const int64_t *)c->sp_indptr, (const int64_t *)c->sp_indices, c->n, c->sp_cb, c->sp_cb_cols, c->sp_blkptr, c->sp_bad);
+            hipLaunchKernelGGL(k_spb_blkptr, dim3(grid_for(c->f * (c->sp_rb + 1), 256, 1 << 20)), dim3(256), 0, c->stream,
+                               (const int64_t *)c->csc_indptr, (const int64_t *)c->csc_rows, c->f, c->sp_rb, c->sp_rb_rows, c->csc_blkptr, c->sp_bad);
+            hipLaunchKernelGGL(k_spb_narrow, dim3(grid_for(c->nnz, 256, 8192)), dim3(256), 0, c->stream, (const int64_t *)c->sp_indices, c->sp_idx32, c->nnz);
+            hipLaunchKernelGGL(k_spb_narrow, dim3(grid_for(c->nnz, 256, 8192)), dim3(256), 0, c->stream, (const int64_t *)c->csc_rows, c->csc_rows32, c->nnz);
+            hipLaunchKernelGGL(k_spb_narrow, dim3(grid_for(c->nnz, 256, 8192)), dim3(256), 0, c->stream, (const int64_t *)c->csc_perm, c->csc_perm32, c->nnz);
+            HIPCHK(hipGetLastError());
+            int bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, c->sp_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (bad) fail(KLNMF_ERR_ARG, "klnmf_upload_csr: the column indices of every row (and the rows of every column in the CSC arrays) must be sorted");
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         c->v_uploaded = true;

@@ -1,4 +1,5 @@
-// CSR input (next-row N3): the reference's sparse branch, exact arithmetic (T = double / float).
+// CSR input (next-row N3): the reference's sparse branch, exact arithmetic (T = double / float) -- the unblocked kernels (k > 512 and
+// degenerate shapes), the sums around the passes and the helpers; the product kernels for k <= 512 are in sparseb.hip.h.
 //
 // With scipy-sparse X the reference evaluates W.H and the ratio only on the stored entries of X
 // (nmf.py:52-70 `_special_sparse_dot`, 331-334 `_Q`): Q is sparse with X's structure, the W rule is
@@ -63,60 +64,6 @@ template <typename T>
 struct LaneTransposeSum<T, 1> {
     static __device__ __forceinline__ T run(const T (&v)[1], int) { return v[0]; }
 };
-
-// One wave per row: q_p = (x_p + eps) / (W_i . H_:,j_p + eps), loss partial of the row (fp64).
-// The wave takes 64 stored entries at a time.  Lane l holds components l, l+64, ... of the row of W in
-// registers; for entry u every lane reads the same components of H^T's row j_u (one coalesced k-vector at a
-// wave-uniform address), which leaves 64 vectors of per-lane partial products; LaneTransposeSum turns them
-// into the 64 dot products, one per lane, and the division and the logarithm run with all lanes active.
-// (Measured on the 11 M-entry test matrix, fp64: lane-per-entry with a sequential k-loop 3.0 ms -- every
-// lane walks a different row of H^T; one entry at a time with a wave reduction and lane 0 taking the
-// logarithm 2.7 ms -- the fp64 log of one lane costs the wave as much as 64 of them; this version: see
-// DESIGN 4.5.)
-// NB = entries per trip: 64 (all lanes end up with one dot product) or 32 (round 4, fp64: the 64 partial-product vectors of
-// a trip are 128 registers, the kernel had 170 and ran two waves per SIMD -- every wave a serial chain of index load, 64
-// gathers, reduction, logarithm with nobody to cover its latencies: 2.07 ms for 11 M entries = 2.1 TB/s of gathers where the
-// same gathers in k_sp_w run at 6.5 TB/s.  With 32 entries per trip the dot products end up twice, in both lane halves (one
-// more exchange), the lower half takes division and logarithm; half the registers per trip, twice the waves per SIMD).
-template <typename T, int KC, int NB = 64>      // KC = ceil(k / 64) <= 8
-__global__ __launch_bounds__(64) void k_sp_q(const int64_t *indptr, const int64_t *indices, const T *data, const T *W,
-                                              const T *HT, T *q, double *row_loss, int64_t k, T eps, int write_q,
-                                              const DevState *st) {
-    static_assert(NB == 64 || NB == 32, "entries per trip");
-    if (st && st->stop) return;
-    const int64_t i = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int el = lane & (NB - 1);            // the entry of the trip this lane ends up with
-    T w[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) w[c] = (64 * c + lane < k) ? W[i * k + 64 * c + lane] : T(0);
-    double local = 0;
-    const int64_t p0 = indptr[i], p1 = indptr[i + 1];
-    for (int64_t p = p0; p < p1; p += NB) {
-        const bool mine = lane < NB && p + lane < p1;
-        const bool have = p + el < p1;
-        const int64_t my_j = have ? indices[p + el] : 0;      // past the end: row 0 of H^T, result unused
-        const T x = mine ? data[p + lane] : T(0);              // (requested with the indices: one round trip, not two)
-        T part[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const T *h = HT + lane_value(my_j, u) * k;
-            part[u] = T(0);
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-                if (64 * c + lane < k) part[u] += w[c] * h[64 * c + lane];
-        }
-        T wh = LaneTransposeSum<T, NB>::run(part, lane);
-        if (NB == 32) wh += __shfl_xor(wh, 32);                // the two lane halves each summed their own 32 lanes
-        if (mine) {
-            const T qq = (x + eps) / (wh + eps);
-            if (write_q) q[p + lane] = qq;
-            local += (double)(x * log(qq)) - (double)x;
-        }
-    }
-    local = wave_sum(local);
-    if (lane == 0) row_loss[i] = local;
-}
 
 // General k (> 512): every lane takes its own entries and loops over the components.
 template <typename T>
