@@ -422,12 +422,15 @@ def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fe
     n, f, k = args.n, args.f, args.k
     iters_per_fit = args.warmup + args.steps
     # ---- the dictionary: `train_iters` fit iterations from H0
-    model.set_H(H0)
-    model.init_W()
-    model.begin()
-    model.iterate_many(args.train_iters, fit=True, tol=0.0)
-    model.end()
-    H = model.get_H()
+    if args.train_iters > 0:
+        model.set_H(H0)
+        model.init_W()
+        model.begin()
+        model.iterate_many(args.train_iters, fit=True, tol=0.0)
+        model.end()
+        H = model.get_H()
+    else:
+        H = np.asarray(H0, dtype=np.float64)           # (PMC passes: no fit launches among the counted ones)
     tmodel, fs = model, f
     if args.slice and args.slice < f:
         # the first `slice` columns against the column-sliced dictionary (modality -> internal: learner.py:67-78)

@@ -34,7 +34,7 @@ __host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 
 // [64][KP] table -- 16 blocks per address, 64 x KP addresses: no hot line -- which ONE block of
 // the launch behind the column pass turns into the next iteration's scales (w8s = those scales: computed by k_post from the
 // previous conversion's table into the buffer the host swaps in as w8s).
-__global__ __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
+KL_GLOBAL __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
                                                     const float *w8s, const DevState *st, int *sat, int probe_col,
                                                     unsigned *tab64) {
     const int ld8 = w8_ld(kp);

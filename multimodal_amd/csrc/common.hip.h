@@ -3,13 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Non-template kernels defined in these headers: external linkage in the library's main translation unit, internal (and
-// dropped as unused) in the translation units that only instantiate k_rowpass4 (rowpass4_inst_*.hip, built in parallel).
-#ifdef KL_INST_TU
+// Non-template kernels defined in these headers have internal linkage: the library is several translation units (ctx.hip.h),
+// each of which compiles the kernels it launches.
 #define KL_GLOBAL static __global__
-#else
-#define KL_GLOBAL __global__
-#endif
 
 namespace klnmf {
 
@@ -30,7 +26,7 @@ struct DevState {
     double corr_eps;   // sum over the stored V of x ln(1 + eps/x): what the loss of an update pass WITHOUT the numerator's eps
                        // (ratio x / (W.H + eps): mfma4.hip.h, NE) lacks against the reference's x ln((x + eps) / (W.H + eps))
     double nnz_x;      // entries of the stored V that are > 0 (counted at upload): the fp8 decision of a loop needs enough of them per
-                       // column, not enough ROWS (klnmf_api.hip, begin_fp8_loop)
+                       // column, not enough ROWS (api_loop.hip, begin_fp8_loop)
     int stop;          // stop rule fired (the `break` of nmf.py:216)
     int n_done;        // updates executed == len(errors)
     int v_overflow;    // uploaded values that exceeded the fp16 range announced with klnmf_set_v_max (saturated)

@@ -315,7 +315,7 @@ __device__ __forceinline__ void decide_here(const DecideArgs &d, double err) {
 }
 
 // Sum of `count` doubles in a fixed order (deterministic), one block.
-__global__ __launch_bounds__(1024) void k_sum_doubles(const double *part, int64_t count,
+KL_GLOBAL __launch_bounds__(1024) void k_sum_doubles(const double *part, int64_t count,
                                                       double *out, const DevState *st,
                                                       DecideArgs dec = DecideArgs{0, nullptr, 0.0, nullptr, 0}) {
     if (st && st->stop) return;

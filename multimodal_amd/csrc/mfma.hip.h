@@ -127,7 +127,7 @@ struct RowPassArgs {
     // blockIdx.y = column chunk of ct_chunk tiles; the workgroup leaves its part of Q.H^T in gpart[chunk][row][KP] and
     // its loss terms in loss_part[chunk * nrt + rt]; k_wrule_slabs sums the chunks and applies the W rule.  null: whole rows.
     // A launch may cover only the workgroups from wg0 on (hybrid update pass: the full rounds of workgroups run whole
-    // rows, the last partial round runs column-split so that it fills the chip: klnmf_api.hip, fast_rowpass); the split
+    // rows, the last partial round runs column-split so that it fills the chip: api_loop.hip, fast_rowpass); the split
     // launch then addresses gpart and the chunks' extra loss parts relative to its first row tile rt0 = 8 * wg0:
     // gpart[chunk][rt - rt0 ...], loss_part[nrt + (chunk - 1) * (nrt - rt0) + rt - rt0] for chunk >= 1.
     float *gpart;
@@ -135,7 +135,7 @@ struct RowPassArgs {
     int wg0, rt0;
     // row tiles per workgroup of the ping-pong pass (0 = its wave count).  One round of workgroups that leaves CUs idle
     // (50 000 rows = 196 workgroups of 8 row tiles on 256 CUs) is spread over more of them with 7, 6, ... row tiles per
-    // workgroup, the workgroup's last waves idling: such problems are HBM-bound per CU (klnmf_api.hip, fast_rowpass)
+    // workgroup, the workgroup's last waves idling: such problems are HBM-bound per CU (api_loop.hip, fast_rowpass)
     int rpw;
     // fp8 x fp8 column pass (colq8x.hip.h): the W rule also leaves the e4m3 image of W_new (f16 image / w8s[component],
     // exactly as k_w8_from_wb converts it) and this wave's column maxima of the f16 image; null: not written

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 // and in the loss term), so no conversion instruction is needed -- the epilogue's VALU time
                 // adds to the matrix time of the SIMD, every instruction counts
                 const float rinv = __builtin_amdgcn_rcpf(EP ? d[e] : d[e] + eps_d);      // EP: eps came in through MFMA-1
-                // NE (Q8 = 2; klnmf_api.hip chooses it per loop from the data's mean): the ratio as x * r.  Against the reference's
+                // NE (Q8 = 2; api_loop.hip, begin_fp8_loop, chooses it per loop from the data's mean): the ratio as x * r.  Against the reference's
                 // (x + eps) * r that is a relative eps / x per element -- chosen only where eps / mean(V) <= 1e-5 (loss record within
                 // 1.5e-6, factors within 2.5e-5 of their maxima over 50 iterations: DESIGN.md section 8, h33) --, no logarithm sees
                 // a zero ratio (the 2^-100 addend above), and the loss gets the exact constant sum x ln(1 + eps/x) back

@@ -105,7 +105,7 @@ __device__ __forceinline__ int mon_row_tile(const MonArgs &a, int s) {
     return (int)((((int64_t)s * a.nrt_data) / a.nsamp + a.rot) % a.nrt_data);
 }
 
-__global__ __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
+KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
     if (a.st->stop) return;
     KL_FP16_SATURATE();
     constexpr int AC = 128;                                   // components per staged chunk

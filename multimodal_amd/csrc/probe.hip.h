@@ -28,7 +28,7 @@ __device__ __forceinline__ void glds_copy(const unsigned char *gsrc, KL_LDS unsi
 }
 
 // P1: D = A[32x16] . B[16x32] through the documented fragment maps.
-__global__ void k_probe_mfma(const float *A, const float *B, float *D) {
+KL_GLOBAL void k_probe_mfma(const float *A, const float *B, float *D) {
     const int l = threadIdx.x, r = l & 31, h = l >> 5;
     opx8 a, b;
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ void k_probe_mfma(const float *A, const float *B, float *D) {
 }
 
 // P2: transposed LDS read with the row-pass addressing (image rows = k index).
-__global__ void k_probe_tr(short *out, int s, int u) {
+KL_GLOBAL void k_probe_tr(short *out, int s, int u) {
     __shared__ __attribute__((aligned(16))) unsigned char img[64 * kHRowB];
     const int l = threadIdx.x;
     for (int e = l; e < 64 * 64; e += 64) {                      // logical (row, col) -> permuted image
@@ -74,7 +74,7 @@ __global__ void k_probe_tr(short *out, int s, int u) {
 
 // P3: X = A0.B0 (32x32, K=16) kept in the accumulator, converted to bf16 and fed
 // as the B operand of Y = A2[32x32] . X with the permuted k order.
-__global__ void k_probe_chain(const float *A0, const float *B0, const float *A2, float *Y) {
+KL_GLOBAL void k_probe_chain(const float *A0, const float *B0, const float *A2, float *Y) {
     const int l = threadIdx.x, r = l & 31, h = l >> 5;
     opx8 a, b;
 #pragma unroll
@@ -108,7 +108,7 @@ __global__ void k_probe_chain(const float *A0, const float *B0, const float *A2,
 }
 
 // P4: global_load_lds round trip (2 rounds of 8 KiB, 512 threads).
-__global__ __launch_bounds__(kThreads) void k_probe_glds(const unsigned char *src, unsigned char *dst) {
+KL_GLOBAL __launch_bounds__(kThreads) void k_probe_glds(const unsigned char *src, unsigned char *dst) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     KL_LDS unsigned char *smem = (KL_LDS unsigned char *)smem_raw;
     glds_copy(src, smem, 2, threadIdx.x);

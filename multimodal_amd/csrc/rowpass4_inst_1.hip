@@ -1,6 +1,5 @@
-// Explicit instantiations of k_rowpass4, part 1 of 3 (rowpass4_list.hip.h): compiled in parallel with klnmf_api.hip
-// (-DKL_SPLIT_TU) and linked into libklnmf.so by __graft_entry__.build() / scripts/build_lib.py.
-#define KL_INST_TU
+// Explicit instantiations of k_rowpass4, part 1 of 3 (rowpass4_list.hip.h): compiled in parallel with the api_*.hip units
+// and linked into libklnmf.so by __graft_entry__.build() / scripts/build_lib.py.
 #include "mfma4.hip.h"
 #include "rowpass4_list.hip.h"
 

@@ -1,7 +1,6 @@
-// Every instantiation of k_rowpass4 the library launches (launch_rowpass4_kt in klnmf_api.hip), as X-macro lists: the
-// translation units rowpass4_inst_*.hip instantiate them (explicit instantiation definitions), klnmf_api.hip -- built with
-// -DKL_SPLIT_TU -- only declares them (extern template), so that the four files compile in parallel.  Without KL_SPLIT_TU
-// klnmf_api.hip is the whole library in one translation unit (experiment builds, `hipcc -c` of the single file).
+// Every instantiation of k_rowpass4 the library launches (launch_rowpass4_kt in api_loop.hip), as X-macro lists: the
+// translation units rowpass4_inst_*.hip instantiate them (explicit instantiation definitions), ctx.hip.h only declares them
+// (extern template), so that the instantiations compile in parallel with the host-side units (__graft_entry__.compile_library).
 //   X(KT, ODD, MODE, EP, NW, SPLIT, Q8)
 #pragma once
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_sp_dots(const double *wpart, int64_t nb
 }
 
 // loss = sum_i row_loss[i] + sum_a prod[a] ; one block, fixed order.
-__global__ __launch_bounds__(1024) void k_sp_loss(const double *row_loss, int64_t n, const double *prod, int64_t k,
+KL_GLOBAL __launch_bounds__(1024) void k_sp_loss(const double *row_loss, int64_t n, const double *prod, int64_t k,
                                                    double *out, const DevState *st,
                                                    DecideArgs dec = DecideArgs{0, nullptr, 0.0, nullptr, 0}) {
     if (st && st->stop) return;

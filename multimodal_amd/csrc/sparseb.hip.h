@@ -27,7 +27,7 @@ constexpr int64_t kSpBlockBytes = (int64_t)3 << 20;       // of H^T (column bloc
 
 // blkptr[r][b] = first position in [ptr[r], ptr[r+1]) whose index is >= b * width (b = 0 .. nb; blkptr[r][nb] = ptr[r+1]);
 // idx sorted ascending inside every row.  bad: set when a row is not sorted.
-__global__ void k_spb_blkptr(const int64_t *ptr, const int64_t *idx, int64_t rows, int nb, int64_t width, int64_t *blkptr, int *bad) {
+KL_GLOBAL void k_spb_blkptr(const int64_t *ptr, const int64_t *idx, int64_t rows, int nb, int64_t width, int64_t *blkptr, int *bad) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= rows * (nb + 1)) return;
     const int64_t r = e / (nb + 1);
@@ -44,7 +44,7 @@ __global__ void k_spb_blkptr(const int64_t *ptr, const int64_t *idx, int64_t row
         for (int64_t p = p0 + 1; p < p1; ++p)
             if (idx[p] < idx[p - 1]) { *bad = 1; break; }
 }
-__global__ void k_spb_narrow(const int64_t *src, int *dst, int64_t count) {
+KL_GLOBAL void k_spb_narrow(const int64_t *src, int *dst, int64_t count) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) dst[e] = (int)src[e];
 }
 

@@ -1,17 +1,18 @@
 """Next-row N3 with a roofline: the reference's CSR branch (nmf.py:52-70, 301-308, 331-334, 342, 349 -- SDDMM + two SpMMs per
-fit iteration, csrc/sparse.hip.h) on an Acorns-shaped matrix (HAC histograms, f = 110 000 columns, very
+fit iteration, csrc/sparseb.hip.h) on an Acorns-shaped matrix (HAC histograms, f = 110 000 columns, very
 sparse): 20 000 x 110 000, 0.5 % stored entries, k = 50.  Prints ONE JSON line in bench.py's shape.
 
     python3 scripts/bench_sparse.py [--precision f64|f32] [--steps 10] [--no-cpu-baseline]
 
-Roofline (HBM-bound integer / gather work, no MFMA): the ALGORITHMIC bytes of one fit iteration are
-    stored entries:  SDDMM  nnz (idx 8 + x es + q es)   W rule  nnz (idx 8 + q es)   H rule  nnz (row 8 + perm 8 + q es)
-    gathers:         one k-vector per stored entry and product: 3 nnz k es   (rows of H^T twice, rows of W once)
-    factors:         W read by the SDDMM, read + written by the W rule, read by the column sums: 4 n k es;
-                     H: transpose (2), dots (1), numerator written (1), H rule (3), = 7 k f es
-`roofline.achieved` = those bytes / the iteration's time (the gathers are what a cache-less machine would move; on this part
-Infinity Cache / L2 serve a share of them -- `hbm_minimal_bytes` is the count without them).  CPU baseline: the scipy
-restatement of the same branch (oracle.sparse_fit_transform), fp64, on a row sample, scaled linearly in n."""
+Roofline (HBM-bound integer / gather work, no MFMA).  `roofline.frac` is quoted on the COMPULSORY bytes of one fit iteration,
+    stored entries:  fused ratio + W rule pass  nnz (idx 4 + x es + q es written)   H pass  nnz (row 4 + perm 4 + q es)
+    factors:         W: read by the fused pass, its partial sums written and read, W_new written, W read again, column sums: 6 n k es
+                     H: transpose (2), dots (1), partial numerator written and read (2), numerator (1), H rule (3) = 9 k f es
+and the figure that includes the GATHERS -- one k-vector per stored entry and pass, 2 nnz k es (rows of H^T once, rows of W
+once), what a cache-less machine would move and what the Infinity Cache / L2 actually serve -- stands beside it
+(`with_gathers`).  `traffic`: HBM bytes per iteration from the committed PMC passes (profiles/r05_pmc_traffic_sparse.json:
+FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs).  CPU baseline: the scipy restatement of the same branch
+(oracle.sparse_fit_transform), fp64, on a row sample, scaled linearly in n."""
 import argparse
 import json
 import os
@@ -74,10 +75,19 @@ def main():
             c.profile_enable(False)
             errs, nd, st = c.loop_end(args.steps + args.warmup)
     t = sorted(seg)[len(seg) // 2] / args.steps
-    entries = nnz * ((8 + 2 * es) + (8 + es) + (16 + es))
-    gathers = 3 * nnz * k * es
-    factors = 4 * n * k * es + 7 * k * f * es
+    entries = nnz * ((4 + 2 * es) + (8 + es))
+    gathers = 2 * nnz * k * es
+    factors = 6 * n * k * es + 9 * k * f * es
     alg = entries + gathers + factors
+    compulsory = entries + factors
+    traffic = None
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_sparse.json')))
+        for w in d.get('workloads', []):
+            if (w.get('n'), w.get('f'), w.get('k'), w.get('precision')) == (n, f, k, args.precision):
+                traffic = w
+    except Exception:
+        pass
     out = {
         'metric': 'nmf_update_iterations_per_sec', 'value': 1.0 / t, 'unit': 'it/s', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * t, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
@@ -90,16 +100,18 @@ def main():
         'valid': bool(nd == args.steps + args.warmup and not st),
         'loss_first': errs[0], 'loss_last': errs[-1],
         'loss_finite_and_decreasing': bool(all(b < a for a, b in zip(errs, errs[1:]))),
-        'roofline': {'bound': 'hbm', 'kernel': 'the whole iteration (k_sp_q SDDMM + loss, k_sp_w, k_sp_n, dense H rule)',
-                     'achieved': alg / t / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': alg / t / 1e9 / PEAK_HBM_GBS,
-                     'traffic': None,
-                     'algorithmic_bytes': alg, 'of_which': {'stored_entries': entries, 'gathers': gathers, 'factors': factors},
-                     'hbm_minimal_bytes': entries + factors,
-                     'frac_of_hbm_minimal': (entries + factors) / t / 1e9 / PEAK_HBM_GBS},
-        'kernels': {'k_sp_q (SDDMM + loss)': {'avg_launch_ms': prof['rowpass_ms'] / max(1, prof['rowpass_launches']),
-                                               'gather_gbs': nnz * k * es / (prof['rowpass_ms'] / max(1, prof['rowpass_launches']) * 1e-3) / 1e9},
-                    'k_sp_n (W^T.Q over CSC)': {'avg_launch_ms': prof['colpass_ms'] / max(1, prof['colpass_launches']),
-                                                'gather_gbs': nnz * k * es / (prof['colpass_ms'] / max(1, prof['colpass_launches']) * 1e-3) / 1e9}},
+        'roofline': {'bound': 'hbm', 'kernel': 'the whole iteration (k_spb_qw: ratio + loss + W rule fused; k_spb_n: W^T.Q over CSC; dense H rule)',
+                     'achieved': compulsory / t / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': compulsory / t / 1e9 / PEAK_HBM_GBS,
+                     'traffic': traffic['hbm_bytes_per_iteration'] if traffic else None,
+                     'traffic_source': 'profiles/r05_pmc_traffic_sparse.json' if traffic else None,
+                     'traffic_over_compulsory': traffic['hbm_bytes_per_iteration'] / compulsory if traffic else None,
+                     'compulsory_bytes': compulsory, 'of_which': {'stored_entries': entries, 'factors': factors},
+                     'with_gathers': {'bytes': alg, 'gathers': gathers, 'achieved_gbs': alg / t / 1e9,
+                                      'what': 'one k-vector per stored entry and pass (served by the Infinity Cache / L2, not HBM)'}},
+        'kernels': {'k_spb_qw (ratio + loss + W rule)': {'avg_launch_ms': prof['rowpass_ms'] / max(1, prof['rowpass_launches']),
+                                                         'gather_gbs': nnz * k * es / (prof['rowpass_ms'] / max(1, prof['rowpass_launches']) * 1e-3) / 1e9},
+                    'k_spb_n (W^T.Q over CSC)': {'avg_launch_ms': prof['colpass_ms'] / max(1, prof['colpass_launches']),
+                                                 'gather_gbs': nnz * k * es / (prof['colpass_ms'] / max(1, prof['colpass_launches']) * 1e-3) / 1e9}},
         'device': _native.device_info(0),
     }
     if not args.no_cpu_baseline:
@@ -116,9 +128,9 @@ def main():
                                          'sparse branch (%.2f s / iteration on the sample), scaled linearly in n' % (rows, iters, dt),
                                'cpu_model': host.get('cpu_model'), 'numpy': host.get('numpy')}
     print(json.dumps(out))
-    sys.stderr.write('%s: %.3f ms / iteration  (%.0f GB/s of %.2f GB algorithmic = %.0f %% of the HBM roof; SDDMM %.3f ms, W^T.Q %.3f ms)\n' % (
-        args.precision, 1e3 * t, alg / t / 1e9, alg / 1e9, 100 * alg / t / 1e9 / PEAK_HBM_GBS,
-        out['kernels']['k_sp_q (SDDMM + loss)']['avg_launch_ms'], out['kernels']['k_sp_n (W^T.Q over CSC)']['avg_launch_ms']))
+    sys.stderr.write('%s: %.3f ms / iteration  (%.2f GB compulsory = %.1f %% of the HBM roof; with the gathers %.2f GB = %.0f GB/s; fused pass %.3f ms, W^T.Q %.3f ms)\n' % (
+        args.precision, 1e3 * t, compulsory / 1e9, 100 * compulsory / t / 1e9 / PEAK_HBM_GBS, alg / 1e9, alg / t / 1e9,
+        out['kernels']['k_spb_qw (ratio + loss + W rule)']['avg_launch_ms'], out['kernels']['k_spb_n (W^T.Q over CSC)']['avg_launch_ms']))
 
 
 if __name__ == '__main__':

@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, 'multimodal_amd', 'csrc', 'klnmf_api.hip')
+src = os.path.join(ROOT, 'multimodal_amd', 'csrc', 'api_loop.hip')
 cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-std=c++17', '--cuda-device-only', '-c',
        '-Rpass-analysis=kernel-resource-usage', '-o', '/tmp/klnmf_dev.o', src] + sys.argv[1:]
 txt = subprocess.run(cmd, capture_output=True, text=True).stderr

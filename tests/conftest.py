@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# the library's development switches (KLNMF_QTILE=8, KLNMF_COL8, KLNMF_Q8_MONITOR, ...: csrc/klnmf_api.hip, DevSwitches) are
+# the library's development switches (KLNMF_QTILE=8, KLNMF_COL8, KLNMF_Q8_MONITOR, ...: csrc/ctx.hip.h, DevSwitches) are
 # honoured only under KLNMF_DEV=1; the tests use them to reach every kernel variant
 os.environ.setdefault('KLNMF_DEV', '1')
 

@@ -664,7 +664,7 @@ def test_nearest_neighbour_measures_match_reference_golden():
 @pytest.mark.gpu
 @pytest.mark.parametrize('precision', ['bf16', 'f64'])
 def test_reused_device_blocks_do_not_change_results(precision):
-    """Contexts take their device memory from a per-process block cache (klnmf_api.hip, DevBlockCache): a fit whose
+    """Contexts take their device memory from a per-process block cache (csrc/ctx.hip.h, DevBlockCache): a fit whose
     buffers are recycled blocks of an earlier, differently shaped problem (padding regions included) must give the
     bits of the same fit on fresh memory."""
     Xa, Ha = orc.synthetic_V(3, 300, 200, 12), orc.synthetic_H0(3, 200, 12)
@@ -798,7 +798,7 @@ def test_data_of_any_magnitude_keeps_the_reference_eps(n, f, k, scale):
     it through the matrix product as an fp16 pair whose row value is eps x (storage factor) x 2^10: found by
     scripts/data_fuzz.py (round 4) -- beyond 65504 for max(V) < 5e-6 (losses 4-9 % off at V x 1e-6, k = 40) and flushed to
     zero for max(V) > 1e7 (NaN losses at 70 000 rows x 1e6: the padded rows divided 0 by 0).  Outside the pair's range the
-    kernels now add eps in fp32 (klnmf_api.hip, choose_eps_carrier)."""
+    kernels now add eps in fp32 (csrc/api_context.hip, choose_eps_carrier)."""
     rs = np.random.RandomState(n + f + k)
     X = (rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))) * scale
     H0 = orc.synthetic_H0(11, f, k)

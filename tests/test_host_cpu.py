@@ -238,7 +238,8 @@ def test_build_staleness_sees_every_kernel_header():
     glob of csrc/, so a header added later (round 2: colq8x.hip.h was missing from a hand-kept list) cannot be forgotten."""
     import __graft_entry__ as ge
     names = {os.path.basename(p) for p in ge._sources()}
-    for must in ('klnmf_api.hip', 'mfma4.hip.h', 'colq.hip.h', 'colq8x.hip.h', 'exact.hip.h', 'sparse.hip.h', 'klnmf.h',
+    for must in ('ctx.hip.h', 'api_context.hip', 'api_loop.hip', 'api_comm.hip', 'api_eval.hip', 'mfma4.hip.h', 'colq.hip.h', 'colq8x.hip.h',
+                 'post.hip.h', 'monitor.hip.h', 'exact.hip.h', 'sparse.hip.h', 'sparseb.hip.h', 'klnmf.h',
                  'rowpass4_list.hip.h', 'rowpass4_inst_1.hip', 'rowpass4_inst_2.hip', 'rowpass4_inst_3.hip'):
         assert must in names
     if not os.path.exists(ge.LIB):
@@ -297,13 +298,13 @@ def test_bench_power_clock_sampler_is_harmless_without_a_card():
 
 
 def test_every_launched_rowpass4_instantiation_is_in_the_list():
-    """The parallel build declares the k_rowpass4 instantiations `extern` in klnmf_api.hip and defines them in
+    """The parallel build declares the k_rowpass4 instantiations `extern` in ctx.hip.h (launched from api_loop.hip) and defines them in
     rowpass4_inst_*.hip from the lists of rowpass4_list.hip.h: an instantiation that the launch code names but the lists lack
-    would be compiled a second time in the main unit (slow, silently); one that the lists name twice fails the build.  Checked
+    would be compiled a second time in the loop unit (slow, silently); one that the lists name twice fails the build.  Checked
     on the text: every `k_rowpass4<KTV, a, MODE, b, c, d, e>` pattern of the launch macros appears in the lists' shapes."""
     import re
     import __graft_entry__ as ge
-    api = open(os.path.join(ge.CSRC, 'klnmf_api.hip')).read()
+    api = open(os.path.join(ge.CSRC, 'api_loop.hip')).read()
     lst = open(os.path.join(ge.CSRC, 'rowpass4_list.hip.h')).read()
     launched = set()
     for m in re.finditer(r'k_rowpass4<KTV, (\d), MODE, (\d)(?:, (\w+), (\d)(?:, (\d))?)?>', api):
