@@ -291,6 +291,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         c->hseg_n = 1; c->hpart = nullptr;
         c->n = n; c->f = f; c->k = k; c->cap = cap;
         c->cur = 0;
+        c->w_is_init = false;
         c->sparse = false;
         c->v_uploaded = false;
         c->refusals_dirty = true;
@@ -774,7 +775,10 @@ int klnmf_set_H(klnmf_ctx *c, const void *src, int dtype) {
         set_matrix(c, src, dtype, c->k, c->f, c->H, c->H32, c->f_pad);
         if (!c->is_exact()) {
             fast_pack_H(c);          // hs-based scales (also leaves them in t_hs)
-            measure_and_pack(c);        // the W that is there (zeros, W0 of another dictionary, a klnmf_set_W) goes with it
+            // the W that is there (zeros, a klnmf_set_W, W0 = V.H_init^T of klnmf_init_W) goes with it; behind klnmf_init_W the
+            // first update still starts from W0 -- about f / k too small whatever dictionary is set now (transform with
+            // components_ != _init_dictionary: nmf.py:159-230) --, so the first update's ratio scale stays on
+            measure_and_pack(c, c->w_is_init);
         }
     });
 }
@@ -805,7 +809,7 @@ int klnmf_set_H_device(klnmf_ctx *c, const void *dsrc, int dtype, int64_t ld, in
         if (last) {
             if (!c->is_exact()) {
                 fast_pack_H(c);
-                measure_and_pack(c);
+                measure_and_pack(c, c->w_is_init);
             }
             HIPCHK(hipStreamSynchronize(c->stream));      // the caller's buffer may go away
         }
@@ -850,6 +854,7 @@ int klnmf_set_W(klnmf_ctx *c, const void *src, int dtype) {
         need_problem(c);
         if (!src) fail(KLNMF_ERR_ARG, "null source");
         set_matrix(c, src, dtype, c->n, c->k, c->W[c->cur], c->W32[c->cur], c->KP, c->v_scale);
+        c->w_is_init = false;
         if (!c->is_exact()) measure_and_pack(c);     // (all padded rows too: the eps carrier column in every row a tile can contain)
     });
 }

@@ -625,6 +625,7 @@ void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol, bool defer_to
         return;
     }
     const bool measured = c->images_measured;
+    c->w_is_init = false;
     fast_rowpass(c, ROW_UPDATE, fit);
     // measured image scales live for one update: the new W image already carries the hs-based scale (tnext); in a fit
     // the H rule re-packs the dictionary image anyway, in a transform the unchanged dictionary is re-packed here
@@ -861,6 +862,7 @@ int klnmf_init_W(klnmf_ctx *c) {
         } else if (c->is_exact()) EXACT_CALL(c, exact_W, c->V, 0);
         else fast_rowpass(c, ROW_INIT);
         c->cur ^= 1;
+        c->w_is_init = true;
         if (!c->is_exact()) measure_and_pack(c, true);     // W0 = V.H0^T scales with H0: images with measured scales for the first update
     });
 }

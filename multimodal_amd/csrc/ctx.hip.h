@@ -347,6 +347,8 @@ struct klnmf_ctx {
     float *tcur = nullptr, *t_hs = nullptr, *t_unit = nullptr;
     unsigned *wmax = nullptr;
     bool images_measured = false;    // the current images carry measured scales: valid for one update (see opnd_t)
+    bool w_is_init = false;          // the current W is W0 = V.H0^T of klnmf_init_W, untouched since: a dictionary set NOW still meets
+                                     // ratios of about f / k on its first update (the ratio scale of k_ratio_scale must stay on)
     float *NpartF = nullptr, *numerF = nullptr;
     double2 *loss_part2 = nullptr;
 

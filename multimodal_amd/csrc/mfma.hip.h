@@ -107,20 +107,18 @@ __device__ __forceinline__ opx8 pack8(const float *q) {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 struct RowPassArgs {
     const void *VtA;          // [nrt][nct] tiles of 16 values per lane (layout A), stored piece-major: [16-byte piece][64 lanes][16 B]
-    const opnd_t *Ht;         // [nst][KP][kHRow] dictionary stage images
     const opnd_t *Wb_old;     // [n_pad(+pad)][w_ld(KP)]
     const float *W32_old;     // [n_pad][KP]
     opnd_t *Wb_new;
     float *W32_new;
     double2 *loss_part;       // [nrt] (sum x*log2 q, sum y)
     const double *hsum;       // [KP] row sums of the 16-bit dictionary image (for sum(W.H)), see row_sum_wh
-    unsigned long long *stamps;   // diagnostic builds (-DKL_STAMPS): [nrt][8] cycle sums per phase
     unsigned char *Qt;            // ratio tiles for k_colpass_q ([nct][nrt][2 KiB], see there), or null (ping-pong pass only)
     const float *tcur;            // [KP] per-component scale t_a of the CURRENT images (W image = W32 * t, H image = H / t; see opnd_t)
     const float *tnext;           // [KP] scale the W rule packs the NEW W image with (the next dictionary image's)
     int kc;                       // eps-carrying pad component (see k_update_pack_H), -1 if none
     const DevState *st;
-    int nrt, nct, nst;        // row tiles, col tiles (even), stages = nct/2
+    int nrt, nct;             // row tiles, column tiles (a multiple of 4)
     float eps;                // c * 1e-8 (scaled units)
     int cq_on;                // the dictionary image carries the ratio scale 2^st->cq_e (k_ratio_scale): the denominator's eps is scaled with it
     // Column-split update pass of the ping-pong kernel (few rows: one workgroup per 256 rows would leave the chip idle):
@@ -141,8 +139,7 @@ struct RowPassArgs {
     // exactly as k_w8_from_wb converts it) and this wave's column maxima of the f16 image; null: not written
     unsigned char *W8;
     const float *w8s;         // [KP]
-    unsigned *w8max;          // [nrt][KP] float bit patterns
-    unsigned *w8tab;          // != nullptr: the maxima go by atomicMax into row (rt & 63) of this [64][KP] table instead (post.hip.h)
+    unsigned *w8tab;          // the maxima go by atomicMax into row (rt & 63) of this [64][KP] table (post.hip.h)
     int *w8_sat;              // entries of this image beyond e4m3's 448 (stored as 448) are counted here, as k_w8_from_wb does
     int w8_probe;             // the image's probe column (colq8x.hip.h; e4m3 1.0 in every row): KP - 1 or -1 (none)
 };

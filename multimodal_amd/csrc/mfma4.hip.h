@@ -808,12 +808,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     u32x4 o;
                     o[0] = __float_as_uint((float)mx8[m][0][0]); o[1] = __float_as_uint((float)mx8[m][0][1]);
                     o[2] = __float_as_uint((float)mx8[m][1][0]); o[3] = __float_as_uint((float)mx8[m][1][1]);
-                    if (a.w8tab != nullptr) {            // fused tail: 64-row table, emptied by k_post when it derives the next scales
-                        unsigned *tb8 = a.w8tab + (int64_t)(rt & 63) * KP + 32 * m + c4;
-                        atomicMax(tb8, o[0]); atomicMax(tb8 + 1, o[1]); atomicMax(tb8 + 2, o[2]); atomicMax(tb8 + 3, o[3]);
-                    } else {
-                        *(u32x4 *)(a.w8max + (int64_t)rt * KP + 32 * m + c4) = o;
-                    }
+                    // 64-row table, emptied by k_post when it derives the next scales
+                    unsigned *tb8 = a.w8tab + (int64_t)(rt & 63) * KP + 32 * m + c4;
+                    atomicMax(tb8, o[0]); atomicMax(tb8 + 1, o[1]); atomicMax(tb8 + 2, o[2]); atomicMax(tb8 + 3, o[3]);
                 }
             }
         }
