@@ -36,7 +36,7 @@ bool comm_multi(const klnmf_ctx *c) { return c->comm != nullptr && (c->comm_size
 // Loop entry.  Every rank must take the same decisions, or the others block in a collective for ever: the refusal counters
 // (a rank-local overflow, a rank-local operand range) are all-reduced (max) and every rank fails TOGETHER; the fp8 decision
 // is taken from the all-reduced sums, so that all ranks run the same kernels and N = 1 / N = 8 differ by summation order only.
-void comm_loop_entry(klnmf_ctx *c, int64_t planned) {
+void comm_loop_entry(klnmf_ctx *c) {
     if (c->sparse) fail(KLNMF_ERR_UNSUPP, "loops on a communicator: dense problems only");
     c->refusals_dirty = true;
     const Refusals mine = read_refusals(c);
@@ -62,7 +62,7 @@ void comm_loop_entry(klnmf_ctx *c, int64_t planned) {
                        : "another rank's shard of V exceeds the maximum given to klnmf_set_v_max: the sharded loop is refused on every rank");
     }
     c->refusals_dirty = false;
-    begin_fp8_loop(c, h[3], h[4], h[5], h[2] == 0.0 ? 1 : 0, planned);
+    begin_fp8_loop(c, h[3], h[4], h[5], h[2] == 0.0 ? 1 : 0);
 }
 
 // One iteration: row pass -> column pass (it does not depend on the stop decision) -> ONE grouped RCCL launch on the
@@ -199,10 +199,10 @@ int klnmf_run_sharded(klnmf_ctx *c, int64_t n_total, int64_t max_iter, int fit, 
         if (c->sparse) fail(KLNMF_ERR_UNSUPP, "klnmf_run_sharded: dense problems only");
         const bool multi = comm_multi(c);
         if (multi) {
-            comm_loop_entry(c, max_iter);
+            comm_loop_entry(c);
         } else {
             check_v_overflow(c);
-            begin_fp8_loop(c, -1.0, -1.0, -1.0, -1, max_iter);
+            begin_fp8_loop(c);
         }
         reset_state(c);
         c->loop_start_cur = c->cur;

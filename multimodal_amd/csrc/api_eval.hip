@@ -201,7 +201,7 @@ int klnmf_query_f64(klnmf_ctx *c, int what, double *value) {
         need_problem(c);
         if (!value) fail(KLNMF_ERR_ARG, "null value");
         if (what == KLNMF_QF_MON_STAT) { *value = c->stat_mon_max; return; }
-        if (what == KLNMF_QF_MON_THRESHOLD) { *value = (double)mon_threshold_for((float)c->loop_planned); return; }
+        if (what == KLNMF_QF_MON_THRESHOLD) { *value = (double)(c->sw.mon_threshold > 0.f ? c->sw.mon_threshold : kMonThreshold); return; }
         if (what == KLNMF_QF_MON_SPREAD) { *value = c->stat_mon_spread; return; }
         if (what == KLNMF_QF_MON_MIN_SPREAD) { *value = (double)kMonMinSpread; return; }
         if (what >= KLNMF_QF_MON_PART0 && what < KLNMF_QF_MON_PART0 + 3) { *value = c->stat_mon_dbg[what - KLNMF_QF_MON_PART0]; return; }

@@ -123,6 +123,8 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.nct = c->nct;
     a.eps = (float)(kEpsRatio * c->v_scale);
     a.cq_on = c->images_measured ? 1 : 0;
+    // stochastic rounding of fp8 ratio tiles: another stream per launch and per rank, the same streams for the same fit
+    a.sr_seed = ((unsigned)c->sr_launches++ * 0x9E3779B9u + 0x7F4A7C15u) ^ ((unsigned)c->comm_rank * 0xC2B2AE35u);
     // e4m3 image of W_new written by the W rule itself (KLNMF_COL8=2, whole-row launches): the maxima go to the 64-row table
     // k_post turns into the next scales, and the image is written from the loop's second iteration on, so that the third can
     // already multiply it
@@ -180,7 +182,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
             const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
             hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
                                c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
-                               (const DevState *)c->st, &c->st->w8_sat, w8_probe_col(c), c->w8tab);
+                               (const DevState *)c->st, &c->st->w8_sat, w8_probe_col(c), c->w8tab, a.sr_seed ^ 0x5bd1e995u);
             HIPCHK(hipGetLastError());
             c->w8_meas = true;
             c->conv_ran = true;
@@ -473,7 +475,8 @@ bool fused_w8_stage(klnmf_ctx *c) {
     const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
     hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1], c->W8, rows,
                        c->KP, (int)w_ld(c->KP), (const float *)c->w8s, (const DevState *)c->st,
-                       &c->st->w8_sat, w8_probe_col(c), c->w8tab);
+                       &c->st->w8_sat, w8_probe_col(c), c->w8tab,
+                       ((unsigned)c->sr_launches++ * 0x9E3779B9u + 0x7F4A7C15u) ^ ((unsigned)c->comm_rank * 0xC2B2AE35u));
     HIPCHK(hipGetLastError());
     c->w8_meas = true;
     c->conv_ran = true;
@@ -552,7 +555,7 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     if (a.do_sum && c->mon_pending) {
         a.mon = MonPost{c->mon_part, c->mon_spread, c->sw.mon_min_spread >= 0.f ? c->sw.mon_min_spread : kMonMinSpread,
                         c->sw.mon_threshold > 0.f ? 1.0f : kMonMaxCommon, c->mon_ncols,
-                        c->mon_noise_scale, c->sw.mon_threshold > 0.f ? c->sw.mon_threshold : mon_threshold_for((float)c->loop_planned)};
+                        c->mon_noise_scale, c->sw.mon_threshold > 0.f ? c->sw.mon_threshold : kMonThreshold};
         c->mon_pending = false;
     }
     a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne; a.cq_on = la.cq_on;
@@ -769,28 +772,25 @@ void raise_refusals(klnmf_ctx *c, const Refusals &r) {
 void check_v_overflow(klnmf_ctx *c) { raise_refusals(c, read_refusals(c)); }
 
 // Loop entry points only (klnmf_run, klnmf_run_sharded, klnmf_loop_begin): may THIS loop use fp8 ratio tiles (e4m3 of
-// ratio x sqrt(2) / 8, from its third iteration on)?  Four things decide, in this order:
-//   shape   q8_ok of klnmf_set_problem: enough rows per context that the tiles' bytes matter (32 769 / 65 536);
-//   length  at most kQ8MaxLoop (50) planned iterations -- klnmf_run's max_iter, the capacity of klnmf_set_problem for loops in
-//           pieces: what the e4m3 rounding does to the loss grows with the square of the iteration count (monitor.hip.h);
+// ratio x sqrt(2) / 8, stochastically rounded, from its third iteration on)?  Three things decide, in this order:
+//   shape   q8_ok of klnmf_set_problem: enough rows per context that the tiles' bytes matter (32 769 / 65 536), one column
+//           tile of data;
 //   range   the tiles end at 3584 / sqrt(2) (saturating): data whose largest entry is more than 256 times the mean entry can hold
 //           ratios beyond that for many iterations (a spike the model has not fitted yet) -- those keep the 16-bit tiles.  What
 //           still saturates in a loop that passed is corrected exactly (fix-up list) or, in bulk, ends the fp8 regime;
-//   what the e4m3 rounding does to THIS data's H numerator is not guessed here but MEASURED while the loop runs: the monitor
-//           (monitor.hip.h, launch_monitor) -- a loop that fails it continues on 16-bit tiles.  Round 4 held five more data
-//           rules at this place (components, columns, stored entries per column, ...), each added after a fuzz case had
-//           ended 2e-4 .. 1.2e-3 off the oracle; KLNMF_Q8_RULES=1 (development switch) re-applies the three that round 5's
-//           monitor replaced, for A/B runs.
+//   noise   what the e4m3 rounding does to THIS data's H numerator is not guessed here but MEASURED while the loop runs: the
+//           monitor (monitor.hip.h, launch_monitor), first as a dry run on the loop's first iteration -- a loop that fails it
+//           continues on 16-bit tiles.  (Round 4 held five data rules at this place, each added after a fuzz case had ended
+//           2e-4 .. 1.2e-3 off the oracle; all of them were symptoms of round-to-nearest tiles' bias: DESIGN.md section 6.)
 // KLNMF_QTILE = 8 (development) forces the tiles on, = 16 off.  `sum_x_global` / `cells_global` / `nnz_global`: the sums over ALL
 // ranks' shards (the sharded loop passes the all-reduced values, so that every rank takes the same path); negative: this
 // context's own.  `ok_all`: the conjunction of every rank's q8_ok (shards that straddle the row threshold must not mix tile
 // formats: since round 4 fp8-tile numerators are sqrt(2) larger than 16-bit-tile ones); negative: this context's own.
-void begin_fp8_loop(klnmf_ctx *c, double sum_x_global, double cells_global, double nnz_global,
-                           int ok_all, int64_t planned) {
+void begin_fp8_loop(klnmf_ctx *c, double sum_x_global, double cells_global, double nnz_global, int ok_all) {
     c->sw = DevSwitches::read();
-    c->loop_planned = planned > 0 ? planned : std::max<int64_t>(1, c->cap);
     c->q8_loop = false;
     c->iter_in_loop = 0;
+    c->sr_launches = 0;
     c->w8_meas = false;
     c->stat_q8_tiles = 0;
     c->stat_col8 = 0;
@@ -825,16 +825,9 @@ void begin_fp8_loop(klnmf_ctx *c, double sum_x_global, double cells_global, doub
         cells = (double)c->n * (double)c->f;
         nnz = ds.nnz_x;
     }
-    if (nnz < 0) nnz = cells;                 // (a caller that all-reduced only the two sums: dense data assumed)
+    (void)nnz;                                // (the stored-entry count stays in the ABI: no rule reads it since the monitor measures)
     const double mean = sum_x / c->v_scale / cells;
     c->q8_loop = c->v_max > 0 && mean > 0 && c->v_max <= 256.0 * mean;
-    if (c->loop_planned > kQ8MaxLoop) c->q8_loop = false;      // length: see monitor.hip.h
-    if (c->sw.q8_rules_r4) {
-        // round 4's data rules (kept for A/B runs against the monitor): fewer than four components or less than one column tile
-        // of data (dead zones of the e4m3 step around ratio 1), fewer stored entries per column than half the row threshold
-        if (c->k < 4) c->q8_loop = false;
-        if (nnz / (double)c->f < 0.5 * (c->big ? 65536.0 : 32768.0)) c->q8_loop = false;
-    }
     // The ratio without the numerator's eps (NE kernels, k <= 224): x / (W.H + eps) differs from the reference's
     // (x + eps) / (W.H + eps) by a relative eps / x per element.  Simulated in fp64 over 50 iterations (DESIGN_APPENDIX.md, h33)
     // the loss record moves by 0.06 .. 0.15 x eps / mean(V) and the factors by 0.5 .. 2.3 x eps / mean(V) of their maxima:
@@ -993,7 +986,7 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         if (max_iter < 0) fail(KLNMF_ERR_ARG, "max_iter < 0");
         if (max_iter > c->cap) fail(KLNMF_ERR_ARG, "max_iter exceeds the capacity given to klnmf_set_problem");
         check_v_overflow(c);
-        begin_fp8_loop(c, -1.0, -1.0, -1.0, -1, max_iter);
+        begin_fp8_loop(c);
         reset_state(c);
         c->loop_start_cur = c->cur;
         c->loop_hswaps = 0; c->loop_h0 = c->H32; c->loop_h1 = c->H32alt;

@@ -36,9 +36,8 @@ __host__ __device__ constexpr int w8_ld(int kp) { return kp + ((kp / 32) % 2 == 
 // previous conversion's table into the buffer the host swaps in as w8s).
 KL_GLOBAL __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned char *W8, int64_t rows, int kp, int wld,
                                                     const float *w8s, const DevState *st, int *sat, int probe_col,
-                                                    unsigned *tab64) {
+                                                    unsigned *tab64, unsigned sr_seed) {
     const int ld8 = w8_ld(kp);
-    typedef __attribute__((ext_vector_type(2))) short s16x2;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
     if (st->stop) return;
     KL_FP16_SATURATE();
@@ -71,10 +70,16 @@ KL_GLOBAL __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned ch
                 unsigned out[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    s16x2 w = {0, 0};
                     const f16x2 p0 = f16x2{v[q][4 * u], v[q][4 * u + 1]} * inv[2 * u], p1 = f16x2{v[q][4 * u + 2], v[q][4 * u + 3]} * inv[2 * u + 1];
-                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p0, 1.f, false);
-                    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, p1, 1.f, true);
+                    // stochastically rounded, as the row pass's own image (mfma4.hip.h, sr_pack4): the seed is a hash of the entry's place
+                    unsigned sd = ((unsigned)row * 0x9E3779B1u) ^ ((unsigned)(comp + 4 * u) * 0x85EBCA6Bu) ^ sr_seed;
+                    sd = (sd ^ (sd >> 15)) * 0x2C1B3C6Du;
+                    const unsigned r1 = (sd ^ (sd >> 12)) * 0x297A2D39u, r2 = (r1 & 0xffffffu) * 0x6C8E95u + 0x3C6EF35Fu;
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, p0[0], r1, 1.f, 0);
+                    w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, p0[1], r1 << 7, 1.f, 1);
+                    w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, p1[0], r2, 1.f, 2);
+                    w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, p1[1], r2 << 7, 1.f, 3);
                     const f16x2 top = __builtin_elementwise_max(p0, p1);                    // (448 is an f16 number)
                     nsat += (top[0] > (_Float16)448.f || top[1] > (_Float16)448.f) ? ((p0[0] > (_Float16)448.f) + (p0[1] > (_Float16)448.f)
                                                                                      + (p1[0] > (_Float16)448.f) + (p1[1] > (_Float16)448.f)) : 0;

@@ -170,7 +170,6 @@ struct DevSwitches {
     int col8 = -1;              // KLNMF_COL8 = 0: no fp8 x fp8 column pass; 1: at any size; 2: the W rule writes the e4m3 image itself
     int ne = -1;                // KLNMF_NE = 0 / 1: the update pass without the numerator's eps never / in every fp8 loop
     bool q8_fixup = true;       // KLNMF_Q8_FIXUP=0: no exact correction of large ratio entries (the tests' control run)
-    bool q8_rules_r4 = false;   // KLNMF_Q8_RULES=1: round 4's data rules at the loop's entry as well as the in-loop monitor (A/B runs)
     bool q8_monitor = true;     // KLNMF_Q8_MONITOR=0: no monitor
     float mon_threshold = 0.f, mon_min_spread = -1.f;      // KLNMF_MON_THRESHOLD / KLNMF_MON_MIN_SPREAD: the monitor's two thresholds (calibration runs)
     bool ratio_scale = true;    // KLNMF_RATIO_SCALE=0: no ratio scale of the first update
@@ -191,7 +190,6 @@ struct DevSwitches {
         d.col8 = num("KLNMF_COL8", -1);
         d.ne = num("KLNMF_NE", -1);
         d.q8_fixup = num("KLNMF_Q8_FIXUP", 1) != 0;
-        d.q8_rules_r4 = num("KLNMF_Q8_RULES", 0) != 0;
         d.q8_monitor = num("KLNMF_Q8_MONITOR", 1) != 0;
         if (const char *e = std::getenv("KLNMF_MON_THRESHOLD")) d.mon_threshold = (float)std::atof(e);
         if (const char *e = std::getenv("KLNMF_MON_MIN_SPREAD")) d.mon_min_spread = (float)std::atof(e);
@@ -301,8 +299,6 @@ struct klnmf_ctx {
     bool mon_dry_pending = false;             // ... and it was the dry run of the loop's second iteration: poll before the third
     int mon_ncols = 0; float mon_noise_scale = 0.f;
     int64_t mon_checks = 0, stat_mon_checks = 0, stat_mon_trips = 0;
-    int64_t loop_planned = 0;                 // iterations this loop may run (klnmf_run: max_iter; loops in pieces: the capacity of
-                                              // klnmf_set_problem): the monitor's threshold depends on it (monitor.hip.h)
     double stat_mon_max = 0.0, stat_mon_dbg[3] = {0, 0, 0}, stat_mon_spread = 1.0;
     bool stat_mon_gave_up = false;
     // the refusal counters of DevState (v_overflow, op_range) change only on uploads and image measurements: they are read
@@ -347,6 +343,7 @@ struct klnmf_ctx {
     float *tcur = nullptr, *t_hs = nullptr, *t_unit = nullptr;
     unsigned *wmax = nullptr;
     bool images_measured = false;    // the current images carry measured scales: valid for one update (see opnd_t)
+    unsigned sr_launches = 0;        // row pass launches of the current loop (the seeds of the tiles' stochastic rounding)
     bool w_is_init = false;          // the current W is W0 = V.H0^T of klnmf_init_W, untouched since: a dictionary set NOW still meets
                                      // ratios of about f / k on its first update (the ratio scale of k_ratio_scale must stay on)
     float *NpartF = nullptr, *numerF = nullptr;
@@ -465,11 +462,10 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
 Refusals read_refusals(klnmf_ctx *c);
 void raise_refusals(klnmf_ctx *c, const Refusals &r);
 void check_v_overflow(klnmf_ctx *c);
-void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cells_global = -1.0, double nnz_global = -1.0, int ok_all = -1,
-                    int64_t planned = -1);
+void begin_fp8_loop(klnmf_ctx *c, double sum_x_global = -1.0, double cells_global = -1.0, double nnz_global = -1.0, int ok_all = -1);
 // api_comm.hip
 bool comm_multi(const klnmf_ctx *c);
-void comm_loop_entry(klnmf_ctx *c, int64_t planned = -1);
+void comm_loop_entry(klnmf_ctx *c);
 void comm_iteration(klnmf_ctx *c, int fit, double tol_abs);
 
 }  // namespace klnmf_host

@@ -142,6 +142,7 @@ struct RowPassArgs {
     unsigned *w8tab;          // the maxima go by atomicMax into row (rt & 63) of this [64][KP] table (post.hip.h)
     int *w8_sat;              // entries of this image beyond e4m3's 448 (stored as 448) are counted here, as k_w8_from_wb does
     int w8_probe;             // the image's probe column (colq8x.hip.h; e4m3 1.0 in every row): KP - 1 or -1 (none)
+    unsigned sr_seed;         // fp8 ratio tiles: this launch's seed of the stochastic rounding (mfma4.hip.h, sr_cvt4)
 };
 
 // ---- column pass on stored ratios ----------------------------------------------------------------

@@ -1,15 +1,19 @@
-// The in-loop monitor of the fp8 ratio tiles: what does their e4m3 rounding do to the H numerator of THIS data?
+// The in-loop monitor of the fp8 ratio tiles: how much noise does their e4m3 rounding put into the H numerator of THIS data?
 //
 //   H <- H * (W_new^T . Q) / norm        nmf.py:345-351, with Q = ratio of the OLD factors (nmf.py:325-336)
 //
 // From a loop's third iteration on the row pass may leave Q as e4m3 of ratio x sqrt(2) / 8 (1 byte per element of V instead
 // of 2) and the column pass may multiply an e4m3 image of W_new.  Their 3-bit significands enter ONLY the H numerator, a sum
-// over all rows: rounding noise averages out like 0.036 sqrt(2 / rows) -- unless the data defeat that: too few stored entries
-// per column, ratios that all sit inside one e4m3 step of 1 (few components on nearly noise-free data: a dead zone, not
-// noise), columns fitted so exactly that every ratio falls on one side of a rounding boundary.  Round 4 met each of these as
-// a fuzz failure (2e-4 .. 1.2e-3 off the oracle's final KL) and answered with a data rule at the loop's entry.  Round 5
-// measures instead.  On monitored iterations, for ONE column tile (32 columns, rotating with the iteration) and a sample of
-// row tiles (up to 256 x 32 rows, strided over the shard, rotating too), this kernel recomputes
+// over all rows.  Both are rounded STOCHASTICALLY since round 5 (mfma4.hip.h, sr_pack4): every stored entry is unbiased, so
+// what reaches the numerator is noise of about 0.036 sqrt(2 / rows) per entry, fresh every iteration -- round to nearest left a
+// mean error that depended on where a column's ratios (a component's coefficients) sat in e4m3's cells, did not fall with the
+// row count, stayed from one iteration to the next and was integrated by the update's slow modes: every class of round 4's fuzz
+// failures (few components in a dead zone, exactly fitted columns cycling between two cells, drift beyond 60 iterations) was
+// that bias; DESIGN.md section 6 has the before / after table.  What is left to decide per problem is whether the NOISE is small
+// enough: it is not when a column has few stored entries (sparse data stored densely: 5 % stored of 70 000 rows give 1.1e-3
+// and end 2e-4 off the oracle), and it is measured, not guessed.  On monitored iterations, for ONE column tile (32 columns,
+// rotating with the iteration) and a sample of row tiles (up to 256 x 32 rows, strided over the shard, rotating too), this
+// kernel recomputes
 //
 //   N16[a][j] = sum_i Wimg[i][a] * q[i][j]        q = (x + eps) / (W_old . H_old + eps) from the fp32 masters, x sqrt(2)
 //   D[a][j]   = sum_i ( Wop[i][a] * held[i][j] - Wimg[i][a] * q[i][j] )
@@ -20,18 +24,20 @@
 // exactly.)  The sample is kept as two halves (even / odd sampled row tiles), which k_post (post.hip.h) combines per
 // component row a over the tile's valid columns j:
 //
-//   bias^2   = sum_j D_A D_B / sum_j N_A N_B            rounding noise of the two halves is independent: it drops out
+//   bias^2   = sum_j D_A D_B / sum_j N_A N_B   (centred on the component's common factor)   the halves' noise is independent: it drops out
 //   noise^2  = sum_j (D_A / N_A - D_B / N_B)^2 / cols   = 2 x (relative variance of one half's numerator)
 //   stat_a^2 = max(bias^2, 0) + noise^2 / 2 x rows_half / rows_of_the_shard        (noise scaled to the FULL row sum)
 //
 // i.e. an estimate of the relative error of the full numerator's entries that does not mistake the sample's own noise for
 // a defect.  max_a stat_a above kMonThreshold makes the loop give the fp8 regime up (the host polls DevState.mon_trips with
-// the saturation counters; on row shards the count rides in the loss exchange, so that every rank decides alike).
+// the saturation counters; on row shards the count rides in the loss exchange, so that every rank decides alike).  The FIRST
+// check is a dry run on the loop's first iteration, still on 16-bit tiles: the bytes the row pass would store are formed here
+// by the same conversion, and a loop that fails never takes an fp8 tile.
 //
 // Cost: the kernel reads 256 x 32 rows of W_old (fp32), W_new (f16, e4m3) and one 32-column tile of V, H_old and the ratio
 // tiles -- 13 MB at k = 200 -- and writes 128 x [2 halves][2][KP][32] partial sums (15 MB, read back by k_post), on the first
-// four fp8 iterations and every eighth after them (measured: DESIGN.md section 5).  The row pass -- the headline kernel -- is not touched: the 16-bit ratio is
-// recomputed from the masters here instead of being stored by it.
+// four fp8 iterations and every eighth after them (measured: DESIGN.md section 6).  The row pass -- the headline kernel -- is
+// not touched: the 16-bit ratio is recomputed from the masters here instead of being stored by it.
 #pragma once
 #include "colq8x.hip.h"
 
@@ -39,40 +45,19 @@ namespace klnmf {
 
 constexpr int kW8TabRows = 64;                  // rows of the conversion kernel's maxima table (blockIdx & 63): [kW8TabRows][KP] float bit patterns
 constexpr int kMonBlocks = 128;                  // blocks of the monitor launch = row tile PAIRS sampled (one tile per half)
-// The averaging argument needs the ratios of a column to be SPREAD over the e4m3 cells (6.25 % wide below a power of two, 12.5 %
-// above): when a column is fitted so exactly that all its ratios sit inside one cell, the rounding is the same for every row, the
-// H rule loses its feedback inside the cell and the column cycles between two cells -- a model error of half a cell that builds
-// up over tens of iterations (every 7th column constant, 66 000 x 300, k = 130: 4e-4 off the oracle's loss at iteration 40, rising
-// loss at 67; no choice of the tiles' scale or of scales alternating between iterations cures it: experiments/README.md).  The
-// monitor therefore also measures the relative spread std(q) / mean(q) of each monitored column's ratios and ends the fp8 regime
-// when one falls below a quarter of the narrow cell.
-constexpr float kMonMinSpread = 0.04f;
-// The same on the other operand: when a COMPONENT's coefficients are gathered inside one or two e4m3 cells (a component that models
-// constant columns has nearly the same coefficient in every row), the e4m3 image of W_new rounds all of them the same way -- its
-// numerator row comes out with a common factor (1.9e-2 measured on the constant-columns class against <= 2.7e-3 everywhere else;
-// harmless in itself, the row normalisation removes it) and, where the coefficients straddle a cell boundary, with an error that
-// follows the rows' pattern: the loss is 1e-4 off the reference's within ten iterations on the e4m3 image, 3e-6 on the f16 one
-// (scripts/const_columns_probe.py).  A common factor beyond kMonMaxCommon ends the fp8 regime.
+// The spread std(q) / mean(q) of each monitored column's ratios is measured as well and reported (klnmf_query_f64): round-to-nearest
+// tiles needed it above a quarter of an e4m3 cell (exactly fitted columns cycled between two cells); with unbiased entries the
+// H rule keeps its feedback inside a cell and the criterion is off (KLNMF_MON_MIN_SPREAD, development, sets one).
+constexpr float kMonMinSpread = 0.f;
+// A gross-error check on the other operand: the common factor of a component's numerator row (harmless in itself, the row
+// normalisation removes it) is 1e-3 .. 2e-3 on every class measured since the e4m3 image of W_new is rounded stochastically
+// (round to nearest: 7e-3 .. 1.9e-2 on coefficients gathered inside one e4m3 cell, and 1e-4 of the loss within ten iterations);
+// beyond kMonMaxCommon something other than rounding is wrong with the image, and the fp8 regime ends.
 constexpr float kMonMaxCommon = 6.0e-3f;
-constexpr float kMonThreshold = 1.0e-3f;
-// ... and the LENGTH of the loop.  The pattern of rounding errors of a nearly converged fit is frozen from one iteration to the next
-// (the ratios barely move), and the multiplicative update is sensitive along its slow directions: a relative error e of the
-// H numerator's entries moves the loss of iteration `it` by about G(it) x e, G growing like it^2 -- measured on the HIP path
-// (scripts/fp8_drift_probe.py: statistic 3.8e-4 -> +4.7e-5 at iteration 50, 1.4e-4 at 75, 2.3e-4 at 200, the same at 40 000 and
-// 160 000 rows) and reproduced on the CPU with nothing but a frozen random pattern on the numerator (e = 1e-4: 7e-6 at 50, 1.6e-4 at
-// 200; experiments/README.md).  With the envelope G(it) = 0.5 (it / 100)^2 and the whole 1e-4 budget the statistic may be at most
-//     min(kMonThreshold, kMonBudget / G(planned iterations)) = min(1e-3, 2 / planned^2):
-// 8e-4 for the 50 iterations of BASELINE configuration 4.  Beyond kQ8MaxLoop planned iterations a loop is not offered the tiles at
-// all: the threshold would be below what e4m3 tiles ever measure (2e-4 at 100, 5e-5 at the 200 of configuration 2), and a class
-// like exactly fitted columns amplifies even three or four fp8 iterations at the loop's start into 1.8e-4 of the loss eighty
-// iterations later (fixture G16).
-constexpr int kQ8MaxLoop = 50;
-constexpr float kMonBudget = 1.0e-4f;
-__host__ __device__ inline float mon_threshold_for(float planned_iterations) {
-    const float g = 0.5f * (planned_iterations / 100.f) * (planned_iterations / 100.f);
-    const float t = g > 0.f ? kMonBudget / g : kMonThreshold;
-    return t < kMonThreshold ? t : kMonThreshold;
-}         // on stat_a (see above); calibrated in round 5: profiles/r05_monitor_calibration.txt
+// On stat_a (above).  Calibrated in round 5 (profiles/r05_monitor_calibration.txt): 2e-4 .. 6e-4 on dense data of 40 000 .. 70 000
+// rows whatever the components, the columns or the loop's length (final KL within 8e-5 of the oracle's through 150 .. 200
+// iterations), 1.1e-3 / 1.5e-3 on 5 % stored entries (2e-4 off).
+constexpr float kMonThreshold = 8.0e-4f;
 
 struct MonArgs {
     const DevState *st;
@@ -159,12 +144,13 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
                 const float rinv = 1.f / (d[t] + a.eps);
                 const float q = fmaf(x, rinv, a.eps * rinv);
                 unsigned byte;
-                if (a.dry) {              // what the row pass's epilogue does to its ratio (mfma4.hip.h, cvt8_of): f16, x sqrt(2), e4m3 of / 8
-                    typedef __attribute__((ext_vector_type(2))) short s16x2;
-                    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-                    s16x2 w8 = {0, 0};
-                    w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, f16x2{(_Float16)q, (_Float16)0.f} * f16x2{(_Float16)kQ8Mid, (_Float16)kQ8Mid}, kQ8Scale, false);
-                    byte = (unsigned)w8[0] & 0xffu;
+                if (a.dry) {              // what the row pass's epilogue does to its ratio (mfma4.hip.h, sr_cvt4): f16, x sqrt(2), e4m3 of / 8,
+                    // stochastically rounded (the seed: a hash of the entry's place and the check's rotation)
+                    unsigned sd = ((unsigned)(row0 + i) * 0x9E3779B1u) ^ ((unsigned)(a.ct * 32 + cc) * 0x85EBCA6Bu) ^ ((unsigned)a.rot * 0xC2B2AE35u);
+                    sd = (sd ^ (sd >> 15)) * 0x2C1B3C6Du;
+                    sd ^= sd >> 12;
+                    const _Float16 qm = (_Float16)q * (_Float16)kQ8Mid;
+                    byte = (unsigned)__builtin_amdgcn_cvt_scalef32_sr_fp8_f16(0, qm, sd * 0x297A2D39u, kQ8Scale, 0) & 0xffu;
                 } else {
                     byte = a.Qt[((int64_t)a.ct * a.nrt + rt) * 1024 + i * 32 + pcol];
                 }
@@ -201,12 +187,12 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
                         const int64_t row = row0 + ii;
                         const float wimg = (float)a.Wb_new[row * a.wld + wb_col(ii, comp)];
                         float wop = used_w8 ? e4m3_value(a.W8[row * a.w8ld + comp]) * a.w8s[comp] : wimg;
-                        if (dry_scale > 0.f) {        // the conversion of k_w8_from_wb on this one value
-                            typedef __attribute__((ext_vector_type(2))) short s16x2;
-                            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-                            s16x2 w8 = {0, 0};
-                            w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, f16x2{(_Float16)wimg, (_Float16)0.f} * f16x2{(_Float16)(1.f / dry_scale), (_Float16)0.f}, 1.f, false);
-                            wop = e4m3_value((unsigned)w8[0] & 0xffu) * dry_scale;
+                        if (dry_scale > 0.f) {        // the conversion of k_w8_from_wb on this one value (stochastically rounded)
+                            unsigned sd = ((unsigned)row * 0x9E3779B1u) ^ ((unsigned)comp * 0x85EBCA6Bu) ^ ((unsigned)a.rot * 0xC2B2AE35u);
+                            sd = (sd ^ (sd >> 15)) * 0x2C1B3C6Du;
+                            const _Float16 wm = (_Float16)wimg * (_Float16)(1.f / dry_scale);
+                            const unsigned b8 = (unsigned)__builtin_amdgcn_cvt_scalef32_sr_fp8_f16(0, wm, (sd ^ (sd >> 12)) * 0x297A2D39u, 1.f, 0) & 0xffu;
+                            wop = e4m3_value(b8) * dry_scale;
                         }
 #pragma unroll
                         for (int j4 = 0; j4 < 32; j4 += 4) {

@@ -67,13 +67,34 @@ def classes(quick):
     out.append(('rank 12 + empty half + spikes 70 000 x 256, k = 200 (the fix-up tests)', spiked(200), 200, 10, 13))
     out.append(('rank 12 + empty half + spikes 70 000 x 256, k = 50', spiked(50), 50, 10, 13))
     out.append(('rank 12 data, k = 200: 70 000 x 256 (run_more test)', lambda: orc.synthetic_V(13, 70000, 256, 12), 200, 7, 13))
+    # ---- round 5: a steep transient of low-noise low-rank data (tol_fuzz's fifth matrix and wider ones), stopped mid-descent
+    def steep(n, f, k):
+        def make():
+            rs = np.random.RandomState(1)
+            return rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
+        return make
+    for f_ in (64, 256, 1024):
+        out.append(('steep: low-noise rank 8, 40 000 x %d, k = 8, 37 iterations' % f_, steep(40000, f_, 8), 8, 37, 40000))
+    out.append(('steep: low-noise rank 50, 40 000 x 512, k = 50, 37 iterations', steep(40000, 512, 50), 50, 37, 40000))
+    out.append(('steep: low-noise rank 16, 40 000 x 512, k = 16, 37 iterations', steep(40000, 512, 16), 16, 37, 40000))
+    out.append(('steep: low-noise rank 32, 40 000 x 512, k = 32, 37 iterations', steep(40000, 512, 32), 32, 37, 40000))
+    out.append(('steep: low-noise rank 8, 160 000 x 256, k = 8, 37 iterations', steep(160000, 256, 8), 8, 37, 40000))
+    out.append(('steep: rank 8 data, 40 000 x 512, k = 32, 37 iterations', steep(40000, 512, 8), 32, 37, 40000))
+    def sparse_wide(f_):
+        def make():
+            rs = np.random.RandomState(3)
+            D = rs.gamma(1.0, 1.0, (70000, 40)).dot(rs.gamma(0.5, 1.0, (40, f_))) / 40 + 0.05 * rs.random_sample((70000, f_))
+            return D * (rs.random_sample((70000, f_)) < 0.05)
+        return make
+    out.append(('sparse stored densely 70 000 x 256, 95 % zeros, k = 40', sparse_wide(256), 40, 30, 11))
+    out.append(('k = 2: 40 000 x 256', lambda: orc.synthetic_V(7 + 40000 + 64 + 2, 40000, 256, 2), 2, 40, 7 + 40000 + 64 + 2))
     if not quick:
         out.append(('constant columns 66 000 x 300, k = 130, 100 iterations', const_cols(66000, 300, 130), 130, 100, 11))
     return out
 
 
 def fit(X, H0, k, iters, env):
-    saved = {n: os.environ.get(n) for n in ('KLNMF_QTILE', 'KLNMF_Q8_MONITOR', 'KLNMF_Q8_RULES')}
+    saved = {n: os.environ.get(n) for n in ('KLNMF_QTILE', 'KLNMF_Q8_MONITOR')}
     for n in saved:
         os.environ.pop(n, None)
     os.environ.update(env)
@@ -93,6 +114,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--only', default=None)
+    ap.add_argument('--iters', type=int, default=0, help='run every chosen class for this many iterations')
     args = ap.parse_args()
     print('%-66s %-8s %10s %5s %5s %10s %6s %-7s %s' % ('class', 'run', 'KL rel', 'len', 'fp8', 'statistic', 'trips', 'gave up',
                                                        '[uncentred bias, noise, common factor]  min spread  KL / sum(V)'))
@@ -101,6 +123,8 @@ def main():
             continue
         t0 = time.time()
         X = make()
+        if args.iters:
+            iters = args.iters
         n, f = X.shape
         H0 = orc.synthetic_H0(hseed, f, k)
         Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0, warn=False)
