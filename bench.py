@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_FP8_TFLOPS = 5000.0
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r04_pmc_traffic.json'), os.path.join('profiles', 'r03_pmc_traffic.json'),
+PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r05_pmc_traffic.json'), os.path.join('profiles', 'r04_pmc_traffic.json'), os.path.join('profiles', 'r03_pmc_traffic.json'),
                      os.path.join('profiles', 'r02_pmc_traffic.json')]
 
 
@@ -848,7 +848,7 @@ def main():
             'vs_baseline': None,
             # the arithmetic types the path computed in (not a precision claim): the W.H and Q.H^T contractions, the W rule
             # and the loss always on f16 operands with fp32 accumulation; the H-numerator product W_new^T.Q on e4m3
-            # operands (ratio / 8 tiles, scaled W image) in the iterations the library reports
+            # operands (ratio x sqrt(2) / 8 tiles, scaled W image, both stochastically rounded) in the iterations the library reports
             'dtype': (('f16 operands, fp32 accumulate; e4m3 ratio tiles and e4m3 W image in the H-numerator product'
                        if col8 else ('f16 operands, fp32 accumulate; e4m3 ratio tiles (converted back to f16) in the H-numerator product'
                                      if frac8 > 0 else 'f16'))

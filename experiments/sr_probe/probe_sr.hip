@@ -9,6 +9,18 @@ __global__ void k(const uint16_t *xb, const unsigned *seeds, int ns, unsigned ch
     int r = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(0, x, seeds[j], 1.0f, 0);
     out[i * ns + j] = (unsigned char)(r & 0xff);
 }
+__global__ void kopsel(unsigned char *out) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    const f16x2 m = {(_Float16)1.0f, (_Float16)2.0f};
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    unsigned w = 0;
+    const float scale = 1.0f;
+    asm volatile("v_cvt_scalef32_sr_fp8_f16 %0, %1, %2, %3" : "+v"(w) : "v"(u), "v"(0u), "s"(scale));
+    asm volatile("v_cvt_scalef32_sr_fp8_f16 %0, %1, %2, %3 op_sel:[1,0,1,0]" : "+v"(w) : "v"(u), "v"(0u), "s"(scale));
+    asm volatile("v_cvt_scalef32_sr_fp8_f16 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(w) : "v"(u), "v"(0u), "s"(scale));
+    asm volatile("v_cvt_scalef32_sr_fp8_f16 %0, %1, %2, %3 op_sel:[1,0,1,1]" : "+v"(w) : "v"(u), "v"(0u), "s"(scale));
+    if (threadIdx.x == 0) { out[0] = w & 0xff; out[1] = (w >> 8) & 0xff; out[2] = (w >> 16) & 0xff; out[3] = (w >> 24) & 0xff; }
+}
 __global__ void ksat(const uint16_t *xb, int nx, unsigned char *out) {
     const int i = threadIdx.x;
     if (i >= nx) return;
@@ -53,6 +65,11 @@ int main() {
         ksat<<<1, 64>>>(dv, nv, do2);
         unsigned char h2[3 * nv]; hipMemcpy(h2, do2, 3 * nv, hipMemcpyDeviceToHost);
         for (int i = 0; i < nv; ++i) printf("x=%g: nearest %02x  sr(seed 0) %02x  sr(seed ~0) %02x\n", vals[i], h2[3 * i], h2[3 * i + 1], h2[3 * i + 2]);
+    }
+    {
+        unsigned char *d4; hipMalloc(&d4, 4); kopsel<<<1, 64>>>(d4);
+        unsigned char h4[4]; hipMemcpy(h4, d4, 4, hipMemcpyDeviceToHost);
+        printf("op_sel probe {lo = 1.0, hi = 2.0}: bytes %02x %02x %02x %02x (expected 38 40 38 40)\n", h4[0], h4[1], h4[2], h4[3]);
     }
     return 0;
 }

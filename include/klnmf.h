@@ -277,8 +277,9 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
 /* ---- introspection ------------------------------------------------------ */
 /* What a context decided and what its last loop actually ran -- no reference counterpart (the reference has one
  * arithmetic); bench.py and the parity tests read it instead of mirroring the library's rules on the host.
- *   KLNMF_Q_FP8_LOOP          1 if the current / last loop was allowed fp8 ratio tiles (data rule at the loop's entry)
- *   KLNMF_Q_FP8_TILE_ITERS    iterations of that loop whose ratio tiles were fp8 (e4m3 of ratio / 8)
+ *   KLNMF_Q_FP8_LOOP          1 if the current / last loop was allowed fp8 ratio tiles (shape and range rules at the loop's entry;
+ *                             what the tiles' rounding noise does to this data is measured while the loop runs: the monitor below)
+ *   KLNMF_Q_FP8_TILE_ITERS    iterations of that loop whose ratio tiles were fp8 (e4m3 of ratio x sqrt(2) / 8, stochastically rounded)
  *   KLNMF_Q_FP8_COL_ITERS     iterations whose H-numerator product ran on e4m3 operands on both sides
  *   KLNMF_Q_RATIO_TILE_BYTES  bytes per element of V the stored ratio tiles take in an fp8 iteration (1), else 2; 0: none stored
  *   KLNMF_Q_COMM_RANKS        ranks RCCL reports for the context's communicator (ncclCommCount); 1 without one */
@@ -291,7 +292,7 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
  *   KLNMF_Q_W8_SATURATED     entries of the e4m3 W image beyond 448 x their component's scale (a column that more than doubled
  *                            in one update), KLNMF_Q_W8_FALLBACKS the iterations whose H-numerator product therefore ran on the
  *                            f16 W image instead;
- *   KLNMF_Q_RATIO_SATURATED  ratio-tile entries at the tiles' maximum (ratio >= 3584): each is recomputed exactly and its excess
+ *   KLNMF_Q_RATIO_SATURATED  ratio-tile entries at the tiles' maximum (ratio >= 3584 / sqrt(2)): each is recomputed exactly and its excess
  *                            added to the H numerator; KLNMF_Q_RATIO_UNFIXED those beyond the correction list's capacity (8192 per
  *                            iteration) -- non-zero means H numerators of this loop were clipped; the loop then drops fp8 tiles */
 #define KLNMF_Q_W8_SATURATED      5
@@ -302,9 +303,10 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
  *                            reference's (x + eps) / (W.H + eps) (nmf.py:332-336): taken at the loop's entry where eps / mean(V)
  *                            <= 1e-5 (k <= 224), V keeps true zeros (2^-100 addend in the ratio), the loss corrected exactly; KLNMF_NE=0 turns it off */
 #define KLNMF_Q_NO_NUM_EPS        9
-/* The fp8 monitor of the last loop (csrc/monitor.hip.h): on its first four fp8 iterations and every eighth after them the
- * library recomputes, for one column tile and a sample of rows, the H numerator (nmf.py:349) the 16-bit ratio tiles would have
- * given and compares it with what the fp8 regime produced -- a measured bound on what the e4m3 rounding does to this data.
+/* The fp8 monitor of the last loop (csrc/monitor.hip.h): on the loop's first iteration (a dry run, before any fp8 tile is
+ * taken), on its first four fp8 iterations and every eighth after them the library recomputes, for one column tile and a sample
+ * of rows, the H numerator (nmf.py:349) the 16-bit ratio tiles would have given and compares it with what the fp8 regime
+ * produced -- a measured bound on the noise the (unbiased) e4m3 rounding puts into this data's numerator.
  *   KLNMF_Q_MON_CHECKS       monitored iterations;  KLNMF_Q_MON_TRIPS  component rows whose statistic exceeded the threshold;
  *   KLNMF_Q_MON_GAVE_UP      1 if the loop therefore (or after bulk saturation) continued on 16-bit tiles;
  *   klnmf_query_f64: KLNMF_QF_MON_STAT the largest statistic of the loop (estimated relative error of a numerator entry),

@@ -48,7 +48,7 @@ constexpr float kCarrierW = 1.f / 1024.f;
 // (experiments/micro/scale_probe.hip), hence a packed multiply in front of it.  The H numerator then comes out sqrt(2) larger as a
 // whole (the row normalisation removes it); the exact fix-ups work in the same units.
 constexpr float kQ8Mid = 1.41421356f;
-constexpr float kQ8Scale = 8.f;                 // fp8 ratio tiles hold ratio / 8: e4m3 then covers 2^-6 .. 3584 (saturating), full precision from 0.125 on        // eps carrier: W image column kc holds 2^-10, H image row kc eps * 2^10
+constexpr float kQ8Scale = 8.f;                 // fp8 ratio tiles hold ratio x kQ8Mid / 8: e4m3 then covers ratios 2^-6.5 .. 3584 / sqrt(2) (saturating)
 // f32 -> f16 conversions that overflow give the largest finite half instead of infinity (MODE bit 23, FP16_OVFL; true
 // infinities stay): a ratio beyond 65504 (x > 0 where W.H ~ 0) or an operand beyond the image range then perturbs one
 // update instead of poisoning the factors with inf - inf.  Set once per kernel (the mode is per wave).

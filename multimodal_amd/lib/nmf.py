@@ -45,6 +45,12 @@ def _default_precision():
 # 10 000 x 4096 at k = 50: below it an f64 iteration is well under a millisecond.  The default stays 'f64' (SURVEY section 5:
 # defaults must reproduce the reference's results).
 AUTO_F16_WORK = 2e9
+# ... and only on shapes inside the 16-bit mode's accuracy envelope: its rounding noise averages out over the columns (W rule), the
+# rows (H rule) and the components (W.H), and with few of either the averaging is weak -- measured against the oracle (round 5,
+# profiles/r05_monitor_calibration.txt): f = 8 ends 2.4e-4 off, f = 64 is up to 4.5e-4 off in mid-descent, k <= 8 on low-noise data
+# up to 8e-4 after 150 iterations; from f = 256 and k = 16 on every class stays within 1e-4.  Smaller shapes run in fp32 (1e-6).
+AUTO_F16_MIN_F = 256
+AUTO_F16_MIN_K = 16
 
 
 MAX_K_MFMA = 512          # the 16-bit MFMA kernels hold a wave's accumulators of all components in registers: k <= 512
@@ -64,7 +70,10 @@ def resolve_precision(precision, n, f, k):
     same library (LDS-tiled VALU GEMMs: any k, at least the 16-bit mode's accuracy) instead of refusing the problem -- and
     say so once on stderr (the fp32 kernels are an order of magnitude slower than the MFMA path)."""
     if precision == 'auto':
-        precision = 'f16' if float(n) * float(f) * float(k) >= AUTO_F16_WORK else 'f64'
+        if float(n) * float(f) * float(k) < AUTO_F16_WORK:
+            precision = 'f64'
+        else:
+            precision = 'f16' if (f >= AUTO_F16_MIN_F and k >= AUTO_F16_MIN_K) else 'f32'
     code = _native.PRECISIONS[precision]
     if code == _native.PREC_BF16 and k > MAX_K_MFMA:
         _note_once(('k', precision), "KLdivNMF: precision=%r holds k <= %d; k = %d runs on the fp32 kernels (precision='f32')\n"

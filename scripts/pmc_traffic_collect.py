@@ -36,7 +36,7 @@ else:
     per_it = {}
     steps = None
     for k, v in d.items():
-        if k.startswith(('k_spb_qw<double, 1, 1>', 'k_spb_qw<float, 1, 1>', 'k_spb_n', 'k_spb_numer', 'k_spb_wrule', 'k_sp_transpose_H', 'k_update_H',
+        if k.startswith(('k_spb_qw<double, 1, 1>', 'k_spb_qw<float, 1, 1>', 'k_spb_n<', 'k_spb_numer', 'k_spb_wrule', 'k_sp_transpose_H', 'k_update_H',
                          'k_sp_hsum', 'k_sp_colsum', 'k_sp_dots', 'k_sp_loss')):
         # one launch of each per fit iteration
             per_it[k] = v['hbm_bytes_per_launch']

@@ -717,6 +717,29 @@ def test_f16_transform_on_a_dictionary_other_than_the_initial_one_keeps_the_firs
     assert np.abs(W - Wo).max() <= 2e-3 * np.abs(Wo).max()
 
 
+@pytest.mark.parametrize('sliced', [False, True])
+def test_f16_transform_at_66000_rows_against_the_oracle_on_a_row_sample(sliced):
+    """N1 at scale (learner.py:11-15, 67-84; nmf.py:275-291): `transform` against a fixed dictionary updates every row of W on its
+    own, so the oracle's transform of a SAMPLE of the rows is the reference for those rows of the full run.  66 000 x 512, k = 64,
+    20 iterations; `sliced`: the dictionary and the data restricted to the first 384 columns, as reconstruct_internal does with one
+    modality's slice -- its rows sum to about 0.75, not 1 (no H normalisation in a transform: nmf.py:342)."""
+    n, f, k, iters = 66000, 512, 64, 20
+    X = orc.synthetic_V(31, n, f, k)
+    D = orc.synthetic_H0(32, f, k)
+    if sliced:
+        X, D = np.ascontiguousarray(X[:, :384]), np.ascontiguousarray(D[:, :384])
+    rows = np.arange(0, n, 129)                      # 512 rows
+    Ws, _, es = orc.fit_transform(X[rows], k=k, max_iter=iters, tol=0, fit=False, components=D, warn=False)
+    m, W, e, _ = fit_gpu(X, D, k, iters, 0, precision='f16', fit=False, components=D)
+    assert len(e) == iters == len(es)
+    np.testing.assert_array_equal(m.components_, D)                    # the dictionary is untouched
+    assert np.abs(W[rows] - Ws).max() <= 2e-3 * np.abs(Ws).max()
+    ko = orc.kl_error(X[rows], Ws, D)
+    assert abs(orc.kl_error(X[rows], W[rows].astype(np.float64), D) - ko) <= 1e-4 * ko
+    # the recorded losses are sums over all rows: against the sample's, scaled by the data mass (1 % statistical agreement)
+    assert_allclose(np.asarray(e) / X.sum(), np.asarray(es) / X[rows].sum(), rtol=3e-2)
+
+
 def test_f16_images_unnormalised_initial_dictionary_and_heavy_rows():
     """A fit from an initial dictionary whose rows do not sum to 1 (W0 = V.H0^T scales WITH it: measured image scales
     for the first update, the row-normalised ones afterwards), on data whose rows span 2^18 in mass (one storage factor

@@ -279,6 +279,9 @@ def test_auto_precision_picks_the_exact_mode_for_small_problems_and_f16_for_larg
     assert nmf.resolve_precision('auto', 50000, 4096, 50) == 'f16'          # config 2
     assert nmf.resolve_precision('auto', 1000000, 4096, 200) == 'f16'       # config 4
     assert nmf.resolve_precision('f32', 1000000, 4096, 200) == 'f32'
+    # outside the 16-bit mode's envelope (few columns / few components: weak averaging of its rounding noise): fp32
+    assert nmf.resolve_precision('auto', 10000000, 64, 50) == 'f32' and nmf.resolve_precision('auto', 1000000, 4096, 8) == 'f32'
+    assert nmf.resolve_precision('auto', 1000000, 256, 16) == 'f16'
     # k > 512: the 16-bit modes hand the problem to the fp32 kernels instead of refusing it; the exact modes are untouched
     assert nmf.resolve_precision('f16', 5000, 1200, 600) == 'f32' and nmf.resolve_precision('auto', 500000, 4096, 600) == 'f32'
     assert nmf.resolve_precision('f16', 5000, 1200, 512) == 'f16' and nmf.resolve_precision('f64', 5000, 1200, 600) == 'f64'
