@@ -304,7 +304,7 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
  *                            <= 1e-5 (k <= 224), V keeps true zeros (2^-100 addend in the ratio), the loss corrected exactly; KLNMF_NE=0 turns it off */
 #define KLNMF_Q_NO_NUM_EPS        9
 /* The fp8 monitor of the last loop (csrc/monitor.hip.h): on the loop's first iteration (a dry run, before any fp8 tile is
- * taken), on its first four fp8 iterations and every eighth after them the library recomputes, for one column tile and a sample
+ * taken), on fp8 iterations 1, 2, 4, 8, 16 and every 32nd after them the library recomputes, for one column tile and a sample
  * of rows, the H numerator (nmf.py:349) the 16-bit ratio tiles would have given and compares it with what the fp8 regime
  * produced -- a measured bound on the noise the (unbiased) e4m3 rounding puts into this data's numerator.
  *   KLNMF_Q_MON_CHECKS       monitored iterations;  KLNMF_Q_MON_TRIPS  component rows whose statistic exceeded the threshold;

@@ -35,8 +35,8 @@
 // by the same conversion, and a loop that fails never takes an fp8 tile.
 //
 // Cost: the kernel reads 256 x 32 rows of W_old (fp32), W_new (f16, e4m3) and one 32-column tile of V, H_old and the ratio
-// tiles -- 13 MB at k = 200 -- and writes 128 x [2 halves][2][KP][32] partial sums (15 MB, read back by k_post), on the first
-// four fp8 iterations and every eighth after them (measured: DESIGN.md section 6).  The row pass -- the headline kernel -- is
+// tiles -- 13 MB at k = 200 -- and writes 128 x [2 halves][2][KP][32] partial sums (15 MB, read back by k_post), on fp8
+// iterations 1, 2, 4, 8, 16 and every 32nd after them (api_loop.hip, monitor_due; measured: DESIGN.md section 6).  The row pass -- the headline kernel -- is
 // not touched: the 16-bit ratio is recomputed from the masters here instead of being stored by it.
 #pragma once
 #include "colq8x.hip.h"

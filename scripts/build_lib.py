@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Builds the library for gfx950:  python scripts/build_lib.py OUT.so [-DFLAG ...]   (see __graft_entry__.compile_library:
-parallel translation units by default, one unit with any -D flag or KLNMF_SINGLE_TU=1)."""
+"""Builds the library for gfx950:  python scripts/build_lib.py OUT.so [-DFLAG ...]   (__graft_entry__.compile_library: seven
+translation units in parallel, the -D flags on every one; KLNMF_LIB=OUT.so selects the variant at run time)."""
 import os
 import sys
 

@@ -5,6 +5,8 @@
 #   3  N1: transform bench (C4's matrix; C3's stack against a column-sliced dictionary) + its HBM traffic; N3: CSR bench + traffic;
 #      the monitor's cost at C4 (interleaved A/B)
 #   4  the fp8 regime against the oracle: scripts/monitor_calibration.py (every class; the long loops), scripts/fp8_drift_probe.py
+#   5  (after scripts/collect_evidence.py + scripts/pmc_traffic_collect.py have written profiles/r05_pmc_traffic*.json) the bench lines
+#      that carry `roofline.traffic` from those files: fit, transform, CSR
 # Output: gpurun_out/$TAG/; scripts/collect_evidence.py TAG r05 copies what is judged into profiles/.
 TAG=${1:-r05_final}
 PART=${2:-1}
@@ -32,7 +34,7 @@ case $PART in
 3)
   timeout -k 10 300 python3 bench.py --workload transform > $O/bench_transform.json 2> $O/bench_transform.err; echo "transform rc=$?"
   timeout -k 10 300 python3 bench.py --workload transform --n 90000 --f 6144 --k 200 --slice 4096 --steps 40 --warmup 3 --no-cpu-baseline > $O/bench_transform_sliced_c3.json 2> $O/bench_transform_sliced_c3.err; echo "sliced rc=$?"
-  bash scripts/pmc_traffic.sh $TAG/pmc_transform python3 $R/bench.py --workload transform --steps 3 --warmup 1 --repeats 1 --data device --no-cpu-baseline > $O/pmc_transform.txt 2>&1
+  bash scripts/pmc_traffic.sh $TAG/pmc_transform python3 $R/bench.py --workload transform --train-iters 0 --steps 3 --warmup 1 --repeats 1 --data device --no-cpu-baseline > $O/pmc_transform.txt 2>&1
   cd $R
   timeout -k 10 300 python3 scripts/bench_sparse.py --precision f64 > $O/sparse_f64.json 2> $O/sparse_f64.err; echo "sparse f64 rc=$?"
   timeout -k 10 200 python3 scripts/bench_sparse.py --precision f32 --no-cpu-baseline > $O/sparse_f32.json 2> $O/sparse_f32.err; echo "sparse f32 rc=$?"
@@ -59,5 +61,10 @@ import json,sys; d=json.loads(open('$O/ab_mon.json').read().strip().splitlines()
     timeout -k 10 300 python3 scripts/monitor_calibration.py --quick --iters 150 --only "$c" 2>&1 | grep -v "^class" >> $O/calibration_150_iterations.txt
   done
   cut -c1-200 $O/calibration.txt | tail -80; cut -c1-200 $O/calibration_150_iterations.txt
+  ;;
+5)
+  timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
+  timeout -k 10 300 python3 bench.py --workload transform > $O/bench_transform.json 2> $O/bench_transform.err; echo "transform rc=$?"
+  timeout -k 10 300 python3 scripts/bench_sparse.py --precision f64 > $O/sparse_f64.json 2> $O/sparse_f64.err; echo "sparse f64 rc=$?"
   ;;
 esac
