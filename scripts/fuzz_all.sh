@@ -16,7 +16,7 @@ run() {   # name, timeout, command...
 }
 if [ "$PART" = 1 ]; then
   run shape_f16_f64   500 python3 scripts/shape_fuzz.py --random 40 --seed 0 --precisions f16,f64
-  run shape_f32_v32   400 python3 scripts/shape_fuzz.py --random 25 --seed 5 --precisions f32,f16_v32
+  run shape_f32       400 python3 scripts/shape_fuzz.py --random 25 --seed 5 --precisions f32,f16
   run data_f16        300 python3 scripts/data_fuzz.py
   run sparse          200 python3 scripts/sparse_fuzz.py
   exit 0

@@ -27,7 +27,7 @@ def main():
     bad = 0
     for step in range(args.steps):
         n, f, k = shapes[rs.randint(len(shapes))]
-        prec = ['f16', 'f16', 'f64', 'f32', 'f16_v32'][rs.randint(5)]
+        prec = ['f16', 'f16', 'f64', 'f32', 'f16'][rs.randint(5)]
         scale = [1.0, 1.0, 1e-6, 1e6, 1e-3, 1e3][rs.randint(6)]
         sparse = rs.rand() < 0.25
         fit = rs.rand() < 0.7

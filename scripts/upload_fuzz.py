@@ -1,6 +1,6 @@
 """Bug hunt, part 10: klnmf_upload_V in pieces -- the same matrix uploaded whole, and as a random tiling of rectangular blocks (random
 order, strided sources: views into a larger array, fp32 / fp64 sources, per-block scale folded back), must give the same context:
-same loss of (W0, H0), same W0, same two updates.  f16 / f16_v32 / f64 / f32.
+same loss of (W0, H0), same W0, same two updates.  f16 / f64 / f32.
 
     python3 scripts/upload_fuzz.py
 """
@@ -28,7 +28,7 @@ def main():
     for (n, f, k) in [(37, 53, 7), (300, 257, 33), (1000, 64, 8), (33000, 40, 5), (70001, 33, 12), (65, 4100, 20)]:
         X = orc.synthetic_V(n + f, n, f, k)
         H0 = orc.synthetic_H0(n + f, f, k)
-        for prec in ('f16', 'f16_v32', 'f64', 'f32'):
+        for prec in ('f16', 'f64', 'f32'):
             out = []
             for mode in ('whole', 'tiled'):
                 with _native.Context(prec) as c:
