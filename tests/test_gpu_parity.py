@@ -976,6 +976,26 @@ def test_rows_dominated_by_one_entry_keep_their_first_ratio_inside_the_half_rang
         assert max(_rel_to_max(W, Wo), _rel_to_max(m.components_, Ho), abs(e_clipped[1] - eo[1]) / eo[1]) > 2e-2
 
 
+def test_stochastically_rounded_tiles_are_reproducible(monkeypatch):
+    """The fp8 tiles' random bits come from a generator seeded by (workgroup, lane, launch counter of the loop, rank) -- nothing of the
+    clock or of the allocation: two fits of the same problem give the same bits, on a pooled context and on a fresh one.
+    70 000 x 256, k = 130: fp8 tiles AND the stochastically rounded e4m3 image of W in the fp8 x fp8 column pass."""
+    _clear_fp8_switches(monkeypatch)
+    n, f, k, iters = 70000, 256, 130, 6
+    X = orc.synthetic_V(41, n, f, 24)
+    H0 = orc.synthetic_H0(41, f, k)
+    m1, W1, e1, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+    assert m1.last_fp8_report['tile_iterations'] == iters - 2 and m1.last_fp8_report['column_pass_iterations'] == iters - 2
+    m2, W2, e2, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')                 # the pooled context again
+    np.testing.assert_array_equal(W1, W2)
+    np.testing.assert_array_equal(m1.components_, m2.components_)
+    np.testing.assert_array_equal(e1, e2)
+    monkeypatch.setenv('KLNMF_NO_POOL', '1')
+    m3, W3, e3, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')                 # a fresh context
+    np.testing.assert_array_equal(W1, W3)
+    np.testing.assert_array_equal(e1, e3)
+
+
 def test_exactly_fitted_columns_do_not_stall_on_fp8_tiles(monkeypatch):
     """ratio / 8 puts ratio 1 on a binade boundary of e4m3 (2^-3): steps of 6 % below and 12 % above -- an asymmetric quantiser
     exactly where accurately fitted entries live.  Columns the model fits (almost) exactly -- here every 7th column is constant --
