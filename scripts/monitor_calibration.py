@@ -80,6 +80,7 @@ def classes(quick):
     out.append(('steep: low-noise rank 32, 40 000 x 512, k = 32, 37 iterations', steep(40000, 512, 32), 32, 37, 40000))
     out.append(('steep: low-noise rank 8, 160 000 x 256, k = 8, 37 iterations', steep(160000, 256, 8), 8, 37, 40000))
     out.append(('steep: rank 8 data, 40 000 x 512, k = 32, 37 iterations', steep(40000, 512, 8), 32, 37, 40000))
+    out.append(('steep: low-noise rank 8, 640 000 x 256, k = 8, 37 iterations', steep(640000, 256, 8), 8, 37, 40000))
     def sparse_wide(f_):
         def make():
             rs = np.random.RandomState(3)
