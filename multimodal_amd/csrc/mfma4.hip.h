@@ -332,7 +332,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         int w;                                // all four bytes are written below: no zero-fill instruction for the tied operand
         asm volatile("" : "=v"(w));
         // (hipcc extracts the odd entries with a shift; the instruction's op_sel[0] would read them in place -- probed in
-        // experiments/sr_probe and tried as inline assembly: 8 of 48 VALU operations per tile less, the same 3.69 ms)
+        // experiments/sr_probe and tried as inline assembly: 8 of 48 vector instructions per tile less, row pass -0.5 .. -0.8 %, but
+        // an asm statement gets no wait state for gfx940's dst-sel forwarding hazard and the interleaved two-dword form that
+        // provides it by construction spills: not adopted)
         w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, m01[0], r1, scale, 0);
         w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, m01[1], r1 << 7, scale, 1);
         w = __builtin_amdgcn_cvt_scalef32_sr_fp8_f16(w, m23[0], r2, scale, 2);
@@ -443,16 +445,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // slices of the dictionary copy issued one E segment ago (first read two or more intervals from now)
         f16x8 &va = vreg[2 * (ts & 1)], &vb = vreg[2 * (ts & 1) + 1];
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
-        // the segment's memory instructions: the previous tile's ratios (still in b0 / b1: a whole tile interval before the next
-        // wait), V of the next tile, this wave's slices of the dictionary copy
+        // the segment's memory instructions: V of the next tile, this wave's slices of the dictionary copy, the previous tile's
+        // ratios (still in b0 / b1: a whole tile interval before the next wait)
         auto vmem_block = [&]() {
-            if (tg > ct0) store_q(tg - 1);
             // (these stay compiler loads: as asm statements with register outputs -- scalar base + lane offset, one VALU
             // instruction less per tile -- they gave wrong results at 70 000 rows: nothing keeps the compiler from touching an
             // asm output before the data lands; and a pointer passed through an asm statement comes back as a FLAT one)
             v_tile_load(vreg[2 * ((ts + 1) & 1)], vreg[2 * ((ts + 1) & 1) + 1], vt + (int64_t)min(tg + 1, a.nct - 1) * TB, vl32);
             if (grpY) dma((ts + 3) % 4, tg + 3);
             else dma((ts + 2) % 4, tg + 2);
+            // ... and only then the previous tile's ratios: their stochastic conversion is 48 vector instructions -- in front of
+            // the loads (round 5's first form) it held this segment's memory requests back by some 250 cycles: row pass +4.2 %
+            // (profiles/r05_ab_e_segment_order.txt)
+            if (tg > ct0) store_q(tg - 1);
         };
         vmem_block();
         float q[16];
