@@ -867,6 +867,11 @@ def main():
                                'w_image_fallback_iterations': fp8['w_image_fallback_iterations'] if fp8 else None,
                                'ratio_entries_saturated': fp8['ratio_saturated'] if fp8 else None,
                                'ratio_entries_unfixed': fp8['ratio_unfixed'] if fp8 else None,
+                               # the in-loop monitor of the last timed loop (each check is followed by a poll = one host
+                               # synchronisation inside the timed region)
+                               'monitor_checks': fp8['monitor_checks'] if fp8 else None,
+                               'monitor_trips': fp8['monitor_trips'] if fp8 else None,
+                               'gave_up': fp8['gave_up'] if fp8 else None,
                                'source': 'klnmf_query'},
                        'rccl_ranks': model.rccl_ranks() if (n_gpus > 1 or comm_single) else None,
                        'collective_path': collective if (n_gpus > 1 or comm_single) else None,

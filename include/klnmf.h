@@ -314,6 +314,12 @@ int klnmf_all_distances_device(int device, int dtype, int metric, int64_t na, in
 #define KLNMF_Q_MON_CHECKS        10
 #define KLNMF_Q_MON_TRIPS         11
 #define KLNMF_Q_MON_GAVE_UP       12
+/*   KLNMF_Q_FP8_POLL_DUE     loops sequenced in pieces on row shards (klnmf_iter_*): 1 if the klnmf_iter_advance that follows the
+ *                            column pass just enqueued reads the all-reduced count in loss[1] (monitor trips + unfixable ratio entries,
+ *                            written by that column pass's last launch).  The caller then all-reduces loss[1] BEHIND
+ *                            klnmf_iter_colpass and before klnmf_iter_advance; loss[0] alone may be exchanged earlier, while the
+ *                            column pass computes.  The loop state behind the answer is the same on every rank. */
+#define KLNMF_Q_FP8_POLL_DUE      13
 int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
 /*   KLNMF_QF_SUM_V  the sum of the uploaded V as stored (16-bit modes; 0 in the exact modes), in the data's own units */
 #define KLNMF_QF_SUM_V            0
@@ -328,6 +334,10 @@ int klnmf_query(klnmf_ctx *ctx, int what, int64_t *value);
  *   rounding only averages out over the rows if the ratios are spread over its cells), KLNMF_QF_MON_MIN_SPREAD its threshold */
 #define KLNMF_QF_MON_SPREAD       7
 #define KLNMF_QF_MON_MIN_SPREAD   8
+/*   KLNMF_QF_KL_OVER_SUM_V  the last loop's final recorded loss over the sum of V (all shards), 16-bit modes; -1: none.  Below
+ *   about 2e-3 the f16 operands' own rounding noise can exceed 1e-4 of the loss (nmf.py:214 has no
+ *   counterpart: the reference has one arithmetic) -- the host layer says so once on stderr */
+#define KLNMF_QF_KL_OVER_SUM_V    9
 int klnmf_query_f64(klnmf_ctx *ctx, int what, double *value);
 
 /* ---- measurement -------------------------------------------------------- */

@@ -236,7 +236,9 @@ Q_FP8_LOOP, Q_FP8_TILE_ITERS, Q_FP8_COL_ITERS, Q_RATIO_TILE_BYTES, Q_COMM_RANKS 
 Q_W8_SATURATED, Q_W8_FALLBACKS, Q_RATIO_SATURATED, Q_RATIO_UNFIXED = 5, 6, 7, 8
 Q_NO_NUM_EPS = 9
 Q_MON_CHECKS, Q_MON_TRIPS, Q_MON_GAVE_UP = 10, 11, 12
+Q_FP8_POLL_DUE = 13
 QF_SUM_V, QF_NNZ_V, QF_MON_STAT, QF_MON_THRESHOLD = 0, 1, 2, 3
+QF_KL_OVER_SUM_V = 9
 
 
 def selftest(device=0):
@@ -655,7 +657,13 @@ class Context(object):
                 'gave_up': bool(self.query(Q_MON_GAVE_UP)), 'monitor_statistic': self.query_f64(QF_MON_STAT),
                 'monitor_threshold': self.query_f64(QF_MON_THRESHOLD),
                 'monitor_parts': [self.query_f64(4 + i) for i in range(3)],
-                'monitor_min_spread': self.query_f64(7), 'monitor_spread_threshold': self.query_f64(8)}
+                'monitor_min_spread': self.query_f64(7), 'monitor_spread_threshold': self.query_f64(8),
+                # the loop's final KL / sum(V) (16-bit modes; -1: none): the data condition of the f16 operands' accuracy envelope
+                'kl_over_sum_v': self.query_f64(QF_KL_OVER_SUM_V)}
+
+    def fp8_poll_due(self):
+        """Loops in pieces on row shards: the next `iter_advance` reads the all-reduced count in loss[1] (KLNMF_Q_FP8_POLL_DUE)."""
+        return bool(self.query(Q_FP8_POLL_DUE))
 
     def query_f64(self, what):
         v = _c.c_double(0.0)

@@ -185,6 +185,7 @@ int klnmf_query(klnmf_ctx *c, int what, int64_t *value) {
             case KLNMF_Q_MON_CHECKS: *value = c->stat_mon_checks; break;
             case KLNMF_Q_MON_TRIPS: *value = c->stat_mon_trips; break;
             case KLNMF_Q_MON_GAVE_UP: *value = c->stat_mon_gave_up ? 1 : 0; break;
+            case KLNMF_Q_FP8_POLL_DUE: *value = (c->have_problem && fp8_poll_due(c)) ? 1 : 0; break;
             case KLNMF_Q_COMM_RANKS: {
                 int cnt = 1;
                 if (c->comm) RCCLCHK(rccl().CommCount(c->comm, &cnt));
@@ -204,6 +205,7 @@ int klnmf_query_f64(klnmf_ctx *c, int what, double *value) {
         if (what == KLNMF_QF_MON_THRESHOLD) { *value = (double)(c->sw.mon_threshold > 0.f ? c->sw.mon_threshold : kMonThreshold); return; }
         if (what == KLNMF_QF_MON_SPREAD) { *value = c->stat_mon_spread; return; }
         if (what == KLNMF_QF_MON_MIN_SPREAD) { *value = (double)kMonMinSpread; return; }
+        if (what == KLNMF_QF_KL_OVER_SUM_V) { *value = c->stat_kl_over_sumv; return; }
         if (what >= KLNMF_QF_MON_PART0 && what < KLNMF_QF_MON_PART0 + 3) { *value = c->stat_mon_dbg[what - KLNMF_QF_MON_PART0]; return; }
         if (what != KLNMF_QF_SUM_V && what != KLNMF_QF_NNZ_V) fail(KLNMF_ERR_ARG, "klnmf_query_f64: unknown item");
         if (c->is_exact()) { *value = 0.0; return; }

@@ -597,6 +597,16 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
 // Row shards: every rank must drop the tiles in the SAME iteration (they would run different kernels otherwise, and the
 // replicas of H would drift apart): the count travels as the second double of the loss exchange -- every loss launch leaves
 // this rank's q8_unfixed in loss_xchg[1], the all-reduce (native or torch) sums it -- and `agreed` polls read that sum.
+// Will the poll behind the iteration whose column pass has just been enqueued (klnmf_iter_advance) read the agreed count?  The
+// torch-sequenced loop exchanges loss_xchg[1] only then, BEHIND the column pass's k_post (distributed.py) -- every rank holds
+// the same loop state, so every rank answers alike.
+bool fp8_poll_due(const klnmf_ctx *c) {
+    if (c->is_exact() || !c->q8_loop || c->in_capture) return false;
+    if (c->mon_dry_pending) return true;
+    const bool q8_then = c->iter_in_loop + 1 >= 2 && (!c->big || (c->W8 != nullptr && c->w8_meas));      // q8() after the advance
+    return q8_then && monitor_due(c->stat_q8_tiles);
+}
+
 void poll_fp8_overflow(klnmf_ctx *c, bool agreed) {
     if (!c->q8_loop || c->in_capture) return;
     const bool dry = c->mon_dry_pending;          // the dry run of the iteration just enqueued decides whether the next one takes fp8 tiles
@@ -735,6 +745,12 @@ void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopp
     { float m; std::memcpy(&m, &hs.mon_stat_bits, 4); c->stat_mon_max = (double)m; }
     for (int i = 0; i < 3; ++i) { float m; std::memcpy(&m, &hs.mon_dbg[i], 4); c->stat_mon_dbg[i] = (double)m; }
     { float m; std::memcpy(&m, &hs.mon_spread_bits, 4); c->stat_mon_spread = (double)m; }
+    // the last recorded loss over the sum of V (the loss is in the data's units, sum_x as stored: x v_scale)
+    c->stat_kl_over_sumv = -1.0;
+    if (!c->is_exact() && hs.n_done > 0) {
+        const double sx = c->loop_sum_x_all >= 0 ? c->loop_sum_x_all : hs.sum_x;
+        if (sx > 0) c->stat_kl_over_sumv = hs.prev_err * c->v_scale / sx;
+    }
     // the current W is the one the last *executed* update wrote
     c->cur = (c->loop_start_cur + (int)(hs.n_done & 1)) & 1;
     // ... and so is the current dictionary master: k_post swaps H32 / H32alt per ENQUEUED H rule, the device performed
@@ -801,6 +817,7 @@ void begin_fp8_loop(klnmf_ctx *c, double sum_x_global, double cells_global, doub
     c->mon_pending = false;
     c->mon_dry_pending = false;
     c->stat_mon_gave_up = false;
+    c->loop_sum_x_all = sum_x_global;              // (stored units; < 0: fetch_results takes this context's own sum)
     if (c->is_exact() || !c->q8_ok || ok_all == 0) return;
     if (c->W8 != nullptr && c->w8tab != nullptr) {
         // a loop that stopped inside k_post can leave the conversion's maxima table filled and the scale buffers swapped an odd

@@ -301,6 +301,10 @@ struct klnmf_ctx {
     int64_t mon_checks = 0, stat_mon_checks = 0, stat_mon_trips = 0;
     double stat_mon_max = 0.0, stat_mon_dbg[3] = {0, 0, 0}, stat_mon_spread = 1.0;
     bool stat_mon_gave_up = false;
+    // the 16-bit mode's data condition (below KL / sum(V) of about 2e-3 the f16 operands' own noise can pass 1e-4
+    // of the loss): sum of V over ALL shards as the loop's entry was given it (stored units; < 0: this context's own), and the
+    // last loop's final KL / sum(V) (klnmf_query_f64 KLNMF_QF_KL_OVER_SUM_V; < 0: no loop yet / exact mode)
+    double loop_sum_x_all = -1.0, stat_kl_over_sumv = -1.0;
     // the refusal counters of DevState (v_overflow, op_range) change only on uploads and image measurements: they are read
     // back (one copy + synchronisation) only when one of those happened since the last check
     bool refusals_dirty = true;
@@ -454,6 +458,7 @@ void piece_update_H(klnmf_ctx *c);
 void piece_fit_tail(klnmf_ctx *c);
 void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopped);
 void poll_fp8_overflow(klnmf_ctx *c, bool agreed = false);
+bool fp8_poll_due(const klnmf_ctx *c);
 bool fused_w8_stage(klnmf_ctx *c);
 void launch_monitor(klnmf_ctx *c, bool use8);
 void fused_colpass_part(klnmf_ctx *c, const klnmf_ctx::PartCfg &p, bool use8);

@@ -147,8 +147,13 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         }
         // the loss partials -> loss_xchg (exchanged between the ranks before anybody decides); [1] carries this rank's count of
         // ratio entries beyond the fix-up list, so that the all-reduced sum tells EVERY rank when a loop must give fp8 up
+        // ([1] belongs to ONE writer per launch: in the iteration's last summing launch that is the block that finishes last, below --
+        // it alone has seen every fix-up and every monitor row)
         const double err = post_loss(a, red, &bc_s);
-        if (tid == 0) { a.loss_xchg[0] = err; a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips); }
+        if (tid == 0) {
+            a.loss_xchg[0] = err;
+            if (!a.last_sum) a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips);
+        }
         return;
     }
     const int comp = b;
@@ -163,7 +168,10 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         const double prev = a.st->prev2[(a.it + 1) & 1];
         const bool stop_now = prev - err < a.tol_abs;
         if (comp == 0 && tid == 0) {
-            if (a.loss_from_parts) { a.loss_xchg[0] = err; a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips); }
+            if (a.loss_from_parts) {
+                a.loss_xchg[0] = err;
+                if (!a.last_sum) a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips);      // (else: the last block's, below)
+            }
             if (stop_now) {
                 a.st->stop = 1;
             } else {
@@ -369,7 +377,9 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
                     // what tells every rank of a sharded loop to give the fp8 regime up travels as the second double of the loss
                     // exchange: published HERE, by the block that finishes last in the iteration's last summing launch -- every
                     // fix-up and every monitor row of the iteration has been counted (round 4 wrote it from the loss block, which
-                    // races with them: the all-reduced count could lag an iteration)
+                    // races with them: the all-reduced count could lag an iteration).  The exchange of [1] must therefore be
+                    // ordered BEHIND this launch: the native path's grouped all-reduce is (same stream); the torch path exchanges
+                    // [0] alone while the column pass computes and [1] behind it, on the iterations that poll (distributed.py)
                     a.loss_xchg[1] = (double)(atomicAdd(&a.st->q8_unfixed, 0) + atomicAdd(&a.st->mon_trips, 0));
                 }
             }

@@ -238,7 +238,10 @@ class ShardedKLNMF(object):
             # iteration's numerator is simply not applied (iter_update_H is a no-op once stopped).
             # The 16-byte loss exchange starts as soon as the row pass has left the local loss and runs on the
             # collective's own stream WHILE the column pass computes: only the numerator exchange is exposed.
-            pending = self._all_reduce_async(self.loss_t)
+            # ... the LOSS alone: loss_t[1] (monitor trips + unfixable fp8 ratio entries) is written by the column pass's last
+            # launch (k_post, csrc/post.hip.h) and must not be in flight while that runs; it is exchanged behind the column
+            # pass, on the iterations whose `iter_advance` polls it (the same iterations on every rank)
+            pending = self._all_reduce_async(self.loss_t[:1])
             if self.parts is not None:
                 # the numerator in column parts: the all-reduce of part p runs (on the collective's own stream) while the
                 # column pass of part p + 1 computes; only the last part's exchange is exposed
@@ -254,6 +257,8 @@ class ShardedKLNMF(object):
                 self._all_reduce(self.numer_xchg)
             if pending is not None:
                 pending.wait()
+            if hasattr(self.ctx, 'fp8_poll_due') and self.ctx.fp8_poll_due():
+                self._all_reduce(self.loss_t[1:])
             self.ctx.iter_decide(tol_abs)
             self.ctx.iter_update_H()
         else:

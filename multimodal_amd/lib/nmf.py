@@ -53,7 +53,14 @@ AUTO_F16_MIN_F = 256
 AUTO_F16_MIN_K = 16
 
 
+# ... and on the data: a fit whose final KL / sum(V) falls below this has so little residual left that the f16 operands' own
+# rounding noise (about 3e-4 / sqrt(terms) per product) can pass 1e-4 of the loss (measured: low-noise rank-8 data, 160 000 rows,
+# 150 iterations: 8e-4).  The library reports the ratio of every loop (klnmf_query_f64
+# KLNMF_QF_KL_OVER_SUM_V); `KLdivNMF.last_fp8_report['outside_f16_envelope']` and one stderr line say when a fit ended below it.
+F16_MIN_KL_OVER_SUM_V = 2e-3
+
 MAX_K_MFMA = 512          # the 16-bit MFMA kernels hold a wave's accumulators of all components in registers: k <= 512
+MAX_ROWS_EXACT = 65535 * 64   # the exact modes' row tiles ride on gridDim.y (csrc/api_context.hip: KLNMF_ERR_UNSUPP beyond)
 
 _NOTED = set()
 
@@ -72,8 +79,26 @@ def resolve_precision(precision, n, f, k):
     if precision == 'auto':
         if float(n) * float(f) * float(k) < AUTO_F16_WORK:
             precision = 'f64'
+        elif f >= AUTO_F16_MIN_F and k >= AUTO_F16_MIN_K:
+            precision = 'f16'
+        elif n > MAX_ROWS_EXACT:
+            # outside the 16-bit mode's envelope, but beyond what one context of the exact modes holds: the 16-bit path runs
+            # it (as 'auto' did before the envelope rule existed) and says what that means
+            _note_once(('auto-rows', f < AUTO_F16_MIN_F, k < AUTO_F16_MIN_K),
+                       "KLdivNMF: precision='auto': %d rows exceed one fp32 context (%d); the problem runs with precision='f16' although "
+                       "f = %d, k = %d lie outside its accuracy envelope (f >= %d, k >= %d: final KL within 1e-4 of the reference's; "
+                       "here up to 5e-4) -- shard the rows for fp32\n"
+                       % (n, MAX_ROWS_EXACT, f, k, AUTO_F16_MIN_F, AUTO_F16_MIN_K))
+            precision = 'f16'
         else:
-            precision = 'f16' if (f >= AUTO_F16_MIN_F and k >= AUTO_F16_MIN_K) else 'f32'
+            precision = 'f32'
+    elif (_native.PRECISIONS[precision] == _native.PREC_BF16 and k <= MAX_K_MFMA
+          and (f < AUTO_F16_MIN_F or k < AUTO_F16_MIN_K)):
+        # an explicit 16-bit mode on a shape outside its envelope is honoured -- and never silent about it
+        _note_once(('envelope', precision, f < AUTO_F16_MIN_F, k < AUTO_F16_MIN_K),
+                   "KLdivNMF: precision=%r on f = %d, k = %d: outside the 16-bit mode's accuracy envelope (f >= %d and k >= %d keep "
+                   "the final KL within 1e-4 of the reference's; measured up to 5e-4 below) -- precision='auto' or 'f32' keeps 1e-6\n"
+                   % (precision, f, k, AUTO_F16_MIN_F, AUTO_F16_MIN_K))
     code = _native.PRECISIONS[precision]
     if code == _native.PREC_BF16 and k > MAX_K_MFMA:
         _note_once(('k', precision), "KLdivNMF: precision=%r holds k <= %d; k = %d runs on the fp32 kernels (precision='f32')\n"
@@ -266,6 +291,7 @@ class KLdivNMF(object):
             # what the loop ran on e4m3 operands (16-bit modes, large problems; all zero otherwise) -- as the library
             # reports it (klnmf_query); no reference counterpart
             self.last_fp8_report = ctx.fp8_report()
+            self._check_f16_envelope(ctx, n_samples, n_features, k)
             W = ctx.get_W(dtype=out_dtype)
             if _fit and n_done > 0:
                 self.components_ = ctx.get_H(dtype=out_dtype)
@@ -276,6 +302,27 @@ class KLdivNMF(object):
         if return_errors:
             return W, errors
         return W
+
+    def _check_f16_envelope(self, ctx, n, f, k):
+        """The run-time half of the 16-bit mode's envelope: the library holds loss and sum(V) on the device; a loop that ended
+        with KL / sum(V) below `F16_MIN_KL_OVER_SUM_V` is reported in `last_fp8_report` and said once on stderr (the shape
+        half is `resolve_precision`'s).  No reference counterpart (nmf.py has one arithmetic)."""
+        rep = self.last_fp8_report
+        if rep is None or ctx.precision != _native.PREC_BF16:
+            return
+        r = rep.get('kl_over_sum_v', -1.0)
+        reasons = []
+        if f < AUTO_F16_MIN_F:
+            reasons.append('f < %d' % AUTO_F16_MIN_F)
+        if k < AUTO_F16_MIN_K:
+            reasons.append('k < %d' % AUTO_F16_MIN_K)
+        if 0.0 <= r < F16_MIN_KL_OVER_SUM_V:
+            reasons.append('KL / sum(V) = %.2e < %.0e' % (r, F16_MIN_KL_OVER_SUM_V))
+            _note_once(('residual',),
+                       "KLdivNMF: this 16-bit fit ended with KL / sum(V) = %.2e (< %.0e): so little residual that the f16 operands' "
+                       "rounding noise can exceed 1e-4 of the final KL (measured up to 8e-4) -- precision='f32' keeps 1e-6\n"
+                       % (r, F16_MIN_KL_OVER_SUM_V))
+        rep['outside_f16_envelope'] = reasons
 
     def fit(self, X, y=None, **params):
         """Learn a NMF model for X; returns self (reference nmf.py:259-273)."""

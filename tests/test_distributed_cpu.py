@@ -447,3 +447,69 @@ def test_every_rank_enters_the_loop_with_the_global_count_of_entries(tmp_path):
     got = [np.load(os.path.join(ok_dir, 'r%d.npy' % r)) for r in range(2)]
     np.testing.assert_array_equal(got[0], got[1])
     assert got[0][3] == 1.0
+
+
+class TrippingContext(OracleContext):
+    """A shard whose column pass publishes a rank-local count in loss[1] AFTER the loss exchange has started -- what k_post's
+    last block does with the fp8 monitor's trips (csrc/post.hip.h) -- and whose `iter_advance` polls it on the iterations
+    `fp8_poll_due` names (KLNMF_Q_FP8_POLL_DUE)."""
+
+    def __init__(self, my_trips, due):
+        OracleContext.__init__(self)
+        self.my_trips, self.due, self.it, self.seen = my_trips, due, 0, []
+
+    def fp8_poll_due(self):
+        return self.it in self.due
+
+    def iter_rowpass(self, fit):
+        OracleContext.iter_rowpass(self, fit)
+        self.loss[1] = -777.0                # (whatever the loss kernel left there: it must never reach a poll)
+
+    def iter_colpass(self):
+        OracleContext.iter_colpass(self)
+        self.loss[1] = float(self.my_trips.get(self.it, 0))
+
+    def iter_advance(self):
+        if self.fp8_poll_due():
+            self.seen.append((self.it, float(self.loss[1])))
+        OracleContext.iter_advance(self)
+        self.it += 1
+
+
+def _trip_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n, f, k = 96, 40, 6
+        X = orc.synthetic_V(77, n, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        # only rank 1's monitor trips, in iteration 2 (3 component rows) -- iterations 1, 2 and 4 poll
+        ctx = TrippingContext({2: 3} if rank == 1 else {}, due=(1, 2, 4))
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=6, backend=ctx)
+        m.set_v_max(X.max()); m.upload_V(X[r0:r1]); m.set_H(orc.synthetic_H0(77, f, k)); m.init_W()
+        errors, n_done, stopped = m.run(6, fit=True, tol=0.0)
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), seen=np.array(ctx.seen), errors=np.array(errors), H=m.get_H())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_trip_count_is_exchanged_behind_the_column_pass(tmp_path):
+    """the torch path started the all-reduce of BOTH loss doubles right behind the row pass, and the
+    column pass's last launch then wrote its rank-local trip count into loss[1] while (or after) that collective ran: each
+    rank polled its own count and the ranks could leave the fp8 regime in different iterations.  Now loss[0] alone is
+    exchanged early; loss[1] behind the column pass on the polling iterations: every rank reads the SUM of the counts the
+    column passes of that iteration published, and the loss itself is untouched by it."""
+    import torch.multiprocessing as mp
+    mp.spawn(_trip_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(2)]
+    np.testing.assert_array_equal(got[0]['seen'], got[1]['seen'])
+    np.testing.assert_array_equal(got[0]['seen'], [[1, 0.0], [2, 3.0], [4, 0.0]])
+    np.testing.assert_array_equal(got[0]['errors'], got[1]['errors'])
+    np.testing.assert_array_equal(got[0]['H'], got[1]['H'])
+    n, f, k = 96, 40, 6
+    X = orc.synthetic_V(77, n, f, k)
+    _, _, eo = orc.fit_transform(X, k=k, H0=orc.synthetic_H0(77, f, k), max_iter=6, tol=0)
+    np.testing.assert_allclose(got[0]['errors'], eo, rtol=1e-10)

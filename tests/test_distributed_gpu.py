@@ -449,3 +449,167 @@ def test_stop_rule_on_the_collective_path_breaks_where_the_oracle_does(monkeypat
         assert stopped and n_done == len(eo) == len(errs), (n_done, len(eo))
         np.testing.assert_allclose(errs, eo, rtol=1e-4)
         assert np.abs(H - Ho).max() <= 5e-3 * Ho.max() and np.abs(W - Wo).max() <= 5e-3 * Wo.max()
+
+
+# ---- the fp8 regime on MORE THAN ONE rank (round-5 verdict, missing 3 / weak 3): torch-sequenced loop, ranks on one GPU over gloo -------
+
+def _shard_data(kind, seed, n, f, k, world):
+    """The whole matrix, the same on every rank (seeded): 'dense' = factorisable + noise of rank k (SURVEY 8d's kind);
+    'last_shard_sparse' = the same with 95 % of the LAST rank's rows zeroed (histogram data stored densely)."""
+    from multimodal_amd.distributed import row_partition
+    X = orc.synthetic_V(seed, n, f, min(k, 24) if kind != 'dense' else k)
+    if kind == 'last_shard_sparse':
+        r0, r1 = row_partition(n, world)[world - 1]
+        X = X.copy()
+        X[r0:r1] *= (np.random.RandomState(seed + 1).random_sample((r1 - r0, f)) < 0.05)
+    return X
+
+
+def _worker_fp8(rank, world, port, kind, seed, n, f, k, iters, env_by_rank, out_dir):
+    import torch
+    import torch.distributed as dist
+    for name, value in (env_by_rank.get(rank) or {}).items():
+        os.environ[name] = value
+    from multimodal_amd.distributed import ShardedKLNMF, row_partition
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        X = _shard_data(kind, seed, n, f, k, world)
+        H0 = orc.synthetic_H0(seed, f, k)
+        r0, r1 = row_partition(n, world)[rank]
+        m = ShardedKLNMF(n, r1 - r0, f, k, max_iter=iters, precision='f16', collective='torch')
+        m.set_v_max(X[r0:r1].max())
+        m.upload_V(X[r0:r1])
+        m.set_H(H0)
+        m.init_W()
+        errors, n_done, stopped = m.run(iters, fit=True, tol=0.0)
+        rep = m.ctx.fp8_report()
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), W=m.get_W_local(), H=m.get_H(), errors=np.array(errors),
+                 rows=np.array([r0, r1]), tile_iterations=rep['tile_iterations'], col8=rep['column_pass_iterations'],
+                 allowed=rep['allowed'], gave_up=rep['gave_up'], trips=rep['monitor_trips'], checks=rep['monitor_checks'])
+        m.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_fp8_ranks(tmp_path, world, kind, seed, n, f, k, iters, env_by_rank=None):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_fp8, args=(world, _free_port(), kind, seed, n, f, k, iters, env_by_rank or {}, str(tmp_path)),
+             nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0]['H'], r['H'])               # replicas bit-identical
+        np.testing.assert_array_equal(res[0]['errors'], r['errors'])
+    W = np.vstack([r['W'] for r in res])
+    assert W.shape[0] == n
+    return res, W
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,rows_per_rank', [(2, 66016), (4, 33024)])
+def test_fp8_regime_on_row_shards_for_30_iterations(tmp_path, world, rows_per_rank):
+    """What the 8-GPU run of configuration 4 executes on every rank, on 2 and 4 ranks for 30 iterations against the oracle
+    (nmf.py:212-222, 345-351): fp8 ratio tiles from the loop's third iteration (world 2: 66 016 rows per rank = also the
+    fp8 x fp8 column pass, k = 200; world 4: 33 024 rows per rank = fp8 tiles under f16 W operands), the monitor's checks with
+    their polls (the trip count exchanged behind the column pass), the agreed shape rule at the loop's entry.  Every rank stays
+    on the tiles for all 28 remaining iterations, the replicas of H are bit-identical, every loss and the TRUE final KL of the
+    gathered factors are within 1e-4 of the oracle's."""
+    n, f, k, iters = world * rows_per_rank, 256, 200, 30
+    res, W = _run_fp8_ranks(tmp_path, world, 'dense', 21, n, f, k, iters)
+    for r in res:
+        assert bool(r['allowed']) and int(r['tile_iterations']) == iters - 2 and not bool(r['gave_up']), dict(r)
+        assert int(r['checks']) >= 5 and int(r['trips']) == 0
+        assert int(r['col8']) == (iters - 2 if rows_per_rank >= 65536 else 0)
+    X = _shard_data('dense', 21, n, f, k, world)
+    H0 = orc.synthetic_H0(21, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    assert len(res[0]['errors']) == iters
+    np.testing.assert_allclose(res[0]['errors'], eo, rtol=1e-4)
+    fo = orc.kl_error(X, Wo, Ho)
+    fg = orc.kl_error(X, W.astype(np.float64), res[0]['H'].astype(np.float64))
+    assert abs(fg - fo) <= 1e-4 * fo, (fg, fo)
+
+
+@pytest.mark.gpu
+def test_one_sparse_shard_takes_every_rank_off_the_fp8_tiles_together(tmp_path):
+    """One rank's shard is 95 % zeros (its columns hold too few entries for the tiles' noise to average out: the monitor's
+    dry run on the loop's first iteration measures 1e-3 against its threshold of 8e-4), the other rank's shard is dense and
+    would keep the tiles.  Ranks must not mix tile formats (the numerators differ by sqrt(2)): the trip count travels with
+    the loss exchange -- behind the column pass that publishes it -- and EVERY rank continues on 16-bit
+    tiles from the same iteration on: only the sparse rank counted trips, both gave the regime up, neither took a tile, the
+    replicas are bit-identical and the fit keeps the oracle's 1e-4."""
+    world, f, k, iters = 2, 96, 40, 12
+    n = world * 40000
+    res, W = _run_fp8_ranks(tmp_path, world, 'last_shard_sparse', 5, n, f, k, iters)
+    assert int(res[0]['trips']) == 0 and int(res[1]['trips']) > 0
+    for r in res:
+        assert bool(r['allowed']) and bool(r['gave_up']) and int(r['tile_iterations']) == 0, dict(r)
+    X = _shard_data('last_shard_sparse', 5, n, f, k, world)
+    H0 = orc.synthetic_H0(5, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    np.testing.assert_allclose(res[0]['errors'], eo, rtol=1e-4)
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(orc.kl_error(X, W.astype(np.float64), res[0]['H'].astype(np.float64)) - fo) <= 1e-4 * fo
+
+
+@pytest.mark.gpu
+def test_only_one_ranks_monitor_trips_and_every_rank_follows(tmp_path):
+    """The same agreement with the trip forced on ONE rank by its own threshold (KLNMF_MON_THRESHOLD, a development switch, set
+    in rank 1's environment only; dense data that passes everywhere else): rank 1's dry run trips, rank 0's does not; both
+    must read the all-reduced count at the poll and neither may take an fp8 tile."""
+    world, f, k, iters = 2, 256, 40, 8
+    n = world * 40000
+    res, _ = _run_fp8_ranks(tmp_path, world, 'dense', 9, n, f, k, iters, env_by_rank={1: {'KLNMF_DEV': '1', 'KLNMF_MON_THRESHOLD': '1e-9'}})
+    assert int(res[0]['trips']) == 0 and int(res[1]['trips']) > 0
+    for r in res:
+        assert bool(r['gave_up']) and int(r['tile_iterations']) == 0, dict(r)
+    # ... and without the forced trip the same ranks keep the tiles
+    sub = tmp_path / 'plain'
+    sub.mkdir()
+    res2, _ = _run_fp8_ranks(sub, world, 'dense', 9, n, f, k, iters)
+    for r in res2:
+        assert not bool(r['gave_up']) and int(r['tile_iterations']) == iters - 2
+
+
+@pytest.mark.gpu
+def test_shards_straddling_the_fp8_row_threshold_stay_on_16_bit_tiles(tmp_path):
+    """65 568 rows over two ranks = 32 800 + 32 768: the first shard's shape allows fp8 ratio tiles (more than 32 768 rows), the
+    second's does not.  The shape rule is agreed at the loop's entry (klnmf_loop_begin_agreed): every
+    rank runs 16-bit tiles, the result equals the single-process fit of the same kernels' 16-bit regime and the oracle."""
+    from multimodal_amd.distributed import row_partition
+    world, n, f, k, iters = 2, 65568, 256, 40, 6
+    assert [b - a for a, b in row_partition(n, world)] == [32800, 32768]
+    res, W = _run_fp8_ranks(tmp_path, world, 'dense', 13, n, f, k, iters)
+    for r in res:
+        assert not bool(r['allowed']) and int(r['tile_iterations']) == 0 and int(r['checks']) == 0, dict(r)
+    X = _shard_data('dense', 13, n, f, k, world)
+    H0 = orc.synthetic_H0(13, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    np.testing.assert_allclose(res[0]['errors'], eo, rtol=1e-4)
+    fo = orc.kl_error(X, Wo, Ho)
+    assert abs(orc.kl_error(X, W.astype(np.float64), res[0]['H'].astype(np.float64)) - fo) <= 1e-4 * fo
+
+
+@pytest.mark.gpu
+def test_bench_native_path_at_one_ranks_shard_of_configuration_4_with_monitor_polls():
+    """One rank's shard of the 8-GPU run of configuration 4 (125 000 x 4096, k = 200) through bench.py's NATIVE collective path
+    (KLNMF_COMM_SINGLE=1: one-rank RCCL communicator, grouped all-reduce of numerator + loss per iteration): every timed
+    iteration on fp8 tiles + the fp8 x fp8 column pass, and the monitor's checks 2, 4, 8, 16 -- each followed by a poll that reads
+    the all-reduced count -- INSIDE the timed region (warm-up 3 = the dry run and check 1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KLNMF_COMM_SINGLE='1', KLNMF_DEV='1')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '20', '--warmup', '3', '--repeats', '2', '--rows', '125000',
+           '--data', 'device', '--no-cpu-baseline', '--no-16bit-segment', '--collective', 'native']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    cfg = d['config']
+    assert cfg['collective_path'] == 'native' and cfg['rccl_ranks'] == 1 and d['valid'] and d['loss_finite_and_decreasing']
+    fp8 = cfg['fp8']
+    assert fp8['timed_iterations_with_fp8_ratio_tiles'] == 20 and fp8['timed_iterations_with_fp8_x_fp8_column_pass'] == 20
+    assert fp8['monitor_checks'] == 6 and fp8['monitor_trips'] == 0 and not fp8['gave_up'], fp8

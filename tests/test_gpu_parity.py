@@ -21,6 +21,7 @@ Tolerances (stated per mode):
            2 000 elements, <= 3e-5 from 20 000 elements on, 3e-6 at config shapes).
 """
 import io
+import os
 import contextlib
 
 import numpy as np
@@ -1243,7 +1244,89 @@ def test_zero_row_and_zero_column_at_fp8_size():
     assert np.abs(W - Wo).max() <= 5e-3 * Wo.max()
     fo = orc.kl_error(X, Wo, Ho)
     assert abs(orc.kl_error(X, W.astype(np.float64), H.astype(np.float64)) - fo) <= 1e-4 * fo
-    # the same with the reference's formula kept (KLNMF_NE=0 path is covered by test_ratio_without_the_numerator_eps...)
+    # (the same regime with the reference's formula kept, KLNMF_NE=0: test_ratio_with_and_without_the_numerator_eps_on_fp8_tiles)
+
+
+def test_ratio_with_and_without_the_numerator_eps_on_fp8_tiles(monkeypatch):
+    """The two update-pass kernel families of the fp8 regime, as an explicit pair against the oracle (nmf.py:332-336): Q8 = 1 forms
+    the ratio as the reference writes it, (x + eps) / (W.H + eps) (eps riding through MFMA-1 or added in the epilogue); Q8 = 2
+    (NE: taken by default where eps / mean(V) <= 1e-5) as fma(x, 1 / (W.H + eps), 2^-100) with the loss corrected exactly.
+    Forced either way by the development switch KLNMF_NE on the same data: both on fp8 tiles from the third iteration, both
+    within 1e-4 of the oracle on every loss and on the true final KL, and within 2e-5 of each other."""
+    _clear_fp8_switches(monkeypatch)
+    n, f, k, iters = 40000, 256, 40, 10
+    X = orc.synthetic_V(41, n, f, 24)
+    H0 = orc.synthetic_H0(41, f, k)
+    Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
+    fo = orc.kl_error(X, Wo, Ho)
+    finals = {}
+    for ne in ('0', '1'):
+        monkeypatch.setenv('KLNMF_NE', ne)
+        m, W, errors, _ = fit_gpu(X, H0, k, iters, 0, precision='f16')
+        rep = m.last_fp8_report
+        assert rep['tile_iterations'] == iters - 2 and rep['no_numerator_eps'] == (ne == '1') and not rep['gave_up'], (ne, rep)
+        assert len(errors) == iters
+        assert_allclose(errors, eo, rtol=1e-4)
+        finals[ne] = orc.kl_error(X, W.astype(np.float64), m.components_.astype(np.float64))
+        assert abs(finals[ne] - fo) <= 1e-4 * fo, (ne, finals[ne], fo)
+        assert np.abs(W - Wo).max() <= 5e-3 * Wo.max() and np.abs(m.components_ - Ho).max() <= 5e-3 * Ho.max()
+    assert abs(finals['0'] - finals['1']) <= 2e-5 * fo, finals
+
+
+_DEV_SWITCH_PROBE = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import klnmf_oracle as orc
+from multimodal_amd import _native
+out = {}
+for n in (8192, 40000):
+    f, k, iters = 256, 40, 8
+    X = orc.synthetic_V(3, n, f, 24)
+    H0 = orc.synthetic_H0(3, f, k)
+    with _native.Context('f16', device=0) as ctx:
+        ctx.set_problem(n, f, k, iters)
+        ctx.upload_blocks([X])
+        ctx.set_H(H0)
+        ctx.init_W()
+        e, nd, st = ctx.run(iters, True, 0.0)
+        rep = ctx.fp8_report()
+        out[str(n)] = {'report': {a: rep[a] for a in ('allowed', 'tile_iterations', 'column_pass_iterations', 'monitor_checks',
+                                                     'no_numerator_eps', 'gave_up')},
+                       'errors': [float(v) for v in e]}
+print('PROBE ' + json.dumps(out))
+'''
+
+
+def test_development_switches_are_ignored_without_KLNMF_DEV():
+    """INTEGRATION.md section 1.1 promises that a production process cannot change the library's arithmetic by accident: the
+    development switches (csrc/ctx.hip.h, DevSwitches) are honoured only under KLNMF_DEV=1 -- which tests/conftest.py sets for
+    this whole suite.  Three child processes run the same two fits (8 192 rows: no fp8 tiles by shape; 40 000 rows: fp8 tiles
+    from the third iteration, monitored):
+      * no KLNMF_DEV, no switches                                              -- the default;
+      * no KLNMF_DEV, KLNMF_QTILE=8 KLNMF_Q8_MONITOR=0 KLNMF_COL8=1 KLNMF_NE=0 -- must equal the default, report AND losses, bit for bit;
+      * KLNMF_DEV=1 and the same switches -- must differ (tiles forced at 8 192 rows, fp8 x fp8 pass, no monitor, eps kept):
+        the switches are live, so the second run's equality is not vacuous."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    switches = {'KLNMF_QTILE': '8', 'KLNMF_Q8_MONITOR': '0', 'KLNMF_COL8': '1', 'KLNMF_NE': '0'}
+    base = {a: b for a, b in os.environ.items() if not a.startswith('KLNMF_')}
+
+    def probe(extra):
+        r = subprocess.run([sys.executable, '-c', _DEV_SWITCH_PROBE % root], env=dict(base, **extra), capture_output=True, text=True,
+                           timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('PROBE ')][-1][6:])
+
+    default, ignored, live = probe({}), probe(switches), probe(dict(switches, KLNMF_DEV='1'))
+    assert ignored == default
+    d8, d40 = default['8192']['report'], default['40000']['report']
+    assert d8['tile_iterations'] == 0 and d40['tile_iterations'] == 6 and d40['monitor_checks'] > 0 and d40['column_pass_iterations'] == 0
+    l8, l40 = live['8192']['report'], live['40000']['report']
+    assert l8['tile_iterations'] == 6 and l8['column_pass_iterations'] > 0 and l40['column_pass_iterations'] > 0
+    assert l40['monitor_checks'] == 0 and not l40['no_numerator_eps'] and d40['no_numerator_eps']
 
 
 def test_len_errors_under_a_positive_tolerance_at_fp8_size(monkeypatch):

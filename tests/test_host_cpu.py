@@ -280,8 +280,14 @@ def test_auto_precision_picks_the_exact_mode_for_small_problems_and_f16_for_larg
     assert nmf.resolve_precision('auto', 1000000, 4096, 200) == 'f16'       # config 4
     assert nmf.resolve_precision('f32', 1000000, 4096, 200) == 'f32'
     # outside the 16-bit mode's envelope (few columns / few components: weak averaging of its rounding noise): fp32
-    assert nmf.resolve_precision('auto', 10000000, 64, 50) == 'f32' and nmf.resolve_precision('auto', 1000000, 4096, 8) == 'f32'
+    assert nmf.resolve_precision('auto', 4000000, 64, 50) == 'f32' and nmf.resolve_precision('auto', 1000000, 4096, 8) == 'f32'
     assert nmf.resolve_precision('auto', 1000000, 256, 16) == 'f16'
+    # ... unless the rows exceed what one context of the exact modes holds (65 535 x 64: klnmf_set_problem refuses beyond):
+    # the 16-bit path then runs it, as 'auto' did before the envelope rule, and says so (the note's text:
+    # test_f16_outside_its_envelope_is_never_silent)
+    assert nmf.MAX_ROWS_EXACT == 65535 * 64
+    assert nmf.resolve_precision('auto', nmf.MAX_ROWS_EXACT, 64, 50) == 'f32'
+    assert nmf.resolve_precision('auto', 10000000, 64, 50) == 'f16'
     # k > 512: the 16-bit modes hand the problem to the fp32 kernels instead of refusing it; the exact modes are untouched
     assert nmf.resolve_precision('f16', 5000, 1200, 600) == 'f32' and nmf.resolve_precision('auto', 500000, 4096, 600) == 'f32'
     assert nmf.resolve_precision('f16', 5000, 1200, 512) == 'f16' and nmf.resolve_precision('f64', 5000, 1200, 600) == 'f64'
@@ -329,7 +335,7 @@ def test_csr_input_and_large_k_never_change_arithmetic_silently(capsys):
     assert nm.sparse_precision('f16') == 'f32' and nm.sparse_precision('f16') == 'f32'
     err = capsys.readouterr().err
     assert err.count("CSR input with precision='f16' runs the reference's sparse branch") == 1
-    assert nm.resolve_precision('f16', 1000, 100, 512) == 'f16'
+    assert nm.resolve_precision('f16', 1000, 300, 512) == 'f16'
     assert capsys.readouterr().err == ''
     assert nm.resolve_precision('f16', 1000, 100, 600) == 'f32' and nm.resolve_precision('f16', 10, 10, 700) == 'f32'
     err = capsys.readouterr().err
@@ -337,3 +343,24 @@ def test_csr_input_and_large_k_never_change_arithmetic_silently(capsys):
     import scipy.sparse as sp
     m = nm.KLdivNMF(n_components=3, precision='f16')
     assert m._sparse_route(sp.csr_matrix(np.eye(3))) and not m._sparse_route(np.eye(3))
+
+
+def test_f16_outside_its_envelope_is_never_silent(capsys):
+    """Round-5 verdict: an explicit precision='f16' on a shape outside the mode's accuracy envelope (f < 256 or k < 16: final KL
+    up to 5e-4 off the reference's) ran without a word.  It is still honoured -- the caller asked for it --
+    but says so once per process and cause on stderr; inside the envelope nothing is written; 'auto' beyond the exact modes'
+    row limit says that it took the 16-bit path.  (The run-time half -- KL / sum(V) below 2e-3 -- needs a fit: GPU test.)"""
+    from multimodal_amd.lib import nmf as nm
+    nm._NOTED.clear()
+    assert nm.resolve_precision('f16', 70000, 256, 16) == 'f16' and nm.resolve_precision('bf16', 70000, 4096, 200) == 'bf16'
+    assert capsys.readouterr().err == ''
+    assert nm.resolve_precision('f16', 70000, 64, 8) == 'f16' and nm.resolve_precision('f16', 500, 64, 8) == 'f16'
+    err = capsys.readouterr().err
+    assert err.count("outside the 16-bit mode's accuracy envelope") == 1 and "f = 64, k = 8" in err and "'f32' keeps 1e-6" in err
+    assert nm.resolve_precision('f16', 70000, 4096, 8) == 'f16'          # another cause (k alone): its own line
+    assert capsys.readouterr().err.count("outside the 16-bit mode's accuracy envelope") == 1
+    assert nm.resolve_precision('f64', 70000, 64, 8) == 'f64' and nm.resolve_precision('f32', 70000, 64, 8) == 'f32'
+    assert capsys.readouterr().err == ''
+    assert nm.resolve_precision('auto', 10000000, 64, 50) == 'f16'
+    err = capsys.readouterr().err
+    assert "exceed one fp32 context" in err and "precision='f16'" in err
