@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_FP8_TFLOPS = 5000.0
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r05_pmc_traffic.json'), os.path.join('profiles', 'r04_pmc_traffic.json'), os.path.join('profiles', 'r03_pmc_traffic.json'),
+PMC_TRAFFIC_FILES = [os.path.join('profiles', 'r06_pmc_traffic.json'), os.path.join('profiles', 'r05_pmc_traffic.json'), os.path.join('profiles', 'r04_pmc_traffic.json'), os.path.join('profiles', 'r03_pmc_traffic.json'),
                      os.path.join('profiles', 'r02_pmc_traffic.json')]
 
 
@@ -283,8 +283,12 @@ def measured_traffic(args, n_local):
                         row = v['hbm_bytes_per_launch']
                     elif 'k_colpass' in kname:
                         col = v['hbm_bytes_per_launch']
+                MEASURED_ITERATION['bytes'] = entry.get('hbm_bytes_per_iteration')
                 return row, col, name, d.get('source_hash')
     return None, None, None, None
+
+
+MEASURED_ITERATION = {'bytes': None}      # ... and of the whole iteration (every steady-state launch), where the file holds it
 
 
 def measured_clock(args, n_local):
@@ -833,6 +837,9 @@ def main():
                                        'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                                        'frac': ((flops_row / (r16 * 1e-3) / 1e12) / PEAK_BF16_TFLOPS) if mfma_bound
                                                else ((alg_bytes_row / (r16 * 1e-3) / 1e9) / PEAK_HBM_GBS)}
+        it_t_mfma = (4.0 * n * f * k / (PEAK_BF16_TFLOPS * 1e12)
+                     + 2.0 * n * f * k * (frac_col8 / (PEAK_FP8_TFLOPS * 1e12) + (1 - frac_col8) / (PEAK_BF16_TFLOPS * 1e12))) / n_gpus
+        it_t_hbm = (n * f * vbytes + 2 * n * k * 4 + 3 * k * f * 4) / (PEAK_HBM_GBS * 1e9) / n_gpus
         errors, n_done, stopped = fits[-1]
         all_full = all(nd == iters_per_fit and not st for _, nd, st in fits)
         out = {
@@ -920,12 +927,15 @@ def main():
                 'iteration_algorithmic_bytes': n * f * vbytes + 2 * n * k * 4 + 3 * k * f * 4,
                 'iteration_schedule_bytes': (sched_bytes_section + sched_bytes_col) * n_gpus,
                 'iteration_algorithmic_tflops': 6.0 * n * f * k / (ms_per_step * 1e-3) / 1e12,
-                # dtype-true t_min of the iteration: 4nfk on 16-bit operands + 2nfk on the operands the column pass ran
-                'iteration_t_min_ms': 1e3 * (4.0 * n * f * k / (PEAK_BF16_TFLOPS * 1e12)
-                                             + 2.0 * n * f * k * (frac_col8 / (PEAK_FP8_TFLOPS * 1e12) + (1 - frac_col8) / (PEAK_BF16_TFLOPS * 1e12))) / n_gpus,
-                'iteration_frac': (4.0 * n * f * k / (PEAK_BF16_TFLOPS * 1e12)
-                                   + 2.0 * n * f * k * (frac_col8 / (PEAK_FP8_TFLOPS * 1e12) + (1 - frac_col8) / (PEAK_BF16_TFLOPS * 1e12)))
-                                  / n_gpus / (ms_per_step * 1e-3),
+                # t_min of the iteration = max(MFMA, HBM).  MFMA, dtype-true: 4nfk on 16-bit operands + 2nfk on the operands
+                # the column pass ran; HBM: the algorithmic minimum bytes above at the nominal 8 TB/s
+                'iteration_t_min_ms': {'mfma': 1e3 * it_t_mfma, 'hbm': 1e3 * it_t_hbm},
+                'iteration_bound': 'mfma' if it_t_mfma >= it_t_hbm else 'hbm',
+                'iteration_frac': max(it_t_mfma, it_t_hbm) / (ms_per_step * 1e-3),
+                # every steady-state launch of one iteration, PMC (FETCH_SIZE x 2 + WRITE_SIZE; the committed pass of this workload)
+                'iteration_traffic': MEASURED_ITERATION['bytes'],
+                'iteration_traffic_over_algorithmic': (MEASURED_ITERATION['bytes'] * n_gpus / (n * f * vbytes + 2 * n * k * 4 + 3 * k * f * 4))
+                                                      if MEASURED_ITERATION['bytes'] else None,
             },
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

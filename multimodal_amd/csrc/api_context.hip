@@ -300,6 +300,7 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
         c->st = (DevState *)c->dalloc(sizeof(DevState));
         c->errors = (double *)c->dalloc(sizeof(double) * (cap > 0 ? cap : 1));
         c->loss_xchg = (double *)c->dalloc(sizeof(double) * 2);
+        c->loss_red = (double2 *)c->dalloc(sizeof(double2) * kLossRedMax);
         if (c->is_exact()) {
             const size_t es = c->esize();
             c->V = c->dalloc((size_t)n * f * es);

@@ -559,7 +559,10 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
                         c->mon_noise_scale, c->sw.mon_threshold > 0.f ? c->sw.mon_threshold : kMonThreshold};
         c->mon_pending = false;
     }
-    a.loss_part = la.part; a.loss_count = la.count; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne; a.cq_on = la.cq_on;
+    // the row pass's loss partials are reduced by up to 16 blocks of k_slab_sum (one slice each); k_post sums their pairs
+    const int nloss = (a.do_sum && la.part != nullptr)
+                          ? (int)std::min<int64_t>(kLossRedMax, std::max<int64_t>(1, (la.count + kLossRedSlice - 1) / kLossRedSlice)) : 0;
+    a.loss_red = c->loss_red; a.nloss = nloss; a.inv_c = la.inv_c; a.loss_xchg = c->loss_xchg; a.ne = la.ne; a.cq_on = la.cq_on;
     a.tol_abs = la.tol_abs; a.errors = c->errors; a.cap = c->cap;
     a.st = c->st;
     a.H_old = c->H32; a.H_new = c->H32alt;
@@ -574,6 +577,15 @@ void launch_post(klnmf_ctx *c, PostMode mode, const klnmf_ctx::PartCfg *parts, i
     a.w8tab = c->w8tab; a.w8s_next = c->w8s_next;
     if (a.do_sum && !fix && c->q8() && c->q8_list != nullptr)      // fix-ups switched off: the list must still be emptied
         HIPCHK(hipMemsetAsync(&c->st->q8_list_n, 0, sizeof(int), c->stream));
+    if (a.do_sum) {
+        // slabs -> numerator rows of these parts, loss partials -> loss_red: the wide launch in front of k_post (post.hip.h)
+        SlabSumArgs sa{};
+        for (int p = 0; p < nparts; ++p) sa.part[p] = a.part[p];
+        sa.nparts = nparts; sa.k = (int)c->k; sa.f_pad = c->f_pad; sa.nloss = nloss;
+        sa.loss_part = la.part; sa.loss_count = la.count; sa.loss_red = c->loss_red; sa.st = c->st;
+        hipLaunchKernelGGL(k_slab_sum, dim3((unsigned)((c->f_pad + 1023) / 1024), (unsigned)(c->k + nloss)), dim3(256), 0, c->stream, sa);
+        HIPCHK(hipGetLastError());
+    }
     // one block per component row, one float4 per thread and trip: 1024 threads for rows of 4096 columns and more
     const int hthreads = c->f_pad >= 4096 ? 1024 : (c->f_pad >= 2048 ? 512 : 256);
     const int blocks = (int)c->k + a.w8_block + a.loss_block;

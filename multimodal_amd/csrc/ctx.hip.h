@@ -225,6 +225,7 @@ struct klnmf_ctx {
     DevState *st = nullptr;
     double *errors = nullptr;
     double *loss_xchg = nullptr;
+    double2 *loss_red = nullptr;              // [kLossRedMax] pairs of the loss slices (k_slab_sum -> k_post; 16-bit modes)
     std::vector<std::pair<void *, size_t>> allocs;      // (block, size class)
 
     // exact modes (T = double or float)

@@ -36,8 +36,18 @@
 
 namespace klnmf {
 
+// Round 6: the slab pass left this kernel again.  One block per component row reads its 16 slab rows in one or two round trips,
+// but only k blocks (200 on 256 CUs at the headline shape) were pulling the 59 MB: 18 us = 3.3 TB/s at one rank's shard of
+// configuration 4, 147 us for the 200 MB of configuration 5's shard -- and in front of it EVERY block reduced all of the row
+// pass's loss partials for the stop rule (5 us at the shard, more at 10^6 rows).  k_slab_sum now does both WIDE (256-thread
+// blocks over (1024-column group, component row): 800 blocks at the headline shape; up to 16 blocks for the loss partials)
+// in a launch of its own in front of k_post -- the boundary between them is cheap, k_slab_sum writes 4 MB where the column
+// pass in front of it leaves 59 MB of dirty lines to write back -- and k_post starts from the numerator rows and from the
+// loss blocks' <= 16 pairs.  The sums keep their fixed orders (slabs 0, 1, 2, ...; loss slices in order).
 constexpr int kPostMaxParts = 4;
 constexpr int kPostSlabBatch = 16;              // slabs in flight per thread (one float4 each)
+constexpr int kLossRedMax = 16;                 // blocks of k_slab_sum that reduce the row pass's loss partials (one slice each)
+constexpr int kLossRedSlice = 2048;             // ... and the fewest partials worth a block of its own
 
 struct PostPart {
     const float *slabs;       // [nslab][KP][ld] of this part (the column pass's Npart for it)
@@ -53,11 +63,11 @@ struct PostArgs {
     PostPart part[kPostMaxParts];
     int nparts;               // parts this launch covers (POST_SUM launches: 1)
     // ---- what the launch does
-    int do_sum;               // numerator rows from the slabs (+ fix-ups)
+    int do_sum;               // the launch behind a column pass (and its k_slab_sum): fix-ups on the numerator rows, the monitor's statistic, the counters
     int do_rule;              // H rule
     int do_decide;            // stop rule (every block evaluates, block 0 records)
-    int loss_from_parts;      // err from the row pass's partials (every block reduces them); else loss_xchg[0] holds it
-    int loss_block;           // one extra block reduces the partials -> loss_xchg (the value is exchanged next)
+    int loss_from_parts;      // err from the row pass's partials as k_slab_sum's loss blocks left them in loss_red; else loss_xchg[0] holds it
+    int loss_block;           // one extra block: err -> loss_xchg (the value is exchanged next)
     int w8_block;             // one extra block: scales of the next e4m3 W image from the conversion's maxima table
     int last_sum;             // the iteration's last summing launch: its last block also clears w8_sat for the next conversion
                               // (every summing launch's last block empties the suspect list: the next part's column pass refills it)
@@ -65,7 +75,7 @@ struct PostArgs {
     MonPost mon;              // the fp8 monitor's partial sums of this iteration (monitor.hip.h): every component block turns its row
                               // into the statistic; nullptr: no check in this launch
     // ---- loss / stop rule
-    const double2 *loss_part; int64_t loss_count; double inv_c; double *loss_xchg; int ne;
+    const double2 *loss_red; int nloss; double inv_c; double *loss_xchg; int ne;      // loss_red[nloss]: (sum s1, sum s2) per slice of the partials
     int cq_on;                // the partials come from a pass over a ratio-scaled dictionary image (LossArgs.cq_on, mfma.hip.h)
     double tol_abs; double *errors; int64_t cap;
     DevState *st;
@@ -80,23 +90,24 @@ struct PostArgs {
     unsigned *w8tab; float *w8s_next;
 };
 
-// err of the current iteration from the row pass's partials: the reduction of loss_from_parts_block without its side effects
-__device__ __forceinline__ double post_loss(const PostArgs &a, double *red, double *bc) {
+// One slice of the row pass's loss partials, fixed order inside the slice (k_slab_sum's loss blocks; 256 threads, eight
+// partials in flight per thread)
+__device__ __forceinline__ double2 loss_slice_sum(const double2 *part, int64_t e0, int64_t e1, double *red) {
     constexpr int U = 8;
     double au[U], bu[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) au[u] = bu[u] = 0.0;
     const int64_t bd = blockDim.x;
-    int64_t e = threadIdx.x;
-    for (; e + (U - 1) * bd < a.loss_count; e += U * bd) {
+    int64_t e = e0 + threadIdx.x;
+    for (; e + (U - 1) * bd < e1; e += U * bd) {
         double2 p[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = a.loss_part[e + u * bd];
+        for (int u = 0; u < U; ++u) p[u] = part[e + u * bd];
 #pragma unroll
         for (int u = 0; u < U; ++u) { au[u] += p[u].x; bu[u] += p[u].y; }
     }
-    for (; e < a.loss_count; e += bd) {
-        const double2 p = a.loss_part[e];
+    for (; e < e1; e += bd) {
+        const double2 p = part[e];
         au[0] += p.x;
         bu[0] += p.y;
     }
@@ -104,12 +115,67 @@ __device__ __forceinline__ double post_loss(const PostArgs &a, double *red, doub
     const double sb = ((bu[0] + bu[1]) + (bu[2] + bu[3])) + ((bu[4] + bu[5]) + (bu[6] + bu[7]));
     const double ta = block_sum(sa, red);
     const double tb = block_sum(sb, red);
-    if (threadIdx.x == 0) {
-        const double ta_q = a.cq_on ? ta + (double)a.st->cq_e * a.st->sum_x : ta;
-        *bc = (kLn2 * ta_q + (a.ne ? a.st->corr_eps : 0.0) + tb - a.st->sum_x - a.st->corr_c) * a.inv_c;
+    return double2{ta, tb};             // (thread 0 holds the sums)
+}
+
+// Slabs of the column pass -> numerator rows (fixed order 0, 1, 2, ...), and the row pass's loss partials -> one pair per slice.
+// Grid: x = 1024-column groups of the padded dictionary row, y = component rows [0, k) then the loss slices [k, k + nloss).
+struct SlabSumArgs {
+    PostPart part[kPostMaxParts];
+    int nparts;
+    int k;
+    int64_t f_pad;
+    int nloss;
+    const double2 *loss_part; int64_t loss_count; double2 *loss_red;
+    const DevState *st;
+};
+
+KL_GLOBAL __launch_bounds__(256) void k_slab_sum(SlabSumArgs a) {
+    if (a.st->stop) return;
+    const int tid = threadIdx.x;
+    const int comp = blockIdx.y;
+    if (comp >= a.k) {
+        if (blockIdx.x != 0) return;
+        __shared__ double red[16];
+        const int l = comp - a.k;
+        const int64_t per = (a.loss_count + a.nloss - 1) / a.nloss;
+        const int64_t e0 = (int64_t)l * per, e1 = min(a.loss_count, e0 + per);
+        const double2 t = loss_slice_sum(a.loss_part, e0, e1, red);
+        if (tid == 0) a.loss_red[l] = t;
+        return;
     }
-    __syncthreads();
-    return *bc;                   // the same bits in every thread of every block that evaluates it
+    const int64_t j4 = 4 * ((int64_t)blockIdx.x * blockDim.x + tid);      // this thread's four columns
+    if (j4 >= a.f_pad) return;
+    int p = 0;                                                            // the part that holds them (parts are multiples of 128 columns)
+    while (p + 1 < a.nparts && j4 >= a.part[p + 1].col0) ++p;
+    const PostPart &pp = a.part[p];
+    const int64_t jl = j4 - pp.col0;
+    if (jl < 0 || jl >= pp.ld) return;
+    const f32x4 *sl = (const f32x4 *)(pp.slabs + (int64_t)comp * pp.ld + jl);
+    const int64_t st4 = pp.slab_stride / 4;
+    f32x4 nj = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < pp.nslab; z0 += kPostSlabBatch) {               // all loads of a batch are issued before the first addition;
+        f32x4 v[kPostSlabBatch];                                          // the additions keep the order 0, 1, 2, ...
+#pragma unroll
+        for (int u = 0; u < kPostSlabBatch; ++u)
+            if (z0 + u < pp.nslab) v[u] = __builtin_nontemporal_load(sl + (z0 + u) * st4);
+#pragma unroll
+        for (int u = 0; u < kPostSlabBatch; ++u)
+            if (z0 + u < pp.nslab) { if (z0 + u == 0) nj = v[u]; else nj += v[u]; }
+    }
+    *(f32x4 *)(pp.numer + (int64_t)comp * pp.ld + jl) = nj;
+}
+
+// err of the current iteration from the loss slices' pairs: <= 16 uniform loads, the same bits in every thread of every block
+__device__ __forceinline__ double post_loss(const PostArgs &a) {
+    double ta = 0.0, tb = 0.0;
+    for (int l = 0; l < a.nloss; ++l) {
+        const double2 p = a.loss_red[l];
+        ta += p.x;
+        tb += p.y;
+    }
+    const double ta_q = a.cq_on ? ta + (double)a.st->cq_e * a.st->sum_x : ta;
+    return (kLn2 * ta_q + (a.ne ? a.st->corr_eps : 0.0) + tb - a.st->sum_x - a.st->corr_c) * a.inv_c;
 }
 
 KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
@@ -149,7 +215,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         // ratio entries beyond the fix-up list, so that the all-reduced sum tells EVERY rank when a loop must give fp8 up
         // ([1] belongs to ONE writer per launch: in the iteration's last summing launch that is the block that finishes last, below --
         // it alone has seen every fix-up and every monitor row)
-        const double err = post_loss(a, red, &bc_s);
+        const double err = post_loss(a);
         if (tid == 0) {
             a.loss_xchg[0] = err;
             if (!a.last_sum) a.loss_xchg[1] = (double)(a.st->q8_unfixed + a.st->mon_trips);
@@ -164,7 +230,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
 
     // ---- stop rule -------------------------------------------------------------------------------------------------------
     if (a.do_decide) {
-        const double err = a.loss_from_parts ? post_loss(a, red, &bc_s) : a.loss_xchg[0];
+        const double err = a.loss_from_parts ? post_loss(a) : a.loss_xchg[0];
         const double prev = a.st->prev2[(a.it + 1) & 1];
         const bool stop_now = prev - err < a.tol_abs;
         if (comp == 0 && tid == 0) {
@@ -256,33 +322,16 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         }
     }
 
-    // ---- the row: slabs in fixed order -> numerator; x old dictionary -> unnormalised new row + row sum -----------------
+    // ---- the row: numerator (k_slab_sum's, or the exchanged one) x old dictionary -> unnormalised new row + row sum --------------
     double s = 0;
-    for (int64_t j4 = 4 * (int64_t)tid; j4 < a.f_pad; j4 += 4 * (int64_t)blockDim.x) {      // this thread's four columns
-        int p = 0;                                                        // the part that holds them (parts are multiples of 128 columns)
-        while (p + 1 < a.nparts && j4 >= a.part[p + 1].col0) ++p;
-        const PostPart &pp = a.part[p];
-        const int64_t jl = j4 - pp.col0;
-        if (jl < 0 || jl >= pp.ld) continue;
-        f32x4 nj;
-        if (a.do_sum) {
-            const f32x4 *sl = (const f32x4 *)(pp.slabs + (int64_t)comp * pp.ld + jl);
-            const int64_t st4 = pp.slab_stride / 4;
-            nj = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int z0 = 0; z0 < pp.nslab; z0 += kPostSlabBatch) {       // all loads of a batch are issued before the first addition;
-                f32x4 v[kPostSlabBatch];                                  // the additions keep the order 0, 1, 2, ...
-#pragma unroll
-                for (int u = 0; u < kPostSlabBatch; ++u)
-                    if (z0 + u < pp.nslab) v[u] = sl[(z0 + u) * st4];
-#pragma unroll
-                for (int u = 0; u < kPostSlabBatch; ++u)
-                    if (z0 + u < pp.nslab) { if (z0 + u == 0) nj = v[u]; else nj += v[u]; }
-            }
-            if (!a.do_rule || defer_rule) *(f32x4 *)(pp.numer + (int64_t)comp * pp.ld + jl) = nj;
-        } else {
-            nj = *(const f32x4 *)(pp.numer + (int64_t)comp * pp.ld + jl);
-        }
-        if (a.do_rule && !defer_rule) {
+    if (a.do_rule && !defer_rule) {
+        for (int64_t j4 = 4 * (int64_t)tid; j4 < a.f_pad; j4 += 4 * (int64_t)blockDim.x) {      // this thread's four columns
+            int p = 0;                                                        // the part that holds them (parts are multiples of 128 columns)
+            while (p + 1 < a.nparts && j4 >= a.part[p + 1].col0) ++p;
+            const PostPart &pp = a.part[p];
+            const int64_t jl = j4 - pp.col0;
+            if (jl < 0 || jl >= pp.ld) continue;
+            const f32x4 nj = *(const f32x4 *)(pp.numer + (int64_t)comp * pp.ld + jl);
             const f32x4 ho = *(const f32x4 *)(hold + j4);
             f32x4 v;
 #pragma unroll

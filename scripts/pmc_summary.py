@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs|k_w8_from_wb|k_post')
+pat = re.compile(r'k_rowpass|k_colpass|k_update_pack_H|k_sum_partials|k_loss_from_parts|k_tile_V|k_wrule_slabs|k_w8_from_wb|k_post|k_slab_sum')
 
 
 def short(name):

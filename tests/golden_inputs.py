@@ -147,3 +147,20 @@ def constant_columns_problem(seed, n, f, k):
     X[:, ::7] = 3.0
     H0 = _normalize_rows(np.abs(np.random.RandomState(seed + 1).random_sample((k, f))) + .01)
     return X, H0
+
+
+def low_rank_problem(seed, n, f, k_true, k, block=8192):
+    """Section-8d data of rank `k_true` (as `synthetic_problem`) fitted with k > k_true components: the H0 of k rows from the
+    same stream rule.  Fixture G18 (rank 12 under k = 200: the class whose fp8-tile noise sits AT the monitor's threshold)."""
+    X, _ = synthetic_problem(seed, n, f, k_true, block=block)
+    H0 = _normalize_rows(np.random.RandomState(seed - 1).random_sample((k, f)) + .01)
+    return X, H0
+
+
+def steep_problem(n, f, k):
+    """Low-noise data of rank k from ONE legacy stream (round 5's "steep transient" class: the fit sits on a plateau for ~100
+    iterations and then escapes; scripts/monitor_calibration.py `steep`), H0 from the stream n - 1.  Fixture G19."""
+    rs = np.random.RandomState(1)
+    X = rs.gamma(1.0, 1.0, (n, k)).dot(rs.gamma(0.5, 1.0, (k, f))) / k + 0.05 * rs.random_sample((n, f))
+    H0 = _normalize_rows(np.random.RandomState(n - 1).random_sample((k, f)) + .01)
+    return X, H0

@@ -544,8 +544,8 @@ def test_one_sparse_shard_takes_every_rank_off_the_fp8_tiles_together(tmp_path):
     n = world * 40000
     res, W = _run_fp8_ranks(tmp_path, world, 'last_shard_sparse', 5, n, f, k, iters)
     assert int(res[0]['trips']) == 0 and int(res[1]['trips']) > 0
-    for r in res:
-        assert bool(r['allowed']) and bool(r['gave_up']) and int(r['tile_iterations']) == 0, dict(r)
+    for r in res:          # ('allowed' reads as False once a loop has given the regime up)
+        assert bool(r['gave_up']) and int(r['tile_iterations']) == 0 and int(r['checks']) == 1, {a: r[a] for a in ('gave_up', 'tile_iterations', 'checks', 'trips')}
     X = _shard_data('last_shard_sparse', 5, n, f, k, world)
     H0 = orc.synthetic_H0(5, f, k)
     Wo, Ho, eo = orc.fit_transform(X, k=k, H0=H0, max_iter=iters, tol=0)
