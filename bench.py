@@ -200,6 +200,10 @@ def parse_args(argv=None):
     p.add_argument('--segment-timeout', type=float, default=float(os.environ.get('KLNMF_BENCH_SEGMENT_TIMEOUT', '300')),
                    help='watchdog: seconds one warm-up + timed segment may take before the rank exits with status 3')
     p.add_argument('--seed', type=int, default=1234)
+    p.add_argument('--event-every', type=int, default=4,
+                   help='HIP events bracket the row-pass and column-pass launches of every N-th timed iteration (the per-kernel '
+                        'durations of `roofline`): an event record is a stream packet of its own -- 5-6 us of dispatch gap each, '
+                        'four per iteration = 3.5 %% of a 0.65 ms shard iteration when every launch is bracketed (N = 1)')
     p.add_argument('--data', default='blocks', choices=['blocks', 'device'],
                    help="blocks: the seeded RandomState blocks of SURVEY 8d (host-generated, identical to the CPU baseline's "
                         "data); device: a torch generator on the GPU (fast set-up for profiling runs, different values)")
@@ -453,7 +457,7 @@ def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fe
             tmodel.init_W()
             tmodel.begin()
             tmodel.iterate_many(args.warmup, fit=False, tol=args.tol)
-            tmodel.ctx.profile_enable(True)
+            tmodel.ctx.profile_enable(args.event_every)
             fence()
             t0 = time.perf_counter()
             tmodel.iterate_many(args.steps, fit=False, tol=args.tol)
@@ -692,7 +696,7 @@ def main():
                 # all-reduce of every iteration included); torch path: the loop's pieces around torch.distributed.
                 model.begin()
                 model.iterate_many(args.warmup, fit=True, tol=args.tol)
-                model.ctx.profile_enable(True)
+                model.ctx.profile_enable(args.event_every)
                 fence()
                 t0 = time.perf_counter()
                 model.iterate_many(args.steps, fit=True, tol=args.tol)
@@ -804,6 +808,8 @@ def main():
             'traffic_is_current': bool(traffic_row and traffic_hash == src_hash),
             'operands': 'f16 (v_mfma_f32_32x32x16_f16), fp32 accumulate' if fast16 else args.precision,
             'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'], 'rows_per_launch': n_row,
+            'launches_timed_by': 'HIP events on the kernel\'s stream around every %s launch of the timed region' % (
+                'single' if args.event_every <= 1 else '%d-th' % args.event_every),
             'algorithmic_flops_per_launch': flops_row,
             'algorithmic_bytes_per_launch': alg_bytes_row,
             'schedule_bytes_per_launch': sched_bytes_row,

@@ -619,7 +619,8 @@ class Context(object):
 
     # -- measurement --
     def profile_enable(self, on=True):
-        _check(self._lib.klnmf_profile_enable(self._h, 1 if on else 0))
+        """True / 1: every iteration's row- and column-pass launches bracketed by HIP events; N > 1: every N-th iteration's."""
+        _check(self._lib.klnmf_profile_enable(self._h, int(on) if on else 0))
 
     def profile_read(self, reset=True):
         rn, cn = _i64(0), _i64(0)

@@ -119,6 +119,9 @@ int klnmf_profile_enable(klnmf_ctx *c, int on) {
     return guarded([&] {
         use(c);
         c->profiling = on != 0;
+        c->profile_every = on > 1 ? on : 1;
+        c->profile_seq = 0;
+        c->prof_now = c->profiling;          // (launches outside a loop's iterations -- klnmf_error, klnmf_init_W -- follow the last setting)
     });
 }
 

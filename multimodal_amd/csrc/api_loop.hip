@@ -140,7 +140,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     }
     if (mode == ROW_UPDATE && a.Qt && c->q8()) c->stat_q8_tiles += 1;      // this update leaves fp8 ratio tiles
     EventPair ev{};
-    if (c->profiling) ev = begin_event(c, c->ev_row);
+    if (c->prof_now) ev = begin_event(c, c->ev_row);
     RowPass4Args a4{a, c->Ht4};
     const int nw = c->big ? 4 : kWaves4;
     const int grid4 = (c->nrt + nw - 1) / nw;
@@ -154,7 +154,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                            c->W32[c->cur ^ 1], c->Wb[c->cur ^ 1], rows, c->KP, (int)w_ld(c->KP), c->kc,
                            (const DevState *)c->st, a.tcur, a.tnext);
         HIPCHK(hipGetLastError());
-        if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+        if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
         return;
     }
     if (mode == ROW_UPDATE && c->tail_wg > 0) {
@@ -163,7 +163,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
         // and its W rule applied from the slabs
         launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4 - c->tail_wg);
         EventPair evt{};
-        if (c->profiling) evt = begin_event(c, c->ev_tail);
+        if (c->prof_now) evt = begin_event(c, c->ev_tail);
         RowPass4Args t4 = a4;
         t4.base.wg0 = grid4 - c->tail_wg;
         t4.base.rt0 = c->tail_rt0();
@@ -187,7 +187,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
             c->w8_meas = true;
             c->conv_ran = true;
         }
-        if (c->profiling) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
+        if (c->prof_now) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
         return;
     }
     if (w8_here) { c->w8_meas = true; c->conv_ran = true; }
@@ -196,7 +196,7 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
         case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
         default: launch_rowpass4_kt<ROW_LOSS>(c, a4, grid4); break;
     }
-    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
 }
 
 // ---- the fused iteration tail (post.hip.h): column pass of one column part, then k_post -----------------------------------
@@ -237,7 +237,7 @@ template <typename T>
 void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
     const int64_t hk = c->k * c->f;
     EventPair ev{};
-    if (c->profiling) ev = begin_event(c, c->ev_row);
+    if (c->prof_now) ev = begin_event(c, c->ev_row);
     hipLaunchKernelGGL((k_sp_transpose_H<T>), dim3(grid_for(hk)), dim3(256), 0, c->stream, (const T *)c->H,
                        (T *)c->HT, c->k, c->f, (const DevState *)c->st);
 #define KL_SPQ_ARGS (const int64_t *)c->sp_indptr, (const int64_t *)c->sp_indices, (const T *)c->sp_data, \
@@ -252,13 +252,13 @@ void sparse_Q(klnmf_ctx *c, int write_q, double eps, const DecideArgs &dec) {
         if (kcb <= 1) KL_SPB_QW_MODE(1); else if (kcb == 2) KL_SPB_QW_MODE(2); else if (kcb <= 4) KL_SPB_QW_MODE(4); else KL_SPB_QW_MODE(8);
 #undef KL_SPB_QW_MODE
         HIPCHK(hipGetLastError());
-        if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+        if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
     } else {
     // (k > 512, or no stored entries: every lane takes its own entries and loops over the components)
     hipLaunchKernelGGL((k_sp_q_anyk<T>), dim3((unsigned)c->n), dim3(64), 0, c->stream, KL_SPQ_ARGS);
 #undef KL_SPQ_ARGS
     HIPCHK(hipGetLastError());
-    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
     }
     hipLaunchKernelGGL((k_sp_colsum_part<T>), dim3((unsigned)c->sp_nblk), dim3(256), 0, c->stream,
                        (const T *)c->W[c->cur], c->sp_wpart, c->n, c->k, (const DevState *)c->st);
@@ -289,13 +289,13 @@ void exact_Q(klnmf_ctx *c, int write_q, double eps = kEpsRatio, DecideArgs dec =
     const int TL = 16 * c->q_tt;
     dim3 grid((unsigned)((c->f + TL - 1) / TL), (unsigned)((c->n + TL - 1) / TL), 1);
     EventPair ev{};
-    if (c->profiling) ev = begin_event(c, c->ev_row);
+    if (c->prof_now) ev = begin_event(c, c->ev_row);
     KL_GEMM_TT(c->q_tt, T, EpiQ<T>, grid, c->stream, (int)c->n, (int)c->f,
                (int)c->k, (const T *)c->W[c->cur], (int64_t)c->k, (int64_t)1,
                (const T *)c->H, (int64_t)c->f, (int64_t)1, (int)c->k + GK,
                (const DevState *)c->st, epi);
     HIPCHK(hipGetLastError());
-    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
     hipLaunchKernelGGL(k_sum_doubles, dim3(1), dim3(1024), 0, c->stream,
                        (const double *)c->loss_part, (int64_t)grid.x * grid.y, c->loss_xchg,
                        (const DevState *)c->st, dec);
@@ -359,7 +359,7 @@ template <typename T>
 void exact_N(klnmf_ctx *c, int widx, bool sum_slabs = true) {
     if (c->sparse && c->sp_blocked) {        // W^T . Q over the CSC order, row block by row block (sparseb.hip.h)
         EventPair evs{};
-        if (c->profiling) evs = begin_event(c, c->ev_col);
+        if (c->prof_now) evs = begin_event(c, c->ev_col);
         const int kcb = (int)((c->k + 63) / 64);
         const unsigned gridb = (unsigned)((int64_t)c->sp_rb * c->f);
 #define KL_SPB_N(KCV) hipLaunchKernelGGL((k_spb_n<T, KCV>), dim3(gridb), dim3(64), 0, c->stream, (const int64_t *)c->csc_blkptr, (const int *)c->csc_rows32, \
@@ -369,31 +369,31 @@ void exact_N(klnmf_ctx *c, int widx, bool sum_slabs = true) {
         hipLaunchKernelGGL((k_spb_numer<T>), dim3((unsigned)((c->f + 31) / 32), (unsigned)((c->k + 31) / 32)), dim3(256), 0, c->stream,
                            (const T *)c->sp_NT, c->sp_rb, (T *)c->numer, c->k, c->f, (const DevState *)c->st);
         HIPCHK(hipGetLastError());
-        if (c->profiling) HIPCHK(hipEventRecord(evs.b, c->stream));
+        if (c->prof_now) HIPCHK(hipEventRecord(evs.b, c->stream));
         return;
     }
     if (c->sparse) {        // W^T . Q, one block per feature column (CSC order)
         EventPair evs{};
-        if (c->profiling) evs = begin_event(c, c->ev_col);
+        if (c->prof_now) evs = begin_event(c, c->ev_col);
         const int spn_threads = (int)std::min<int64_t>(256, (c->k + 63) / 64 * 64);
         hipLaunchKernelGGL((k_sp_n<T>), dim3((unsigned)c->f), dim3(spn_threads), 0, c->stream, (const int64_t *)c->csc_indptr,
                            (const int64_t *)c->csc_rows, (const int64_t *)c->csc_perm, (const T *)c->sp_q,
                            (const T *)c->W[widx], (T *)c->numer, c->k, c->f, (const DevState *)c->st);
         HIPCHK(hipGetLastError());
-        if (c->profiling) HIPCHK(hipEventRecord(evs.b, c->stream));
+        if (c->prof_now) HIPCHK(hipEventRecord(evs.b, c->stream));
         return;
     }
     EpiN<T> epi{(T *)c->Npart, c->f, c->k * c->f};
     const int TLn = 16 * c->n_tt;
     dim3 grid((unsigned)((c->f + TLn - 1) / TLn), (unsigned)((c->k + TLn - 1) / TLn), (unsigned)c->nsplit);
     EventPair ev{};
-    if (c->profiling) ev = begin_event(c, c->ev_col);
+    if (c->prof_now) ev = begin_event(c, c->ev_col);
     KL_GEMM_TT(c->n_tt, T, EpiN<T>, grid, c->stream, (int)c->k, (int)c->f,
                (int)c->n, (const T *)c->W[widx], (int64_t)1, (int64_t)c->k,
                (const T *)c->Q, (int64_t)c->f, (int64_t)1, c->kchunk,
                (const DevState *)c->st, epi);
     HIPCHK(hipGetLastError());
-    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
     if (!sum_slabs) return;
     const int64_t count = c->k * c->f;
     hipLaunchKernelGGL((k_sum_partials<T>), dim3(grid_for(count)), dim3(256), 0, c->stream,
@@ -488,7 +488,7 @@ void fused_colpass_part(klnmf_ctx *c, const klnmf_ctx::PartCfg &p, bool use8) {
     ColPassQArgs a = colq_part_args(c, p);
     const int grid = p.ncb * p.nchunks;
     EventPair ev{};
-    if (c->profiling) ev = begin_event(c, c->ev_col);
+    if (c->prof_now) ev = begin_event(c, c->ev_col);
     auto launch_q2 = [&](const ColPassQArgs &g, bool fp8_tiles) {
         switch (c->KT) {
 #define KL_PQ2(KTV) case KTV:                                                                                                    \
@@ -529,7 +529,7 @@ void fused_colpass_part(klnmf_ctx *c, const klnmf_ctx::PartCfg &p, bool use8) {
     } else {
         launch_q2(a, c->q8());
     }
-    if (c->profiling) HIPCHK(hipEventRecord(ev.b, c->stream));
+    if (c->prof_now) HIPCHK(hipEventRecord(ev.b, c->stream));
 }
 
 // POST_FULL: everything behind the column pass of a single-context fit iteration (`la`: the row pass's loss partials and the
@@ -641,6 +641,7 @@ void poll_fp8_overflow(klnmf_ctx *c, bool agreed) {
 
 // fused_tol != nullptr (klnmf_run): the stop rule rides in the launch that reduces the loss (no k_decide launch)
 void piece_rowpass(klnmf_ctx *c, int fit, const double *fused_tol, bool defer_to_post) {
+    c->prof_now = c->profiling && (c->profile_seq++ % c->profile_every) == 0;      // (sampled event bracketing: ctx.hip.h)
     // the W rule is the same for fit and transform (nmf.py:251-253); a fit also keeps the ratios for the H rule
     if (c->is_exact()) {
         // fused_tol (single-context loops): the stop rule in the loss reduction's launch, no k_decide

@@ -360,6 +360,12 @@ struct klnmf_ctx {
     bool v_uploaded = false;
 
     bool profiling = false;
+    // every `profile_every`-th iteration of a loop has its row-pass / column-pass launches bracketed by HIP events (1: every one).
+    // An event record is a packet of its own in the stream: about 5-6 us of dispatch gap each -- four of them per fit iteration
+    // were 3.5 % of one rank's 0.65 ms shard iteration (profiles/r06_timelines_shard.txt), so bench.py samples every 4th
+    int profile_every = 1;
+    int64_t profile_seq = 0;
+    bool prof_now = false;           // this iteration's launches are bracketed (set by piece_rowpass)
     std::vector<EventPair> ev_row, ev_col, ev_tail;      // ev_tail: the column-split tail + slabs part of a hybrid row pass
 
     // row shards over the GPUs of a node (klnmf_comm_*, klnmf_run_sharded): this rank's RCCL communicator

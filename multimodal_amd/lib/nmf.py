@@ -55,9 +55,10 @@ AUTO_F16_MIN_K = 16
 
 # ... and on the data: a fit whose final KL / sum(V) falls below this has so little residual left that the f16 operands' own
 # rounding noise (about 3e-4 / sqrt(terms) per product) can pass 1e-4 of the loss (measured: low-noise rank-8 data, 160 000 rows,
-# 150 iterations: 8e-4).  The library reports the ratio of every loop (klnmf_query_f64
+# 150 iterations: 8e-4, at KL / sum(V) = 4e-4; the reference's fixtures G18 / G19 sit at 5.5e-4 and 2.9e-3; the BASELINE
+# configurations' data at 4.8e-3 .. 9.5e-3).  The library reports the ratio of every loop (klnmf_query_f64
 # KLNMF_QF_KL_OVER_SUM_V); `KLdivNMF.last_fp8_report['outside_f16_envelope']` and one stderr line say when a fit ended below it.
-F16_MIN_KL_OVER_SUM_V = 2e-3
+F16_MIN_KL_OVER_SUM_V = 3e-3
 
 MAX_K_MFMA = 512          # the 16-bit MFMA kernels hold a wave's accumulators of all components in registers: k <= 512
 MAX_ROWS_EXACT = 65535 * 64   # the exact modes' row tiles ride on gridDim.y (csrc/api_context.hip: KLNMF_ERR_UNSUPP beyond)
