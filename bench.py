@@ -285,8 +285,8 @@ def measured_traffic(args, n_local):
                 for kname, v in entry.get('kernels', {}).items():
                     if 'k_rowpass' in kname and 'column-split' not in kname:      # the whole-row launch (the roofline entry)
                         row = v['hbm_bytes_per_launch']
-                    elif 'k_colpass' in kname:
-                        col = v['hbm_bytes_per_launch']
+                    elif 'k_colpass' in kname:      # (the guarded fallback launch behind the fp8 x fp8 pass moves nothing: the larger one)
+                        col = max(col or 0.0, v['hbm_bytes_per_launch'])
                 MEASURED_ITERATION['bytes'] = entry.get('hbm_bytes_per_iteration')
                 return row, col, name, d.get('source_hash')
     return None, None, None, None

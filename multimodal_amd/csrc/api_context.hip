@@ -408,10 +408,6 @@ int klnmf_set_problem(klnmf_ctx *c, int64_t n, int64_t f, int64_t k, int64_t cap
             const bool col8_size = c->big || (c->KT >= 4 && n >= 65536) || c->sw.col8 >= 1;
             if (c->q8_ok && !col8_off && col8_size) {
                 c->W8 = (unsigned char *)c->dalloc((size_t)(c->n_pad + 64) * w8_ld(c->KP) + 65536);
-                // who writes the e4m3 image: the conversion kernel behind the row pass (default) or the row pass's W rule itself
-                // (KLNMF_COL8=2, k <= 224: one pass over W less and no conversion launch -- +0.6 % at n = 10^6, -0.8 % on a
-                // 125 000-row shard where the tail weighs more: profiles/r03_ab_w8_from_w_rule.txt; not the default)
-                c->w8_tail = !c->big && c->sw.col8 == 2;
                 c->w8s = (float *)c->dalloc((size_t)c->KP * 4);
                 const std::vector<float> unit8((size_t)c->KP, 256.f);
                 HIPCHK(hipMemcpyAsync(c->w8s, unit8.data(), unit8.size() * 4, hipMemcpyHostToDevice, c->stream));

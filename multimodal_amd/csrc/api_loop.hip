@@ -125,19 +125,6 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
     a.cq_on = c->images_measured ? 1 : 0;
     // stochastic rounding of fp8 ratio tiles: another stream per launch and per rank, the same streams for the same fit
     a.sr_seed = ((unsigned)c->sr_launches++ * 0x9E3779B9u + 0x7F4A7C15u) ^ ((unsigned)c->comm_rank * 0xC2B2AE35u);
-    // e4m3 image of W_new written by the W rule itself (KLNMF_COL8=2, whole-row launches): the maxima go to the 64-row table
-    // k_post turns into the next scales, and the image is written from the loop's second iteration on, so that the third can
-    // already multiply it
-    const bool w8_here = c->w8_tail && c->W8 && store_q && mode == ROW_UPDATE && c->row_chunks == 1 && c->q8_loop && c->iter_in_loop >= 1;
-    if (c->w8_tail && mode == ROW_UPDATE) { c->conv_ran = false; c->tail_use8 = false; }
-    if (w8_here) {
-        c->tail_use8 = c->w8_meas && c->q8();
-        a.w8tab = c->w8tab;
-        a.W8 = c->W8;
-        a.w8s = c->w8s;
-        a.w8_sat = &c->st->w8_sat;
-        a.w8_probe = w8_probe_col(c);
-    }
     if (mode == ROW_UPDATE && a.Qt && c->q8()) c->stat_q8_tiles += 1;      // this update leaves fp8 ratio tiles
     EventPair ev{};
     if (c->prof_now) ev = begin_event(c, c->ev_row);
@@ -177,20 +164,9 @@ void fast_rowpass(klnmf_ctx *c, int mode, int store_q = 0) {
                            c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), c->kc,
                            (const DevState *)c->st, a.tcur, a.tnext);
         HIPCHK(hipGetLastError());
-        if (w8_here) {         // the rows of the split tail: image and maxima by the conversion kernel (a few thousand rows)
-            const int groups = c->KP / 8, rpb = 256 / groups;
-            const int blocks = (int)std::min<int64_t>((rows + rpb - 1) / rpb, kW8Blocks);
-            hipLaunchKernelGGL(k_w8_from_wb, dim3(blocks), dim3(256), 0, c->stream, (const opnd_t *)c->Wb[c->cur ^ 1] + row0 * w_ld(c->KP),
-                               c->W8 + row0 * w8_ld(c->KP), rows, c->KP, (int)w_ld(c->KP), (const float *)c->w8s,
-                               (const DevState *)c->st, &c->st->w8_sat, w8_probe_col(c), c->w8tab, a.sr_seed ^ 0x5bd1e995u);
-            HIPCHK(hipGetLastError());
-            c->w8_meas = true;
-            c->conv_ran = true;
-        }
         if (c->prof_now) { HIPCHK(hipEventRecord(evt.b, c->stream)); HIPCHK(hipEventRecord(ev.b, c->stream)); }
         return;
     }
-    if (w8_here) { c->w8_meas = true; c->conv_ran = true; }
     switch (mode) {
         case ROW_UPDATE: launch_rowpass4_kt<ROW_UPDATE>(c, a4, grid4); break;
         case ROW_INIT: launch_rowpass4_kt<ROW_INIT>(c, a4, grid4); break;
@@ -465,7 +441,6 @@ void launch_monitor(klnmf_ctx *c, bool use8) {
 // the e4m3 image of W_new for this iteration's fp8 x fp8 column pass (once per iteration, before the first part's pass):
 // converted with the scales k_post derived from the PREVIOUS conversion's maxima; returns whether the fp8 x fp8 pass may run
 bool fused_w8_stage(klnmf_ctx *c) {
-    if (c->w8_tail) return c->tail_use8 && c->conv_ran;      // the row pass's W rule wrote image and maxima itself (fast_rowpass)
     c->conv_ran = false;
     if (!c->W8 || !c->q8_loop) return false;
     const bool measure_only = c->iter_in_loop == 1 && !c->w8_meas;      // the loop's second iteration (16-bit tiles still)

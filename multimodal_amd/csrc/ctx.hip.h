@@ -167,7 +167,7 @@ extern DevBlockCache g_block_cache;      // (api_context.hip)
 // KLNMF_PRECISION / KLNMF_DEVICE / KLNMF_LIB / KLNMF_NO_POOL: INTEGRATION.md section 1.)
 struct DevSwitches {
     int qtile = 0;              // KLNMF_QTILE = 8 / 16: fp8 ratio tiles forced on (from a loop's third iteration) / off      [16: also without KLNMF_DEV]
-    int col8 = -1;              // KLNMF_COL8 = 0: no fp8 x fp8 column pass; 1: at any size; 2: the W rule writes the e4m3 image itself
+    int col8 = -1;              // KLNMF_COL8 = 0: no fp8 x fp8 column pass; 1: at any size
     int ne = -1;                // KLNMF_NE = 0 / 1: the update pass without the numerator's eps never / in every fp8 loop
     bool q8_fixup = true;       // KLNMF_Q8_FIXUP=0: no exact correction of large ratio entries (the tests' control run)
     bool q8_monitor = true;     // KLNMF_Q8_MONITOR=0: no monitor
@@ -270,8 +270,6 @@ struct klnmf_ctx {
     unsigned char *W8 = nullptr;              // e4m3 image of W_new for the fp8 x fp8 column pass (colq8x.hip.h; KLNMF_COL8=0: off)
     float *w8s = nullptr;                     // [KP] power-of-two scales of the e4m3 image
     bool w8_meas = false;                     // the maxima table holds a measurement of this loop
-    bool w8_tail = false;                     // KLNMF_COL8=2: the W rule writes the e4m3 image itself (whole-row launch); the conversion
-                                              // kernel then only covers the rows of the column-split last partial round
     int64_t loss_parts() const {               // entries of loss_part2 an update pass writes
         if (tail_wg > 0) return (int64_t)nrt + (int64_t)(tail_chunks - 1) * (nrt - tail_rt0());
         return (int64_t)nrt * row_chunks;
@@ -326,7 +324,6 @@ struct klnmf_ctx {
     float *loop_h0 = nullptr, *loop_h1 = nullptr;      // H32 / H32alt as the loop found them
     unsigned *w8tab = nullptr;                // [kW8TabRows][KP] maxima of the conversion kernel (k_post: -> w8s_next, emptied)
     float *w8s_next = nullptr;                // [KP] scales of the NEXT image: k_post writes them, then w8s / w8s_next swap
-    bool tail_use8 = false;                   // KLNMF_COL8=2 on the fused tail: the image the W rule just wrote carries measured scales
     bool conv_ran = false;                    // this iteration's conversion ran: k_post derives the next scales
 
     // Column parts of the H numerator.  `whole`: all columns as one part (layout [KP][f_pad], what every single-context loop

@@ -135,13 +135,10 @@ struct RowPassArgs {
     // (50 000 rows = 196 workgroups of 8 row tiles on 256 CUs) is spread over more of them with 7, 6, ... row tiles per
     // workgroup, the workgroup's last waves idling: such problems are HBM-bound per CU (api_loop.hip, fast_rowpass)
     int rpw;
-    // fp8 x fp8 column pass (colq8x.hip.h): the W rule also leaves the e4m3 image of W_new (f16 image / w8s[component],
-    // exactly as k_w8_from_wb converts it) and this wave's column maxima of the f16 image; null: not written
-    unsigned char *W8;
-    const float *w8s;         // [KP]
-    unsigned *w8tab;          // the maxima go by atomicMax into row (rt & 63) of this [64][KP] table (post.hip.h)
-    int *w8_sat;              // entries of this image beyond e4m3's 448 (stored as 448) are counted here, as k_w8_from_wb does
-    int w8_probe;             // the image's probe column (colq8x.hip.h; e4m3 1.0 in every row): KP - 1 or -1 (none)
+    // (The e4m3 image of W_new for the fp8 x fp8 column pass is written by the conversion kernel k_w8_from_wb, colq8x.hip.h.  Until
+    // round 6 the W rule could write it itself -- KLNMF_COL8=2, measured three times as no gain: what the conversion launch costs
+    // came back as un-overlapped tail of the row pass -- and its registers made every KT = 7 update kernel spill 8 of them: a
+    // kernel with scratch pays 4 us more per launch on this part: profiles/r06_boundary_probe.txt, r06_ab_w8_from_w_rule.txt.)
     unsigned sr_seed;         // fp8 ratio tiles: this launch's seed of the stochastic rounding (mfma4.hip.h, sr_cvt4)
 };
 

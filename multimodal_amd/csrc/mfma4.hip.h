@@ -727,15 +727,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
         // registers of the main loop are dead here, so KT*16 registers are free): one memory round trip per wave.
         // (For KT > 8 in blocks of 8 component tiles: the accumulators alone fill half the register file.)
         KL_LDS float *tb = (KL_LDS float *)arena + wave * (32 * kTLD);
-        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2w;
-        typedef __attribute__((ext_vector_type(2))) short s16x2w;
-        const bool w8on = MODE == ROW_UPDATE && KT <= 8 && a.W8 != nullptr;      // scalar
-        f16x2w mx8[KT <= 8 ? KT : 1][2];                                         // running column maxima of the f16 image (packed)
-        int nsat8 = 0;                                                           // entries of the e4m3 image that clipped at 448 (wave-uniform: a scalar)
-        if (w8on) {
-#pragma unroll
-            for (int m = 0; m < (KT <= 8 ? KT : 1); ++m) { mx8[m][0] = f16x2w{(_Float16)0.f, (_Float16)0.f}; mx8[m][1] = mx8[m][0]; }
-        }
         const int c4 = (lane & 7) * 4, rj = lane >> 3;
         const int64_t row0 = (int64_t)rt * 32;
         constexpr int MB = KT <= 8 ? KT : 8;
@@ -769,12 +760,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own writes, read back by other lanes
                 const f32x4 tc = *(const KL_LDS f32x4 *)(tc_lds + 32 * m + c4), tn = *(const KL_LDS f32x4 *)(tn_lds + 32 * m + c4);
-                f16x2w inv8[2];
-                if (w8on) {
-                    const f32x4 s8 = *(const f32x4 *)(a.w8s + 32 * m + c4);      // powers of two: the reciprocals are exact
-                    inv8[0] = f16x2w{(_Float16)__builtin_amdgcn_rcpf(s8[0]), (_Float16)__builtin_amdgcn_rcpf(s8[1])};
-                    inv8[1] = f16x2w{(_Float16)__builtin_amdgcn_rcpf(s8[2]), (_Float16)__builtin_amdgcn_rcpf(s8[3])};
-                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int rl = 8 * j + rj, comp = 32 * m + c4;
@@ -788,54 +773,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_rowpass4(RowPass4A
                     }
                     __builtin_nontemporal_store(w, (f32x4 *)(a.W32_new + (row0 + rl) * KP + comp));
                     *(opx4 *)(a.Wb_new + (row0 + rl) * WLD + wb_col(rl, comp)) = wb;
-                    if (w8on) {                                             // the e4m3 image, the operations of k_w8_from_wb
-                        const f16x2w lo = f16x2w{wb[0], wb[1]}, hi = f16x2w{wb[2], wb[3]};
-                        mx8[mm][0] = __builtin_elementwise_max(mx8[mm][0], lo);
-                        mx8[mm][1] = __builtin_elementwise_max(mx8[mm][1], hi);
-                        const f16x2w p0 = lo * inv8[0], p1 = hi * inv8[1];
-                        const unsigned w8 = sr_pack4(p0, p1, std::integral_constant<int, 1>{});
-                        const f16x2w top = __builtin_elementwise_max(p0, p1);                  // (448 is an f16 number)
-                        if (__builtin_amdgcn_ballot_w64(top[0] > (_Float16)448.f || top[1] > (_Float16)448.f) != 0ull)      // rare, wave-uniform:
-                            nsat8 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p0[0] > (_Float16)448.f))                // a column that more than doubled
-                                   + __builtin_popcountll(__builtin_amdgcn_ballot_w64(p0[1] > (_Float16)448.f))
-                                   + __builtin_popcountll(__builtin_amdgcn_ballot_w64(p1[0] > (_Float16)448.f))
-                                   + __builtin_popcountll(__builtin_amdgcn_ballot_w64(p1[1] > (_Float16)448.f));
-                        unsigned w8u = w8;
-                        // the probe column (always the image's last one, KP - 1 = byte 3 of the last block's last word): e4m3 1.0 in every row
-                        if (m == KT - 1 && a.w8_probe >= 0 && c4 == 28) w8u = (w8u & 0x00ffffffu) | 0x38000000u;
-                        *(unsigned *)(a.W8 + (row0 + rl) * (KP + ((KP / 32) % 2 == 0 ? 32 : 0)) + comp) = w8u;      // row stride: w8_ld(KP), colq8x.hip.h
-                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // block m read before block m + 1 overwrites it
             }
             if (MODE == ROW_UPDATE) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (w8on && nsat8 != 0 && a.w8_sat != nullptr && lane == 0) atomicAdd(a.w8_sat, nsat8);
-        if (w8on) {
-            // maxima over the wave's 32 rows: the eight lanes with the same components differ in lane bits 3..5
-#pragma unroll
-            for (int m = 0; m < (KT <= 8 ? KT : 1); ++m)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    unsigned v = __builtin_bit_cast(unsigned, mx8[m][q]);
-#pragma unroll
-                    for (int o = 8; o < 64; o <<= 1) {
-                        const unsigned other = (unsigned)__shfl_xor((int)v, o, 64);
-                        v = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2w, v), __builtin_bit_cast(f16x2w, other)));
-                    }
-                    mx8[m][q] = __builtin_bit_cast(f16x2w, v);
-                }
-            if (lane < 8) {
-#pragma unroll
-                for (int m = 0; m < (KT <= 8 ? KT : 1); ++m) {
-                    u32x4 o;
-                    o[0] = __float_as_uint((float)mx8[m][0][0]); o[1] = __float_as_uint((float)mx8[m][0][1]);
-                    o[2] = __float_as_uint((float)mx8[m][1][0]); o[3] = __float_as_uint((float)mx8[m][1][1]);
-                    // 64-row table, emptied by k_post when it derives the next scales
-                    unsigned *tb8 = a.w8tab + (int64_t)(rt & 63) * KP + 32 * m + c4;
-                    atomicMax(tb8, o[0]); atomicMax(tb8 + 1, o[1]); atomicMax(tb8 + 2, o[2]); atomicMax(tb8 + 3, o[3]);
-                }
-            }
         }
     }
 }

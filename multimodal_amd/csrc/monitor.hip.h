@@ -100,6 +100,7 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
     __shared__ __attribute__((aligned(16))) float Hd[32][32]; // held
     __shared__ float Qx[32][33];                              // the plain ratio where the entry of V is > 0, else 0
     __shared__ float Sp[3][32];                               // this block's count / sum / sum of squares of the ratios per column
+    __shared__ float Wi_s[32][256], Wo_s[32][256];            // phase B: each thread's 32 image entries / operands of the row tile (its own column)
     if (threadIdx.x < 96) Sp[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
     const int tid = threadIdx.x;
     const int i = tid >> 3, c4 = (tid & 7) * 4;              // phase A: this thread's row and first column of the tile
@@ -183,10 +184,31 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
                             dry_scale = ldexpf(1.f, e);
                         }
                     }
+                    // this component's 32 image entries (and e4m3 bytes) of the row tile: all requested before the first use -- one
+                    // dependent load per row made this loop 64 round trips per block, most of the launch's 128 us at k = 200 (round 6).
+                    // The operands of the rolled loop below wait in this thread's own LDS column (registers indexed by the loop
+                    // counter would live in scratch).
+                    {
+                        opnd_t wimg_r[32];
+                        unsigned w8_r[32];
+#pragma unroll
+                        for (int ii = 0; ii < 32; ++ii) wimg_r[ii] = a.Wb_new[(row0 + ii) * a.wld + wb_col(ii, comp)];
+                        if (used_w8) {
+#pragma unroll
+                            for (int ii = 0; ii < 32; ++ii) w8_r[ii] = a.W8[(row0 + ii) * a.w8ld + comp];
+                        }
+                        const float w8s_c = used_w8 ? a.w8s[comp] : 0.f;
+#pragma unroll
+                        for (int ii = 0; ii < 32; ++ii) {
+                            const float wimg = (float)wimg_r[ii];
+                            Wi_s[ii][tid] = wimg;
+                            Wo_s[ii][tid] = used_w8 ? e4m3_value(w8_r[ii]) * w8s_c : wimg;
+                        }
+                    }
                     for (int ii = 0; ii < 32; ++ii) {
                         const int64_t row = row0 + ii;
-                        const float wimg = (float)a.Wb_new[row * a.wld + wb_col(ii, comp)];
-                        float wop = used_w8 ? e4m3_value(a.W8[row * a.w8ld + comp]) * a.w8s[comp] : wimg;
+                        const float wimg = Wi_s[ii][tid];
+                        float wop = Wo_s[ii][tid];
                         if (dry_scale > 0.f) {        // the conversion of k_w8_from_wb on this one value (stochastically rounded)
                             unsigned sd = ((unsigned)row * 0x9E3779B1u) ^ ((unsigned)comp * 0x85EBCA6Bu) ^ ((unsigned)a.rot * 0xC2B2AE35u);
                             sd = (sd ^ (sd >> 15)) * 0x2C1B3C6Du;

@@ -298,13 +298,23 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         }
         if (comp == 0) {
             // the relative spread of each monitored column's ratios (monitor.hip.h, kMonMinSpread): block 0, thread = column
-            __shared__ float sp_s[32];
+            // (32 lanes walking the 128 blocks' sums one after the other were 384 dependent loads: 30 of the 45 us this kernel took on
+            // a monitored iteration at one rank's shard; every 32-thread group now takes a contiguous run of blocks -- round 6)
+            __shared__ float sp_s[32], sp_g[32][3][32];
+            const int ngrp = (int)(blockDim.x >> 5), gi = tid >> 5, ci = tid & 31;      // ngrp = 8, 16 or 32
+            {
+                const int per = kMonBlocks / ngrp;
+                float cnt = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int blk = gi * per; blk < (gi + 1) * per; ++blk) {
+                    const float *sp = a.mon.spread + (int64_t)blk * 96;
+                    cnt += sp[ci]; s1 += sp[32 + ci]; s2 += sp[64 + ci];
+                }
+                sp_g[gi][0][ci] = cnt; sp_g[gi][1][ci] = s1; sp_g[gi][2][ci] = s2;
+            }
+            __syncthreads();
             if (tid < 32) {
                 float cnt = 0.f, s1 = 0.f, s2 = 0.f;
-                for (int blk = 0; blk < kMonBlocks; ++blk) {
-                    const float *sp = a.mon.spread + (int64_t)blk * 96;
-                    cnt += sp[tid]; s1 += sp[32 + tid]; s2 += sp[64 + tid];
-                }
+                for (int g = 0; g < ngrp; ++g) { cnt += sp_g[g][0][tid]; s1 += sp_g[g][1][tid]; s2 += sp_g[g][2][tid]; }
                 float rel = 1.f;                                  // (a column without entries > 0 in the sample: nothing to resolve)
                 if (tid < a.mon.ncols && cnt >= 64.f && s1 > 0.f) {
                     const float m = s1 / cnt, var = fmaxf(s2 / cnt - m * m, 0.f);
