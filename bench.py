@@ -450,7 +450,7 @@ def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fe
         tmodel.set_v_max(vmax)
         synthetic.for_each_block(args.seed, r0, r1, n, f, k,
                                  lambda lo, arr: tmodel.upload_V(np.ascontiguousarray(arr[:, :fs]), row0=lo, col0=0))
-    segments, prof_tot, last = [], {'rowpass_ms': 0.0, 'rowpass_launches': 0}, None
+    segments, prof_tot, last, tail_rows = [], {'rowpass_ms': 0.0, 'rowpass_launches': 0}, None, 0
     for rep in range(max(1, args.repeats)):
         with Watchdog(args.segment_timeout, 'transform segment %d' % rep, rank):
             tmodel.set_H(H)
@@ -464,6 +464,7 @@ def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fe
             fence()
             elapsed = time.perf_counter() - t0
             prof = tmodel.ctx.profile_read(reset=True)
+            tail_rows = prof.get('tail_rows', 0) if prof.get('tail_launches', 0) else 0
             tmodel.ctx.profile_enable(False)
             last = tmodel.end()
             t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -490,7 +491,7 @@ def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fe
     row_s = row_ms * 1e-3
     tfl, gbs = flops_row / row_s / 1e12, alg_bytes_row / row_s / 1e9
     traffic = None
-    for name in [os.path.join('profiles', 'r05_pmc_traffic_transform.json')]:
+    for name in [os.path.join('profiles', 'r05_pmc_traffic_transform.json'), os.path.join('profiles', 'r06_pmc_traffic_transform.json')]:      # (the later file wins)
         try:
             d = json.load(open(os.path.join(ROOT, name)))
             for entry in d.get('workloads', []):
@@ -529,7 +530,11 @@ def run_transform(args, torch, dist, model, H0, world, rank, n_local, r0, r1, fe
             'traffic': traffic['bytes_per_launch'] if traffic else None,
             'traffic_source': traffic['source'] if traffic else None,
             'traffic_is_current': bool(traffic and traffic.get('source_hash') == kernel_source_hash()),
-            'traffic_over_algorithmic': (traffic['bytes_per_launch'] / alg_bytes_row) if traffic else None,
+            # (the PMC figure is the WHOLE-ROW launch's: where the last partial round of workgroups runs column-split, it covers
+            # n_local - tail_rows rows, and so does the algorithmic figure it is divided by -- ADVICE round 5)
+            'traffic_rows': n_local - tail_rows,
+            'traffic_over_algorithmic': (traffic['bytes_per_launch'] / ((n_local - tail_rows) * fs * vbytes + 2 * (n_local - tail_rows) * k * 4))
+                                        if traffic else None,
             'source_hash': kernel_source_hash(),
             'avg_launch_ms': row_ms, 'launches': prof_tot['rowpass_launches'], 'rows_per_launch': n_local,
             'algorithmic_flops_per_launch': flops_row, 'algorithmic_bytes_per_launch': alg_bytes_row,

@@ -11,7 +11,7 @@ void monitor_setup(klnmf_ctx *c) {
     c->mon_pending = false;
     if (!c->q8_ok) return;
     c->mon_part = (float *)c->dalloc((size_t)kMonBlocks * 2 * 2 * c->KP * 32 * 4);
-    c->mon_spread = (float *)c->dalloc((size_t)kMonBlocks * 96 * 4);
+    c->mon_spread = (float *)c->dalloc((size_t)2 * kMonBlocks * 96 * 4);
 }
 
 
@@ -269,6 +269,8 @@ int klnmf_destroy(klnmf_ctx *c) {
         if (c->comm || c->comm_scratch) {
             try { comm_release(c); } catch (...) {}
         }
+        if (c->poll_ev) (void)hipEventDestroy(c->poll_ev);
+        if (c->poll_host) (void)hipHostFree(c->poll_host);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
     });

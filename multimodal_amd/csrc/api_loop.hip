@@ -429,7 +429,7 @@ void launch_monitor(klnmf_ctx *c, bool use8) {
     if (a.nsamp < 2) return;
     a.rot = (int)((c->mon_checks * 7) % a.nrt_data);
     a.eps = (float)(kEpsRatio * c->v_scale);
-    hipLaunchKernelGGL(k_q8_monitor, dim3(kMonBlocks), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_q8_monitor, dim3(2 * kMonBlocks), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     c->mon_pending = true;
     c->mon_dry_pending = dry;
@@ -594,23 +594,48 @@ bool fp8_poll_due(const klnmf_ctx *c) {
     return q8_then && monitor_due(c->stat_q8_tiles);
 }
 
+// what a poll's read-back says: 16-bit tiles from the next iteration on (klnmf_query reports the counts and the statistic)
+static void poll_verdict(klnmf_ctx *c, bool agreed) {
+    bool give_up;
+    if (agreed) {
+        const double *h = (const double *)c->poll_host;
+        give_up = h[1] > 0;
+    } else {
+        const DevState *hs = (const DevState *)c->poll_host;
+        give_up = hs->q8_unfixed > 0 || hs->mon_trips > 0;
+    }
+    if (give_up) { c->q8_loop = false; c->stat_mon_gave_up = true; }
+}
+
+// the answer of a deferred poll (enqueued behind an EARLIER iteration: the event has passed or is about to)
+void poll_resolve(klnmf_ctx *c) {
+    if (!c->poll_inflight) return;
+    c->poll_inflight = false;
+    HIPCHK(hipEventSynchronize(c->poll_ev));
+    if (c->q8_loop) poll_verdict(c, c->poll_agreed);
+}
+
 void poll_fp8_overflow(klnmf_ctx *c, bool agreed) {
+    poll_resolve(c);
     if (!c->q8_loop || c->in_capture) return;
     const bool dry = c->mon_dry_pending;          // the dry run of the iteration just enqueued decides whether the next one takes fp8 tiles
     c->mon_dry_pending = false;
     if (!dry && !(c->q8() && monitor_due(c->stat_q8_tiles))) return;
-    if (agreed) {
-        double h[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(h, c->loss_xchg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    if (!c->poll_host) {
+        HIPCHK(hipHostMalloc(&c->poll_host, sizeof(DevState) > 16 ? sizeof(DevState) : 16, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->poll_ev, hipEventDisableTiming));
+    }
+    if (agreed) HIPCHK(hipMemcpyAsync(c->poll_host, c->loss_xchg, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    else HIPCHK(hipMemcpyAsync(c->poll_host, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    if (dry) {                                    // the next iteration's kernels depend on the answer: wait for it
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (h[1] > 0) { c->q8_loop = false; c->stat_mon_gave_up = true; }
+        poll_verdict(c, agreed);
         return;
     }
-    DevState hs{};
-    HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    // 16-bit tiles from the next iteration on (klnmf_query reports the counts and the statistic)
-    if (hs.q8_unfixed > 0 || hs.mon_trips > 0) { c->q8_loop = false; c->stat_mon_gave_up = true; }
+    // a later check guards a regime the loop is already in: its answer may come one iteration late, and the stream keeps running
+    HIPCHK(hipEventRecord(c->poll_ev, c->stream));
+    c->poll_inflight = true;
+    c->poll_agreed = agreed;
 }
 
 
@@ -717,6 +742,7 @@ void piece_fit_tail(klnmf_ctx *c) {
 }
 
 void fetch_results(klnmf_ctx *c, double *errors_out, int64_t *n_done, int *stopped) {
+    poll_resolve(c);
     DevState hs{};
     HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -805,6 +831,7 @@ void begin_fp8_loop(klnmf_ctx *c, double sum_x_global, double cells_global, doub
     c->mon_pending = false;
     c->mon_dry_pending = false;
     c->stat_mon_gave_up = false;
+    if (c->poll_inflight) { (void)hipEventSynchronize(c->poll_ev); c->poll_inflight = false; }      // (a loop abandoned without klnmf_loop_end)
     c->loop_sum_x_all = sum_x_global;              // (stored units; < 0: fetch_results takes this context's own sum)
     if (c->is_exact() || !c->q8_ok || ok_all == 0) return;
     if (c->W8 != nullptr && c->w8tab != nullptr) {
@@ -1020,7 +1047,9 @@ int klnmf_run(klnmf_ctx *c, int64_t max_iter, int fit, double tol_abs, double *e
         // Measured (scripts/small_problem_timing.py, 200 x 450 .. 10 000 x 4096): 29.5 us per iteration replayed against
         // 28.3 eager -- the iteration is the kernels' own few microseconds and their dependent boundaries, which a graph
         // keeps (MI355X_MICROARCH.md: "dependent kernel boundary ... eager = hipGraph"), not host launch cost.  Off unless asked for.
-        const bool want_graph = c->stream != nullptr && !c->profiling && max_iter >= 12 && c->sw.graph != 0;
+        // (never on a loop that may take fp8 tiles: a replay would reuse the captured iterations' stochastic-rounding seeds and skip the
+        // monitor's checks and polls -- the premises of the fp8 regime)
+        const bool want_graph = c->stream != nullptr && !c->profiling && max_iter >= 12 && c->sw.graph != 0 && !c->q8_loop;
         if (want_graph) {
             for (; it < 2; ++it) one_iteration();
             hipGraph_t graph = nullptr;

@@ -55,7 +55,7 @@ KL_GLOBAL __launch_bounds__(256) void k_w8_from_wb(const opnd_t *Wb, unsigned ch
     for (int e = 0; e < 8; ++e) mx[e] = 0.f;
     if (rl < rows_per_block) {
         const int64_t stride = (int64_t)gridDim.x * rows_per_block;
-        constexpr int U = 8;                          // rows in flight per thread (one dependent load per trip was latency-bound; 4 -> 8 in round 6)
+        constexpr int U = 4;                          // rows in flight per thread (one dependent load per trip was latency-bound; 8 measured in round 6: no gain)
         for (int64_t row0 = (int64_t)blockIdx.x * rows_per_block + rl; row0 < rows; row0 += U * stride) {
             opx8 v[U];
 #pragma unroll

@@ -300,6 +300,13 @@ struct klnmf_ctx {
     int64_t mon_checks = 0, stat_mon_checks = 0, stat_mon_trips = 0;
     double stat_mon_max = 0.0, stat_mon_dbg[3] = {0, 0, 0}, stat_mon_spread = 1.0;
     bool stat_mon_gave_up = false;
+    // polls of the monitor's verdict (poll_fp8_overflow).  The dry run's poll synchronises (its answer decides the NEXT iteration's
+    // kernels); every later one is deferred: the counts are copied to pinned host memory behind the monitored iteration, an event
+    // marks the copy, and the answer is read one iteration later, when the event has long passed -- the stream never drains
+    // (a synchronising poll cost a pipeline bubble plus a pageable read-back per check: 5 checks in bench.py's 40 timed iterations)
+    void *poll_host = nullptr;                // pinned: a DevState or the two doubles of the loss exchange
+    hipEvent_t poll_ev = nullptr;
+    bool poll_inflight = false, poll_agreed = false;
     // the 16-bit mode's data condition (below KL / sum(V) of about 2e-3 the f16 operands' own noise can pass 1e-4
     // of the loss): sum of V over ALL shards as the loop's entry was given it (stored units; < 0: this context's own), and the
     // last loop's final KL / sum(V) (klnmf_query_f64 KLNMF_QF_KL_OVER_SUM_V; < 0: no loop yet / exact mode)

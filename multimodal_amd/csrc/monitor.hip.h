@@ -44,7 +44,7 @@
 namespace klnmf {
 
 constexpr int kW8TabRows = 64;                  // rows of the conversion kernel's maxima table (blockIdx & 63): [kW8TabRows][KP] float bit patterns
-constexpr int kMonBlocks = 128;                  // blocks of the monitor launch = row tile PAIRS sampled (one tile per half)
+constexpr int kMonBlocks = 128;                  // row tile PAIRS sampled (one tile per half-sample); the monitor launch has one block per tile
 // The spread std(q) / mean(q) of each monitored column's ratios is measured as well and reported (klnmf_query_f64): round-to-nearest
 // tiles needed it above a quarter of an e4m3 cell (exactly fitted columns cycled between two cells); with unbiased entries the
 // H rule keeps its feedback inside a cell and the criterion is off (KLNMF_MON_MIN_SPREAD, development, sets one).
@@ -69,7 +69,7 @@ struct MonArgs {
     const unsigned char *W8;      // e4m3 image of W_new if this iteration's column pass multiplies it, else nullptr
     const float *w8s;             // [KP]
     float *part;                  // [kMonBlocks][2 halves][2 (N16, D)][KP][32]
-    float *spread;                // [kMonBlocks][3 (count, sum q, sum q^2)][32]: the ratios' spread per column (entries of V > 0)
+    float *spread;                // [2 kMonBlocks][3 (count, sum q, sum q^2)][32]: the ratios' spread per column (entries of V > 0)
     int nrt, nct, kp, k, wld, w8ld;   // nrt / nct: row / column tiles of the tiled buffers (layout)
     int nrt_data;                 // row tiles that hold data (the sample's range)
     int64_t f_pad;
@@ -105,8 +105,10 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
     const int tid = threadIdx.x;
     const int i = tid >> 3, c4 = (tid & 7) * 4;              // phase A: this thread's row and first column of the tile
     const bool used_w8 = a.W8 != nullptr && a.st->w8_sat == 0;      // (a clipped image: the f16-operand pass runs in its place)
-    for (int half = 0; half < 2; ++half) {
-        const int s = 2 * (int)blockIdx.x + half;
+    {
+        // one sampled row tile per block (round 6; a block used to take both halves of its pair in sequence: 128 blocks of one
+        // wave per SIMD, 123 us of vector arithmetic at k = 200 -- the chip has 256 CUs)
+        const int s = (int)blockIdx.x;
         float n16[2][32], dd[2][32];                          // phase B accumulators: components tid and tid + 256
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -119,13 +121,27 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
             float d[4] = {0.f, 0.f, 0.f, 0.f};
             for (int a0 = 0; a0 < a.k; a0 += AC) {
                 __syncthreads();
-                for (int e = tid; e < AC * 32; e += 256) {
-                    const int aa = e >> 5, jj = e & 31;
-                    Hs[aa][jj] = (a0 + aa < a.k) ? a.H_old[(int64_t)(a0 + aa) * a.f_pad + (int64_t)a.ct * 32 + jj] : 0.f;
-                }
-                for (int e = tid; e < 32 * AC; e += 256) {
-                    const int ii = e / AC, aa = e % AC;
-                    Ws[ii][aa] = (a0 + aa < a.k) ? a.W32_old[(row0 + ii) * a.kp + a0 + aa] : 0.f;
+                {
+                    // the chunk's 2 x 16 loads of this thread are requested together (as rolled loops they were 32 dependent round
+                    // trips per chunk: most of what this launch took -- round 6)
+                    constexpr int NL = AC * 32 / 256;
+                    float hv[NL], wv[NL];
+#pragma unroll
+                    for (int u = 0; u < NL; ++u) {
+                        const int e = tid + 256 * u, aa = e >> 5, jj = e & 31;
+                        hv[u] = (a0 + aa < a.k) ? a.H_old[(int64_t)(a0 + aa) * a.f_pad + (int64_t)a.ct * 32 + jj] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < NL; ++u) {
+                        const int e = tid + 256 * u, ii = e / AC, aa = e % AC;
+                        wv[u] = (a0 + aa < a.k) ? a.W32_old[(row0 + ii) * a.kp + a0 + aa] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < NL; ++u) {
+                        const int e = tid + 256 * u;
+                        Hs[e >> 5][e & 31] = hv[u];
+                        Ws[e / AC][e % AC] = wv[u];
+                    }
                 }
                 __syncthreads();
                 const int na = min(AC, a.k - a0);
@@ -174,6 +190,7 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
                     float dry_scale = 0.f;        // dry run: the scale k_post will give this component's e4m3 image (post.hip.h, w8 block)
                     if (a.dry && a.w8tab != nullptr) {
                         unsigned mb = 0u;
+#pragma unroll 16
                         for (int rr = 0; rr < kW8TabRows; ++rr) mb = max(mb, a.w8tab[rr * a.kp + comp]);
                         const float mx = __uint_as_float(mb);
                         dry_scale = 1.f;
@@ -231,7 +248,7 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
             }
         }
         // this half's partial sums (zeros for a block beyond the sample: k_post sums all blocks)
-        float *pb = a.part + ((int64_t)blockIdx.x * 2 + half) * 2 * (int64_t)a.kp * 32;
+        float *pb = a.part + (int64_t)blockIdx.x * 2 * (int64_t)a.kp * 32;      // [pair = block >> 1][half = block & 1]
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int comp = tid + 256 * g;
@@ -251,7 +268,7 @@ KL_GLOBAL __launch_bounds__(256) void k_q8_monitor(MonArgs a) {
 // What k_post needs to turn the partial sums into the statistic (post.hip.h)
 struct MonPost {
     const float *part;            // [kMonBlocks][2 halves][2][KP][32]; nullptr: no check in this launch
-    const float *spread;          // [kMonBlocks][3][32]
+    const float *spread;          // [2 kMonBlocks][3][32]
     float min_spread;             // threshold on the smallest relative spread of a column's ratios (kMonMinSpread)
     float max_common;             // threshold on a component row's common factor over the tile (kMonMaxCommon)
     int ncols;                    // valid columns of the monitored tile

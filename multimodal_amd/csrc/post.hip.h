@@ -256,8 +256,19 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
         const int q = tid & 127, sub = tid >> 7, nsub = (int)(blockDim.x >> 7);      // q = (half, array, column); blocks dealt over `sub`
         const int half = q >> 6, arr = (q >> 5) & 1, col = q & 31;
         float acc = 0.f;
-        for (int blk = sub; blk < kMonBlocks; blk += nsub)        // fixed order
-            acc += a.mon.part[(((int64_t)blk * 2 + half) * 2 + arr) * (int64_t)a.kp * 32 + (int64_t)comp * 32 + col];
+        // fixed order; 16 loads in flight (one dependent load per trip made this 16 .. 64 round trips: 25 of the 45 us this kernel
+        // took on a monitored iteration -- round 6)
+        constexpr int MU = 16;
+        for (int blk0 = sub; blk0 < kMonBlocks; blk0 += nsub * MU) {
+            float v[MU];
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                const int blk = blk0 + u * nsub;
+                v[u] = blk < kMonBlocks ? a.mon.part[(((int64_t)blk * 2 + half) * 2 + arr) * (int64_t)a.kp * 32 + (int64_t)comp * 32 + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < MU; ++u) acc += v[u];
+        }
         mred[sub][q] = acc;
         __syncthreads();
         if (tid < 128) {
@@ -303,7 +314,7 @@ KL_GLOBAL __launch_bounds__(1024) void k_post(PostArgs a) {
             __shared__ float sp_s[32], sp_g[32][3][32];
             const int ngrp = (int)(blockDim.x >> 5), gi = tid >> 5, ci = tid & 31;      // ngrp = 8, 16 or 32
             {
-                const int per = kMonBlocks / ngrp;
+                const int per = 2 * kMonBlocks / ngrp;                                  // (one entry per block of the monitor launch)
                 float cnt = 0.f, s1 = 0.f, s2 = 0.f;
                 for (int blk = gi * per; blk < (gi + 1) * per; ++blk) {
                     const float *sp = a.mon.spread + (int64_t)blk * 96;

@@ -22,7 +22,6 @@ ap.add_argument('--precision', default='f16')
 args = ap.parse_args()
 d = json.load(open(os.path.join(args.dir, 'traffic_by_kernel.json')))
 if args.kind == 'transform':
-    name = [k for k in d if k.startswith('k_rowpass4') and k.replace(' ', '').endswith(',0,0,0>') is False and ', 0, 1, 8, 0, 0>' in k]
     # the update pass with 16-bit tiles switched off at run time: <KT, ODD, MODE 0, EP, 8 waves, whole rows, Q8 0>
     name = [k for k in d if k.startswith('k_rowpass4') and ', 0, ' in k and k.rstrip('>').endswith('8, 0, 0')]
     name = max(name, key=lambda k: d[k]['launches_per_pass'])
@@ -31,7 +30,7 @@ if args.kind == 'transform':
                           'hbm_bytes_per_launch': d[name]['hbm_bytes_per_launch'], 'read': d[name]['fetch_bytes_corrected'],
                           'written': d[name]['write_bytes'], 'launches': d[name]['launches_per_pass'],
                           'mean_duration_ms_under_pmc': d[name]['mean_duration_ms_under_pmc']}]}
-    path = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_transform.json')
+    path = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic_transform.json')
 else:
     per_it = {}
     steps = None
