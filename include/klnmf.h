@@ -134,11 +134,15 @@ int klnmf_run(klnmf_ctx *ctx, int64_t max_iter, int fit, double tol_abs,
  * the collective between the pieces (sum of the exchange buffers over ranks).
  *   klnmf_loop_begin                          reset prev_error / counters
  *   per iteration:
- *     klnmf_iter_rowpass   loss partial + W update        -> loss exchange
- *     [all-reduce loss exchange]
- *     klnmf_iter_decide    stop rule (nmf.py:214-220)
- *     klnmf_iter_colpass   H numerator W_new^T . Q_old    -> numerator exchange
+ *     klnmf_iter_rowpass   loss partial + W update        -> loss exchange [0]
+ *     [all-reduce loss[0]: may run while the column pass computes]
+ *     klnmf_iter_colpass   H numerator W_new^T . Q_old    -> numerator exchange; its last launch writes loss[1], the count of
+ *                          fp8-monitor trips and unfixable ratio entries of this iteration
  *     [all-reduce numerator exchange]
+ *     [all-reduce loss[1] -- BEHIND klnmf_iter_colpass, never together with loss[0] in front of it -- on the iterations for
+ *      which klnmf_query(KLNMF_Q_FP8_POLL_DUE) answers 1: the klnmf_iter_advance below then polls the sum, and every rank
+ *      leaves the fp8 regime in the same iteration]
+ *     klnmf_iter_decide    stop rule (nmf.py:214-220) on loss[0]
  *     klnmf_iter_update_H  H * num, row-normalise (nmf.py:349-350)
  *     klnmf_iter_advance   swap the W_old / W_new buffers
  *   klnmf_loop_end         sync, fetch errors / counters
