@@ -613,3 +613,26 @@ def test_bench_native_path_at_one_ranks_shard_of_configuration_4_with_monitor_po
     fp8 = cfg['fp8']
     assert fp8['timed_iterations_with_fp8_ratio_tiles'] == 20 and fp8['timed_iterations_with_fp8_x_fp8_column_pass'] == 20
     assert fp8['monitor_checks'] == 6 and fp8['monitor_trips'] == 0 and not fp8['gave_up'], fp8
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_in_the_fp8_regime():
+    """bench.py's N > 1 path on the torch-sequenced loop with BOTH ranks' shards large enough for fp8 ratio tiles (2 x 40 000
+    rows): the timed iterations run on the tiles on every rank, the monitor's polls (loss[1] exchanged behind the column pass:
+    distributed.py) happen inside the timed region, and the line is valid."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KLNMF_BENCH_REHEARSAL='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '12', '--warmup', '3',
+           '--repeats', '2', '--rows', '80000', '--features', '256', '--components', '40', '--no-cpu-baseline', '--no-16bit-segment']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    cfg = d['config']
+    assert d['n_gpus'] == 2 and d['valid'] and d['loss_finite_and_decreasing'] and cfg['rows_per_gpu'] == 40000
+    assert cfg['collective_path'] == 'torch'
+    fp8 = cfg['fp8']
+    assert fp8['loop_allowed'] and fp8['timed_iterations_with_fp8_ratio_tiles'] == 12 and not fp8['gave_up'] and fp8['monitor_checks'] >= 4, fp8

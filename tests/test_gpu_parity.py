@@ -1475,3 +1475,34 @@ def test_stop_rule_inside_the_fused_launch_matches_the_oracle():
             assert_allclose(errors, eo, rtol=1e-4)
             assert np.abs(m.components_ - Ho).max() <= 5e-3 * Ho.max()
             assert np.abs(W - Wo).max() <= 5e-3 * Wo.max()
+
+
+def test_profile_events_can_sample_every_nth_iteration():
+    """klnmf_profile_enable(ctx, N): HIP events bracket the row- and column-pass launches of every N-th iteration of a loop (an
+    event record is a stream packet of its own: four per iteration were 1.7 % of one rank's shard iteration, so bench.py samples
+    every 4th since round 6); N = 1 / True: every iteration's, as before.  The results do not depend on it."""
+    n, f, k, iters = 3000, 256, 24, 8
+    X = orc.synthetic_V(3, n, f, 12)
+    H0 = orc.synthetic_H0(3, f, k)
+    out = {}
+    for every in (True, 4, 3):
+        with _native.Context('f16', device=0) as ctx:
+            ctx.set_problem(n, f, k, iters)
+            ctx.upload_blocks([X])
+            ctx.set_H(H0)
+            ctx.init_W()
+            ctx.loop_begin()
+            ctx.profile_enable(every)
+            ctx.run_more(iters, True, 0.0)
+            prof = ctx.profile_read(reset=True)
+            ctx.profile_enable(False)
+            e, nd, st = ctx.loop_end(iters)
+            out[every] = (prof, np.asarray(e), ctx.get_W(), ctx.get_H())
+    assert out[True][0]['rowpass_launches'] == iters and out[True][0]['colpass_launches'] == iters
+    assert out[4][0]['rowpass_launches'] == 2 and out[4][0]['colpass_launches'] == 2            # iterations 0 and 4
+    assert out[3][0]['rowpass_launches'] == 3 and out[3][0]['colpass_launches'] == 3            # iterations 0, 3 and 6
+    assert out[4][0]['rowpass_ms'] > 0 and out[4][0]['colpass_ms'] > 0
+    for every in (4, 3):
+        np.testing.assert_array_equal(out[every][1], out[True][1])
+        np.testing.assert_array_equal(out[every][2], out[True][2])
+        np.testing.assert_array_equal(out[every][3], out[True][3])
