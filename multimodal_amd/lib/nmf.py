@@ -309,7 +309,10 @@ class KLdivNMF(object):
         with KL / sum(V) below `F16_MIN_KL_OVER_SUM_V` is reported in `last_fp8_report` and said once on stderr (the shape
         half is `resolve_precision`'s).  No reference counterpart (nmf.py has one arithmetic)."""
         rep = self.last_fp8_report
-        if rep is None or ctx.precision != _native.PREC_BF16:
+        if rep is None:
+            return
+        if ctx.precision != _native.PREC_BF16:
+            rep['outside_f16_envelope'] = None      # (not a 16-bit loop: the key is there, the question does not arise)
             return
         r = rep.get('kl_over_sum_v', -1.0)
         reasons = []
