@@ -5,6 +5,7 @@
 #   3  interleaved A/B against round 5's tree (ab/r05tree: its bench.py + host layer + library) at the C4 shard, C4, C2, C3, the C5 shard;
 #      per-iteration times of the shard (single context and the native collective branch); timelines; transform bench
 #   4  (after scripts/pmc_traffic_fit_collect.py + pmc_traffic_collect.py wrote profiles/r06_pmc_traffic*.json) the bench lines that carry the traffic
+#   5  the counter groups of configuration 2 (what holds the HBM-bound configuration below its roof)
 # Output: gpurun_out/$TAG/.
 TAG=${1:-r06_final}
 PART=${2:-1}
@@ -53,6 +54,10 @@ case $PART in
   cd $R
   rm -rf $O/tl_shard $O/tl_c2 $O/tl_c3 $O/tl_c5shard
   timeout -k 10 300 python3 bench.py --workload transform > $O/bench_transform.json 2> $O/bench_transform.err; echo "transform rc=$?"
+  ;;
+5)
+  # the instruction-mix / busy counter groups of configuration 2's row pass (profiles/r06_pmc_summary_c2.txt)
+  bash scripts/pmc_profile.sh $TAG/pmc_mix_c2 --rows 50000 --components 50 $B > /dev/null 2>&1; echo "pmc mix c2 rc=$?"
   ;;
 4)
   timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
